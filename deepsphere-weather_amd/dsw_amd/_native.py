@@ -1,0 +1,77 @@
+"""ctypes binding of ``libdsw_hip.so`` (C ABI declared in ``include/dsw_hip.h``).
+
+The library is built in-tree (``__graft_entry__.build()`` or ``python -m dsw_amd.build``) next to
+this file.  There is NO fallback: if the shared object is missing or a symbol cannot be
+resolved, importing the compute path raises - a GPU box must run the HIP kernels or fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdsw_hip.so")
+
+DSW_F32 = 0
+DSW_BF16 = 1
+
+_i32p = ctypes.c_void_p
+_f32p = ctypes.c_void_p
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_f32 = ctypes.c_float
+_int = ctypes.c_int
+
+# name -> (restype, argtypes): exactly the declarations of include/dsw_hip.h
+SIGNATURES = {
+    "dsw_version": (_int, []),
+    "dsw_strerror": (ctypes.c_char_p, [_int]),
+    "dsw_spmm_csr": (
+        _int,
+        [_i32p, _i32p, _f32p, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _f32, _vp, _f32, _vp, _f32, _int, _vp],
+    ),
+    "dsw_cheb_basis_fwd": (_int, [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _int, _vp]),
+    "dsw_cheb_mix_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp]),
+    "dsw_cheb_fwd": (
+        _int,
+        [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp],
+    ),
+    "dsw_cheb_bwd_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64, _i64, _int]),
+    "dsw_cheb_bwd": (
+        _int,
+        [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
+         _i64, _int, _vp],
+    ),
+}
+
+_lib = None
+
+
+class DswNativeError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library with typed entry points."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DswNativeError(
+            f"{LIB_PATH} not found: the HIP library has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` at the repo root). "
+            "There is no CPU/PyTorch fallback for the dsw hot path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().dsw_strerror(int(rc)).decode()
+        raise DswNativeError(f"{what} failed: {msg} (code {rc})")

@@ -1,0 +1,40 @@
+"""Build ``libdsw_hip.so`` in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "csrc")
+SOURCES = ["dsw_api.hip", "dsw_spmm.hip", "dsw_gemm.hip"]
+OUT = os.path.join(HERE, "libdsw_hip.so")
+
+
+def hipcc_path():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps.append(os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "dsw_hip.h"))
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return OUT
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", OUT]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print("[dsw build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

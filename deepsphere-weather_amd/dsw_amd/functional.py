@@ -1,0 +1,298 @@
+"""Host side of the hot path: operator caches and ``torch.autograd.Function`` wrappers that call the
+C ABI of ``libdsw_hip.so`` on the current HIP stream.
+
+PyTorch is plumbing here (device memory, streams, autograd graph); every FLOP and byte of the path
+runs in the hand-written gfx950 kernels under ``csrc/``.  CPU tensors are rejected: there is no
+fallback implementation in the product.  (Tests may inject a checker backend with
+``set_test_backend`` to exercise the host logic on CPU; nothing in the package does.)
+"""
+from __future__ import annotations
+
+import weakref
+
+import torch
+
+from . import _native
+
+__all__ = [
+    "CsrOperator",
+    "get_operator",
+    "cheb_conv",
+    "sparse_remap",
+    "cheb_basis",
+    "set_test_backend",
+]
+
+_DTYPES = {torch.float32: _native.DSW_F32, torch.bfloat16: _native.DSW_BF16}
+
+
+# ----------------------------------------------------------------------------------------------
+# Operator: device CSR (+ lazily, CSR of the transpose) derived from a torch sparse COO buffer
+# ----------------------------------------------------------------------------------------------
+class CsrOperator:
+    """int32 CSR + fp32 values of a sparse operator, resident on the operator's device.
+
+    Derived *cache* of the module's sparse-COO buffer (which stays the state_dict citizen, as in
+    the reference ``modules/layers.py:241,954``).  Values are widened to fp32 whatever the
+    buffer dtype is: the kernels keep operator and accumulators in fp32.
+    """
+
+    def __init__(self, rowptr, colind, values, shape):
+        self.rowptr = rowptr
+        self.colind = colind
+        self.values = values
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.nnz = int(colind.numel())
+        self._t = None
+
+    @classmethod
+    def from_sparse_coo(cls, mat: torch.Tensor) -> "CsrOperator":
+        if mat.layout != torch.sparse_coo:
+            raise TypeError("expected a torch sparse COO tensor")
+        if mat.dim() != 2:
+            raise ValueError("operator must be 2-D")
+        if not mat.is_coalesced():
+            mat = mat.coalesce()
+        idx = mat.indices()
+        nrow, ncol = mat.shape
+        if nrow >= 2**31 or ncol >= 2**31 or idx.shape[1] >= 2**31:
+            raise ValueError("operator too large for int32 CSR")
+        # coalesced COO is sorted row-major (checked by the golden fixture G4), i.e. CSR-ready
+        rowptr = torch._convert_indices_from_coo_to_csr(idx[0], nrow, out_int32=True)
+        colind = idx[1].to(torch.int32).contiguous()
+        values = mat.values().to(torch.float32).contiguous()
+        return cls(rowptr, colind, values, (nrow, ncol))
+
+    @property
+    def device(self):
+        return self.values.device
+
+    def transpose(self) -> "CsrOperator":
+        """CSR of the transposed operator (built once, on first backward)."""
+        if self._t is None:
+            nrow, ncol = self.shape
+            counts = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
+            rows = torch.repeat_interleave(
+                torch.arange(nrow, device=self.device, dtype=torch.int64), counts
+            )
+            cols = self.colind.to(torch.int64)
+            order = torch.argsort(cols * nrow + rows)
+            t_rows = cols[order]
+            t_rowptr = torch._convert_indices_from_coo_to_csr(t_rows, ncol, out_int32=True)
+            t = CsrOperator(
+                t_rowptr, rows[order].to(torch.int32).contiguous(), self.values[order].contiguous(),
+                (ncol, nrow),
+            )
+            t._t = self
+            self._t = t
+        return self._t
+
+
+_op_cache: dict = {}
+
+
+def get_operator(mat: torch.Tensor) -> CsrOperator:
+    """CSR cache keyed on the sparse buffer's identity / version / device / dtype.
+
+    ``model.to(device)`` and dtype casts create new tensors (new id); ``load_state_dict`` copies
+    in place and bumps ``_version`` - both invalidate the entry.
+    """
+    key = id(mat)
+    sig = (mat._version, mat.device, mat.dtype, tuple(mat.shape))
+    hit = _op_cache.get(key)
+    if hit is not None and hit[0]() is mat and hit[1] == sig:
+        return hit[2]
+    op = CsrOperator.from_sparse_coo(mat)
+
+    def _evict(_ref, key=key):
+        _op_cache.pop(key, None)
+
+    _op_cache[key] = (weakref.ref(mat, _evict), sig, op)
+    return op
+
+
+# ----------------------------------------------------------------------------------------------
+# Backends: the HIP library (product) and an injectable checker (tests only)
+# ----------------------------------------------------------------------------------------------
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class _HipBackend:
+    """Thin tensor-level wrapper over the C ABI (include/dsw_hip.h)."""
+
+    name = "hip"
+
+    def spmm(self, op, x, alpha=1.0, z=None, beta=0.0, z2=None, gamma=0.0, out=None):
+        lib = _native.load()
+        B, v_in, C = x.shape
+        assert v_in == op.shape[1]
+        y = out if out is not None else torch.empty((B, op.shape[0], C), dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.dsw_spmm_csr(
+                op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), op.shape[0], op.shape[1],
+                op.nnz, x.data_ptr(), y.data_ptr(), B, C, alpha, _ptr(z), beta, _ptr(z2), gamma,
+                _DTYPES[x.dtype], _stream(x),
+            )
+        _native.check(rc, "dsw_spmm_csr")
+        return y
+
+    def cheb_basis(self, op, x, K):
+        lib = _native.load()
+        B, V, C = x.shape
+        T = torch.empty((max(K - 1, 0), B, V, C), dtype=x.dtype, device=x.device)
+        if K > 1:
+            with torch.cuda.device(x.device):
+                rc = lib.dsw_cheb_basis_fwd(
+                    op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz,
+                    x.data_ptr(), T.data_ptr(), B, C, K, _DTYPES[x.dtype], _stream(x),
+                )
+            _native.check(rc, "dsw_cheb_basis_fwd")
+        return T
+
+    def cheb_fwd(self, op, x, w, bias):
+        lib = _native.load()
+        B, V, Fin = x.shape
+        _, K, Fout = w.shape
+        y = torch.empty((B, V, Fout), dtype=x.dtype, device=x.device)
+        T = torch.empty((K - 1, B, V, Fin), dtype=x.dtype, device=x.device) if K > 1 else None
+        with torch.cuda.device(x.device):
+            rc = lib.dsw_cheb_fwd(
+                op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz,
+                x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(T), B, Fin, Fout, K,
+                _DTYPES[x.dtype], _stream(x),
+            )
+        _native.check(rc, "dsw_cheb_fwd")
+        return y, T
+
+    def cheb_bwd(self, op, x, T, w, dy, need_dx, need_dw, need_db):
+        lib = _native.load()
+        B, V, Fin = x.shape
+        _, K, Fout = w.shape
+        dt = _DTYPES[x.dtype]
+        dx = torch.empty_like(x) if need_dx else None
+        want_w = need_dw or need_db
+        dw = torch.empty_like(w) if want_w else None
+        db = torch.empty((Fout,), dtype=w.dtype, device=w.device) if want_w else None
+        nbytes = int(lib.dsw_cheb_bwd_workspace_bytes(B, V, Fin, Fout, K, dt))
+        if nbytes < 0:
+            _native.check(nbytes, "dsw_cheb_bwd_workspace_bytes")
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+        opt = op.transpose() if (need_dx and K > 1) else op
+        with torch.cuda.device(x.device):
+            rc = lib.dsw_cheb_bwd(
+                opt.rowptr.data_ptr(), opt.colind.data_ptr(), opt.values.data_ptr(), V, opt.nnz,
+                x.data_ptr(), _ptr(T), w.data_ptr(), dy.data_ptr(), _ptr(dx), _ptr(dw), _ptr(db),
+                ws.data_ptr(), nbytes, B, Fin, Fout, K, dt, _stream(x),
+            )
+        _native.check(rc, "dsw_cheb_bwd")
+        return dx, (dw if need_dw else None), (db if need_db else None)
+
+
+_HIP = _HipBackend()
+_test_backend = None
+
+
+def set_test_backend(backend):
+    """TEST-ONLY hook: backend used for non-CUDA tensors (``None`` restores the strict default).
+
+    The product never calls this.  It exists so that the host logic (autograd wiring, module
+    plumbing, DDP sharding) can be exercised on CPU with the oracle standing in as the checker.
+    """
+    global _test_backend
+    _test_backend = backend
+
+
+def _backend_for(t: torch.Tensor):
+    if t.is_cuda:
+        return _HIP
+    if _test_backend is not None:
+        return _test_backend
+    raise RuntimeError(
+        "dsw: the ConvCheb / RemapBlock hot path runs only on a ROCm device (got a "
+        f"{t.device.type} tensor). There is no CPU fallback; move the model and inputs to 'cuda'."
+    )
+
+
+def _check_dtype(*tensors):
+    dt = tensors[0].dtype
+    if dt not in _DTYPES:
+        raise TypeError(f"dsw: unsupported dtype {dt}; the HIP path implements float32 and bfloat16")
+    for t in tensors[1:]:
+        if t is not None and t.dtype != dt:
+            raise TypeError(f"dsw: mixed dtypes {dt} vs {t.dtype}")
+
+
+# ----------------------------------------------------------------------------------------------
+# autograd Functions
+# ----------------------------------------------------------------------------------------------
+class _ChebConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, op):
+        be = _backend_for(x)
+        xc = x.contiguous()
+        wc = weight.contiguous()
+        bc = None if bias is None else bias.contiguous()
+        y, T = be.cheb_fwd(op, xc, wc, bc)
+        # the output is NOT saved: callers modify it in place (layers.py:375, my_models_graph.py:213)
+        ctx.save_for_backward(xc, wc, T)
+        ctx.op = op
+        ctx.has_bias = bias is not None
+        ctx.be = be
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        xc, wc, T = ctx.saved_tensors
+        need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], (
+            ctx.has_bias and ctx.needs_input_grad[2]
+        )
+        dx, dw, db = ctx.be.cheb_bwd(ctx.op, xc, T, wc, dy.contiguous(), need_dx, need_dw, need_db)
+        return dx, dw, db, None
+
+
+class _RemapFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, op):
+        be = _backend_for(x)
+        ctx.op = op
+        ctx.be = be
+        return be.spmm(op, x.contiguous())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        return ctx.be.spmm(ctx.op.transpose(), dy.contiguous()), None
+
+
+def cheb_conv(op: CsrOperator, x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
+    """``Y = sum_k T_k(L) x W_k (+ bias)`` for node-major ``x [B, V, Fin]``, ``weight [Fin, K, Fout]``."""
+    if x.dim() != 3 or weight.dim() != 3:
+        raise ValueError("expected inputs [B, V, Fin] and weight [Fin, K, Fout]")
+    if x.shape[1] != op.shape[1] or op.shape[0] != op.shape[1]:
+        raise ValueError(
+            f"operator shape {op.shape} does not match the {x.shape[1]} nodes of the input"
+        )
+    _check_dtype(x, weight, bias)
+    return _ChebConvFn.apply(x, weight, bias, op)
+
+
+def sparse_remap(op: CsrOperator, x: torch.Tensor) -> torch.Tensor:
+    """``Y[b, d, f] = sum_v M[d, v] X[b, v, f]`` (pooling / unpooling), output contiguous [B, Vd, F]."""
+    if x.dim() != 3:
+        raise ValueError("expected input [B, V, F]")
+    if x.shape[1] != op.shape[1]:
+        raise ValueError(f"remap matrix has {op.shape[1]} source nodes, input has {x.shape[1]}")
+    _check_dtype(x)
+    return _RemapFn.apply(x, op)
+
+
+def cheb_basis(op: CsrOperator, x: torch.Tensor, K: int) -> torch.Tensor:
+    """``T_1 .. T_{K-1}`` as ``[K-1, B, V, C]`` (no autograd; used by benchmarks and tests)."""
+    _check_dtype(x)
+    return _backend_for(x).cheb_basis(op, x.contiguous(), K)

@@ -1,0 +1,300 @@
+"""Spherical samplings -> k-NN graphs -> normalized Laplacians and pooling matrices.
+
+Host-side (numpy / scipy) builder of the *operators* the hot path consumes.  The
+reference gets these from the un-vendored ``pygsp@sphere-graphs`` package
+(``/root/reference/modules/models.py:43-46``, ``modules/utils_models.py:11-20``) and,
+for interpolation pooling, from ``xsphere`` + the CDO binary
+(``/root/reference/modules/layers.py:531-581``).  None of those are available, so this
+module provides self-contained stand-ins written from the public HEALPix geometry
+(Gorski et al. 2005) and a plain symmetrised k-NN Gaussian graph.
+
+PARITY UNPINNED: the edge weights are *not* claimed to equal pygsp's (which uses a
+per-(k, nside) optimal kernel width table) nor CDO's conservative remap weights.  Only
+the structure (k-NN stencil, symmetric normalized Laplacian, row-stochastic pooling
+matrices satisfying the invariants asserted at ``modules/layers.py:540-571``) matches.
+Everything downstream (ConvCheb, RemapBlock) takes the operator as an input, so parity
+tests always feed the *same prepared operator* to reference and build.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy import sparse
+from scipy.spatial import cKDTree
+
+__all__ = [
+    "healpix_pix2vec",
+    "healpix_nest2ring",
+    "equiangular_vec",
+    "knn_graph_laplacian",
+    "SphereHealpix",
+    "SphereEquiangular",
+    "healpix_pool_matrices",
+    "equiangular_pool_matrices",
+    "knn_interp_pool_matrices",
+    "build_pooling_matrices",
+]
+
+_JRLL = np.array([2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4], dtype=np.int64)
+_JPLL = np.array([1, 3, 5, 7, 0, 2, 4, 6, 1, 3, 5, 7], dtype=np.int64)
+
+
+def _compress_bits(v: np.ndarray) -> np.ndarray:
+    """Keep the even bits of ``v`` and pack them (inverse of Morton spreading)."""
+    v = v & 0x5555555555555555
+    v = (v | (v >> 1)) & 0x3333333333333333
+    v = (v | (v >> 2)) & 0x0F0F0F0F0F0F0F0F
+    v = (v | (v >> 4)) & 0x00FF00FF00FF00FF
+    v = (v | (v >> 8)) & 0x0000FFFF0000FFFF
+    v = (v | (v >> 16)) & 0x00000000FFFFFFFF
+    return v
+
+
+def _nest2xyf(nside: int, pix: np.ndarray):
+    npface = nside * nside
+    face = pix // npface
+    p = pix % npface
+    ix = _compress_bits(p)
+    iy = _compress_bits(p >> 1)
+    return ix, iy, face
+
+
+def _xyf2loc(nside: int, ix, iy, face):
+    """(x, y, face) -> (z, phi) following the HEALPix base-pixel geometry."""
+    npix = 12 * nside * nside
+    fact2 = 4.0 / npix
+    fact1 = (2 * nside) * fact2
+    jr = _JRLL[face] * nside - ix - iy - 1
+    north = jr < nside
+    south = jr > 3 * nside
+    nr = np.where(north, jr, np.where(south, 4 * nside - jr, nside))
+    z = np.where(
+        north,
+        1.0 - nr.astype(np.float64) ** 2 * fact2,
+        np.where(south, nr.astype(np.float64) ** 2 * fact2 - 1.0, (2 * nside - jr) * fact1),
+    )
+    kshift = np.where(north | south, 0, (jr - nside) & 1)
+    jp = (_JPLL[face] * nr + ix - iy + 1 + kshift) // 2
+    jp = np.where(jp > 4 * nr, jp - 4 * nr, jp)
+    jp = np.where(jp < 1, jp + 4 * nr, jp)
+    phi = (jp - (kshift + 1) * 0.5) * (np.pi / 2.0 / nr)
+    return z, phi, jr, jp, nr
+
+
+def _ring2loc(nside: int, pix: np.ndarray):
+    npix = 12 * nside * nside
+    ncap = 2 * nside * (nside - 1)
+    fact2 = 4.0 / npix
+    fact1 = (2 * nside) * fact2
+    z = np.empty(pix.shape, dtype=np.float64)
+    phi = np.empty(pix.shape, dtype=np.float64)
+    # north polar cap
+    m = pix < ncap
+    p = pix[m]
+    iring = (1 + np.floor(np.sqrt(1 + 2 * p)).astype(np.int64)) >> 1
+    iphi = p + 1 - 2 * iring * (iring - 1)
+    z[m] = 1.0 - iring.astype(np.float64) ** 2 * fact2
+    phi[m] = (iphi - 0.5) * (np.pi / 2.0) / iring
+    # equatorial belt
+    m = (pix >= ncap) & (pix < npix - ncap)
+    ip = pix[m] - ncap
+    tmp = ip // (4 * nside)
+    iring = tmp + nside
+    iphi = ip - 4 * nside * tmp + 1
+    fodd = np.where(((iring + nside) & 1) == 1, 1.0, 0.5)
+    z[m] = (2 * nside - iring) * fact1
+    phi[m] = (iphi - fodd) * (np.pi / 2.0) / nside
+    # south polar cap
+    m = pix >= npix - ncap
+    ip = npix - pix[m]
+    iring = (1 + np.floor(np.sqrt(2 * ip - 1)).astype(np.int64)) >> 1
+    iphi = 4 * iring + 1 - (ip - 2 * iring * (iring - 1))
+    z[m] = -1.0 + iring.astype(np.float64) ** 2 * fact2
+    phi[m] = (iphi - 0.5) * (np.pi / 2.0) / iring
+    return z, phi
+
+
+def healpix_pix2vec(nside: int, nest: bool = True) -> np.ndarray:
+    """Unit vectors ``[12*nside**2, 3]`` of all HEALPix pixel centres."""
+    if nside < 1 or (nside & (nside - 1)) != 0:
+        raise ValueError("nside must be a power of two")
+    pix = np.arange(12 * nside * nside, dtype=np.int64)
+    if nest:
+        ix, iy, face = _nest2xyf(nside, pix)
+        z, phi, *_ = _xyf2loc(nside, ix, iy, face)
+    else:
+        z, phi = _ring2loc(nside, pix)
+    st = np.sqrt(np.clip(1.0 - z * z, 0.0, None))
+    return np.stack([st * np.cos(phi), st * np.sin(phi), z], axis=1)
+
+
+def healpix_nest2ring(nside: int) -> np.ndarray:
+    """``ring_index[nest_index]`` permutation for all pixels."""
+    pix = np.arange(12 * nside * nside, dtype=np.int64)
+    ix, iy, face = _nest2xyf(nside, pix)
+    _, _, jr, jp, nr = _xyf2loc(nside, ix, iy, face)
+    ncap = 2 * nside * (nside - 1)
+    npix = 12 * nside * nside
+    north = jr < nside
+    south = jr > 3 * nside
+    n_before = np.where(
+        north,
+        2 * nr * (nr - 1),
+        np.where(south, npix - 2 * (nr + 1) * nr, ncap + (jr - nside) * 4 * nside),
+    )
+    return n_before + jp - 1
+
+
+def equiangular_vec(nlat: int, nlon: int):
+    """Cell-centre unit vectors of an equiangular grid, row-major (lat, lon)."""
+    lat = np.pi / 2.0 - (np.arange(nlat) + 0.5) * np.pi / nlat
+    lon = np.arange(nlon) * 2.0 * np.pi / nlon
+    lat2, lon2 = np.meshgrid(lat, lon, indexing="ij")
+    lat2 = lat2.ravel()
+    lon2 = lon2.ravel()
+    xyz = np.stack(
+        [np.cos(lat2) * np.cos(lon2), np.cos(lat2) * np.sin(lon2), np.sin(lat2)], axis=1
+    )
+    return xyz, lat2, lon2
+
+
+def knn_graph_laplacian(coords: np.ndarray, k: int, lap_type: str = "normalized"):
+    """Symmetrised k-NN Gaussian graph and its Laplacian (scipy CSR, float64).
+
+    Weight ``exp(-d^2 / (2 s^2))`` with ``s^2`` the mean squared k-NN distance;
+    symmetrisation keeps an edge if either endpoint selected it (so degrees are >= k
+    and irregular where the sampling is anisotropic, e.g. equiangular poles).
+    """
+    n = coords.shape[0]
+    tree = cKDTree(coords)
+    dist, idx = tree.query(coords, k=k + 1)
+    dist = dist[:, 1:]
+    idx = idx[:, 1:]
+    s2 = float(np.mean(dist**2))
+    w = np.exp(-(dist**2) / (2.0 * s2))
+    rows = np.repeat(np.arange(n), k)
+    W = sparse.csr_matrix((w.ravel(), (rows, idx.ravel())), shape=(n, n))
+    W = W.maximum(W.T).tocsr()
+    W.setdiag(0)
+    W.eliminate_zeros()
+    d = np.asarray(W.sum(axis=1)).ravel()
+    if lap_type == "combinatorial":
+        L = sparse.diags(d) - W
+    elif lap_type == "normalized":
+        dinv = 1.0 / np.sqrt(d)
+        L = sparse.identity(n) - sparse.diags(dinv) @ W @ sparse.diags(dinv)
+    else:
+        raise ValueError("unknown lap_type")
+    L = sparse.csr_matrix(L)
+    L.sort_indices()
+    return W, L
+
+
+class _SphereGraph:
+    """Minimal stand-in for the pygsp graph objects the reference touches:
+    ``.L``, ``.W``, ``.n_vertices``, ``.coords``, ``.signals['lat'|'lon']``
+    (``/root/reference/modules/models.py:54``, ``modules/layers.py:540-543``)."""
+
+    def __init__(self, coords, k, lap_type):
+        self.coords = coords
+        self.n_vertices = coords.shape[0]
+        self.k = k
+        self.lap_type = lap_type
+        self.W, self.L = knn_graph_laplacian(coords, k, lap_type)
+        lat = np.degrees(np.arcsin(np.clip(coords[:, 2], -1, 1)))
+        lon = np.degrees(np.arctan2(coords[:, 1], coords[:, 0])) % 360.0
+        self.signals = {"lat": lat, "lon": lon}
+
+
+class SphereHealpix(_SphereGraph):
+    """HEALPix k-NN graph (``subdivisions`` = nside), nested or ring order."""
+
+    def __init__(self, subdivisions=2, nest=False, k=20, lap_type="normalized", **kwargs):
+        self.subdivisions = int(subdivisions)
+        self.nest = bool(nest)
+        super().__init__(healpix_pix2vec(self.subdivisions, self.nest), k, lap_type)
+
+
+class SphereEquiangular(_SphereGraph):
+    """Equiangular (nlat x nlon) k-NN graph; irregular degree near the poles."""
+
+    def __init__(self, nlat=36, nlon=72, poles=0, k=20, lap_type="normalized", **kwargs):
+        self.nlat = int(nlat)
+        self.nlon = int(nlon)
+        coords, _, _ = equiangular_vec(self.nlat, self.nlon)
+        super().__init__(coords, k, lap_type)
+
+
+def healpix_pool_matrices(nside_fine: int, nest: bool = True):
+    """Exact-hierarchy HEALPix pooling (4 children x 0.25) / unpooling (x 1.0).
+
+    Returns scipy COO ``(pool [V/4, V], unpool [V, V/4])`` in the requested ordering.
+    """
+    nside_c = nside_fine // 2
+    vf = 12 * nside_fine**2
+    vc = 12 * nside_c**2
+    child = np.arange(vf, dtype=np.int64)
+    parent = child // 4
+    if not nest:
+        child = healpix_nest2ring(nside_fine)[child]
+        parent = healpix_nest2ring(nside_c)[parent]
+    pool = sparse.coo_matrix((np.full(vf, 0.25), (parent, child)), shape=(vc, vf))
+    unpool = sparse.coo_matrix((np.ones(vf), (child, parent)), shape=(vf, vc))
+    return pool, unpool
+
+
+def equiangular_pool_matrices(nlat: int, nlon: int, c: int = 2):
+    """Area-weighted (cos-latitude band) conservative c x c block pooling."""
+    nlat_c, nlon_c = nlat // c, nlon // c
+    edges = np.pi / 2.0 - np.arange(nlat + 1) * np.pi / nlat
+    band = np.sin(edges[:-1]) - np.sin(edges[1:])  # cell area ~ band area / nlon
+    i, j = np.meshgrid(np.arange(nlat), np.arange(nlon), indexing="ij")
+    src = (i * nlon + j).ravel()
+    dst = ((i // c) * nlon_c + (j // c)).ravel()
+    area = band[i.ravel()]
+    weights = sparse.csr_matrix((area, (dst, src)), shape=(nlat_c * nlon_c, nlat * nlon))
+    return _normalise_pool_unpool(weights)
+
+
+def knn_interp_pool_matrices(src_coords, dst_coords, k: int = 6):
+    """Generic overlap-like interpolation weights between two samplings.
+
+    Each coarse (dst) cell collects its ``k`` nearest fine (src) cells with a
+    compact kernel weight; used where no exact hierarchy exists.  Not CDO-conservative
+    (parity unpinned) but rectangular, irregular and row-normalised like the real thing.
+    """
+    tree = cKDTree(src_coords)
+    dist, idx = tree.query(dst_coords, k=k)
+    h = dist[:, -1:] * 1.0001
+    w = np.clip(1.0 - (dist / h) ** 2, 1e-6, None)
+    rows = np.repeat(np.arange(dst_coords.shape[0]), k)
+    weights = sparse.csr_matrix(
+        (w.ravel(), (rows, idx.ravel())), shape=(dst_coords.shape[0], src_coords.shape[0])
+    )
+    # make sure every source cell is covered (column sums > 0) for the unpool normalisation
+    covered = np.asarray(weights.sum(axis=0)).ravel() > 0
+    if not covered.all():
+        miss = np.nonzero(~covered)[0]
+        _, near = cKDTree(dst_coords).query(src_coords[miss], k=1)
+        weights = weights + sparse.csr_matrix(
+            (np.full(miss.size, 0.5), (near, miss)), shape=weights.shape
+        )
+    return _normalise_pool_unpool(sparse.csr_matrix(weights))
+
+
+def _normalise_pool_unpool(weights):
+    """Same normalisation as ``/root/reference/modules/layers.py:576-581``."""
+    pool = weights.multiply(1.0 / weights.sum(1))
+    unpool = weights.multiply(1.0 / weights.sum(0)).T
+    return sparse.coo_matrix(pool), sparse.coo_matrix(unpool)
+
+
+def build_pooling_matrices(src_graph, dst_graph):
+    """Build (pool, unpool) between two graphs of this module (src = finer)."""
+    if isinstance(src_graph, SphereHealpix) and isinstance(dst_graph, SphereHealpix):
+        if src_graph.subdivisions == 2 * dst_graph.subdivisions and src_graph.nest == dst_graph.nest:
+            return healpix_pool_matrices(src_graph.subdivisions, src_graph.nest)
+    if isinstance(src_graph, SphereEquiangular) and isinstance(dst_graph, SphereEquiangular):
+        c = src_graph.nlat // dst_graph.nlat
+        if c >= 1 and dst_graph.nlat * c == src_graph.nlat and dst_graph.nlon * c == src_graph.nlon:
+            return equiangular_pool_matrices(src_graph.nlat, src_graph.nlon, c)
+    return knn_interp_pool_matrices(src_graph.coords, dst_graph.coords)

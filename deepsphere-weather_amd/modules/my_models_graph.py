@@ -1,0 +1,249 @@
+"""Spherical residual U-Net on the HIP ConvCheb / interpolation-pooling layers.
+
+Counterpart of ``/root/reference/modules/my_models_graph.py`` (ConvBlock ``:26-118``, ResBlock
+``:121-216``, UNetSpherical ``:220-564``): same constructor signatures, config keys, sub-module /
+parameter / buffer names (``conv1.convblock1.conv.weight``, ``conv1.rezero_weight``,
+``conv1.res_connection.weight``, ``pool1.remap_matrix`` ...) and forward semantics, so that
+checkpoints and the JSON configs of the reference load unchanged.  Pinned by fixture G5.
+"""
+from typing import Dict
+
+import numpy as np
+import torch
+from torch.nn import BatchNorm1d, Identity, Linear
+from torch.nn import functional as F
+
+from modules.layers import GeneralConvBlock, PoolUnpoolBlock
+from modules.models import UNet
+from modules.utils_models import (
+    check_conv_type,
+    check_pool_method,
+    check_sampling,
+    check_skip_connection,
+    pygsp_graph_coarsening,
+)
+
+_CANONICAL_DIMS = ("sample", "node", "time", "feature")
+
+
+class ConvBlock(GeneralConvBlock):
+    """conv -> [batch-norm] -> activation -> [batch-norm] on ``(sample, node, channel)`` tensors.
+
+    With ``batch_norm`` the convolution carries no bias; ``batch_norm_before_activation`` selects on
+    which side of the activation the normalisation sits.
+    """
+
+    def __init__(
+        self,
+        in_channels,
+        out_channels,
+        laplacian,
+        kernel_size=3,
+        conv_type="graph",
+        bias=True,
+        batch_norm=False,
+        batch_norm_before_activation=False,
+        activation=True,
+        activation_fun="relu",
+        periodic_padding=True,
+        lonlat_ratio=2,
+    ):
+        super().__init__()
+        self.conv = GeneralConvBlock.getConvLayer(
+            in_channels=in_channels,
+            out_channels=out_channels,
+            kernel_size=kernel_size,
+            laplacian=laplacian,
+            conv_type=conv_type,
+            bias=bias and not batch_norm,
+            periodic_padding=periodic_padding,
+            lonlat_ratio=lonlat_ratio,
+        )
+        if batch_norm:
+            self.bn = BatchNorm1d(out_channels)
+        self.norm = batch_norm
+        self.bn_before_act = batch_norm_before_activation
+        self.act = activation
+        self.act_fun = getattr(F, activation_fun)
+
+    def _normalise(self, x):
+        return self.bn(x.transpose(1, 2)).transpose(1, 2)  # BatchNorm1d wants (sample, channel, node)
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.norm and self.bn_before_act:
+            x = self._normalise(x)
+        if self.act:
+            x = self.act_fun(x)
+        if self.norm and not self.bn_before_act:
+            x = self._normalise(x)
+        return x
+
+
+class ResBlock(torch.nn.Module):
+    """Stack of ConvBlocks (``convblock1..n``, no activation on the last) with a ReZero-scaled
+    residual branch: ``out = rezero_weight * convs(x) + res_connection(x)``."""
+
+    def __init__(self, in_channels, out_channels, laplacian, convblock_kwargs, **kwargs):
+        super().__init__()
+        self.rezero = True
+        if not isinstance(out_channels, (int, tuple, list)):
+            raise TypeError("'output_channels' must be int or list/tuple of int.")
+        widths = list(out_channels) if isinstance(out_channels, (tuple, list)) else [out_channels]
+        self.conv_names_list = []
+        width_in = in_channels
+        for pos, width_out in enumerate(widths, start=1):
+            opts = dict(convblock_kwargs)
+            if pos == len(widths):
+                opts["activation"] = False  # a relu here would only allow positive increments
+            name = f"convblock{pos}"
+            setattr(self, name, ConvBlock(width_in, width_out, laplacian=laplacian, **opts))
+            self.conv_names_list.append(name)
+            width_in = width_out
+        self.res_connection = Identity() if in_channels == widths[-1] else Linear(in_channels, widths[-1])
+        if self.rezero:
+            self.rezero_weight = torch.nn.Parameter(torch.zeros(1), requires_grad=True)
+        if convblock_kwargs["batch_norm"]:  # start each block as an identity mapping
+            last = getattr(self, self.conv_names_list[-1])
+            torch.nn.init.constant_(last.bn.weight, 0)
+            torch.nn.init.constant_(last.bn.bias, 0)
+
+    def forward(self, x):
+        y = x
+        for name in self.conv_names_list:
+            y = getattr(self, name)(y)
+        if self.rezero:
+            y *= self.rezero_weight
+        y += self.res_connection(x)
+        return y
+
+
+class UNetSpherical(UNet, torch.nn.Module):
+    """Three-level spherical U-Net with residual blocks (see the reference docstring for the
+    meaning of every option; the keys are those of ``configs/UNetSpherical/*/*.json``)."""
+
+    def __init__(
+        self,
+        tensor_info: Dict,
+        sampling: str,
+        sampling_kwargs: Dict,
+        # Convolutions options
+        kernel_size_conv: int = 3,
+        conv_type: str = "graph",
+        graph_type: str = "knn",
+        knn: int = 20,
+        # Options for classical image convolution on equiangular sampling
+        periodic_padding: bool = True,
+        # ConvBlock Options
+        bias: bool = True,
+        batch_norm: bool = False,
+        batch_norm_before_activation: bool = False,
+        activation: bool = True,
+        activation_fun: str = "relu",
+        # Pooling options
+        pool_method: str = "max",
+        kernel_size_pooling: int = 4,
+        # Architecture options
+        skip_connection: str = "stack",
+        increment_learning: bool = False,
+    ):
+        super().__init__()
+        self.dim_names = tensor_info["dim_order"]["dynamic"]
+        self.input_n_feature = tensor_info["input_n_feature"]
+        self.output_n_feature = tensor_info["output_n_feature"]
+        self.input_n_time = tensor_info["input_n_time"]
+        self.output_n_time = tensor_info["output_n_time"]
+        self.input_n_node = tensor_info["input_shape_info"]["dynamic"]["node"]
+        self.output_n_node = tensor_info["output_shape_info"]["dynamic"]["node"]
+        # ConvCheb mixes the merged (time, feature) axis
+        self.input_channels = self.input_n_feature * self.input_n_time
+        self.output_channels = self.output_n_feature * self.output_n_time
+        self.increment_learning = increment_learning
+
+        sampling = check_sampling(sampling)
+        conv_type = check_conv_type(conv_type, sampling)
+        pool_method = check_pool_method(pool_method)
+        skip_connection = check_skip_connection(skip_connection)
+        lonlat_ratio = sampling_kwargs["nlon"] / sampling_kwargs["nlat"] if sampling == "equiangular" else None
+        block_opts = {
+            "kernel_size": kernel_size_conv,
+            "conv_type": conv_type,
+            "bias": bias,
+            "batch_norm": batch_norm,
+            "batch_norm_before_activation": batch_norm_before_activation,
+            "activation": activation,
+            "activation_fun": activation_fun,
+            "periodic_padding": periodic_padding,
+            "lonlat_ratio": lonlat_ratio,
+        }
+
+        # one graph per U-Net level, each `coarsening` times coarser than the previous
+        depth = 3
+        coarsening = int(np.sqrt(kernel_size_pooling))
+        sampling_kwargs["k"] = knn
+        level_kwargs = [sampling_kwargs]
+        for _ in range(1, depth):
+            level_kwargs.append(pygsp_graph_coarsening(sampling, level_kwargs[-1], coarsening))
+        self.init_graph_and_laplacians(
+            sampling_list=[sampling] * depth,
+            sampling_kwargs_list=level_kwargs,
+            graph_type=graph_type,
+            conv_type=conv_type,
+        )
+
+        if pool_method in ("interp", "maxval", "maxarea", "learn"):
+            assert conv_type == "graph"
+            self.pool1, self.unpool1 = PoolUnpoolBlock.getGeneralPoolUnpoolLayer(
+                src_graph=self.graphs[0], dst_graph=self.graphs[1], pool_method=pool_method
+            )
+            self.pool2, self.unpool2 = PoolUnpoolBlock.getGeneralPoolUnpoolLayer(
+                src_graph=self.graphs[1], dst_graph=self.graphs[2], pool_method=pool_method
+            )
+        elif pool_method in ("max", "avg"):
+            assert sampling in ["healpix", "equiangular"]
+            opts = dict(sampling=sampling, pool_method=pool_method, kernel_size=kernel_size_pooling,
+                        lonlat_ratio=lonlat_ratio)
+            self.pool1, self.unpool1 = PoolUnpoolBlock.getPoolUnpoolLayer(**opts)
+            self.pool2, self.unpool2 = PoolUnpoolBlock.getPoolUnpoolLayer(**opts)
+        elif pool_method is not None:
+            raise ValueError("Not valid pooling method provided.")
+
+        lap0, lap1, lap2 = self.laplacians
+        # encoder
+        self.conv1 = ResBlock(self.input_channels, (64, 128), laplacian=lap0, convblock_kwargs=block_opts)
+        self.conv2 = ResBlock(128, (192, 256), laplacian=lap1, convblock_kwargs=block_opts)
+        self.conv3 = ResBlock(256, (512, 256), laplacian=lap2, convblock_kwargs=block_opts)
+        # decoder (inputs are the stacked skip connections)
+        self.uconv2 = ResBlock(512, (256, 128), laplacian=lap1, convblock_kwargs=block_opts)
+        self.uconv1 = ResBlock(256, (128, 64), laplacian=lap0, convblock_kwargs=block_opts)
+        self.uconv1_final = ResBlock(64, self.output_channels, laplacian=lap0, convblock_kwargs=block_opts)
+        if self.increment_learning:
+            self.res_increment = torch.nn.Parameter(torch.zeros(1), requires_grad=True)
+
+    def encode(self, x):
+        """``x`` in ``self.dim_names`` order -> (x_enc3, x_enc2, x_enc1, idx2, idx1, x_last_timestep)."""
+        batch = x.shape[0]
+        x_last_timestep = x[:, -1, :, -2:].unsqueeze(dim=1)
+        order = [self.dim_names.index(d) for d in _CANONICAL_DIMS]
+        x = x.permute(*order).reshape(batch, self.input_n_node, self.input_channels)
+        x_enc1 = self.conv1(x)
+        x_enc2_ini, idx1 = self.pool1(x_enc1)
+        x_enc2 = self.conv2(x_enc2_ini)
+        x_enc3_ini, idx2 = self.pool2(x_enc2)
+        x_enc3 = self.conv3(x_enc3_ini)
+        return x_enc3, x_enc2, x_enc1, idx2, idx1, x_last_timestep
+
+    def decode(self, x_enc3, x_enc2, x_enc1, idx2, idx1, x_last_timestep):
+        x = self.unpool2(x_enc3, idx2)
+        x = self.uconv2(torch.cat((x, x_enc2), dim=2))
+        x = self.unpool1(x, idx1)
+        x = self.uconv1(torch.cat((x, x_enc1), dim=2))
+        x = self.uconv1_final(x)
+        batch = x.shape[0]
+        x = x.reshape(batch, self.output_n_node, self.output_n_time, self.output_n_feature)
+        order = [_CANONICAL_DIMS.index(d) for d in self.dim_names]
+        x = x.permute(*order)
+        if self.increment_learning:
+            x *= self.res_increment
+            x += x_last_timestep
+        return x

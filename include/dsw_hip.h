@@ -1,0 +1,102 @@
+/* dsw_hip.h - C ABI of libdsw_hip.so: the MI355X (gfx950) hot path of DeepSphere-Weather.
+ *
+ * The reference is pure Python; its "FFI" for this path is the two stock PyTorch ops called from
+ * modules/layers.py (torch.sparse.mm at :164, :167, :962 and Tensor.matmul at :177) plus the layout
+ * copies around them (:158-160, :165, :168, :171-173).  The entry points below are what the
+ * reference's conv_cheb / RemapBlock.forward (and their autograd backward) bind instead; the
+ * Python-side binding (ctypes) is shown in INTEGRATION.md and lives in
+ * deepsphere-weather_amd/dsw_amd/_native.py.
+ *
+ * Conventions
+ *   - plain C, no exceptions; every call returns 0 on success or a negative DSW_ERR_* code
+ *     (dsw_strerror() gives the text); the Python side turns it into RuntimeError.
+ *   - all data pointers are DEVICE pointers owned by the caller (torch tensors); the library never
+ *     allocates.  Scratch memory is passed in (dsw_cheb_bwd_workspace_bytes tells how much).
+ *   - every call enqueues work on `stream` (a hipStream_t, e.g. torch.cuda.current_stream()) and
+ *     returns immediately; calls are re-entrant and thread-safe (autograd runs backward on its
+ *     own thread).
+ *   - activations are node-major: [B, V, C] contiguous (sample, node, channel) - the layout
+ *     ConvCheb.forward receives (layers.py:365-376) - never the reference's internal [V, Fin*B].
+ *   - operators are CSR with int32 rowptr[v_out+1] / colind[nnz] and FP32 values (also for bf16
+ *     activations: the operator and every accumulation stay fp32).
+ *   - dtype: DSW_F32 (0) or DSW_BF16 (1) is the storage type of activations, weights and grads.
+ */
+#ifndef DSW_HIP_H
+#define DSW_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSW_F32 0
+#define DSW_BF16 1
+
+#define DSW_OK 0
+#define DSW_ERR_BAD_ARG (-1)
+#define DSW_ERR_BAD_DTYPE (-2)
+#define DSW_ERR_WORKSPACE (-3)
+#define DSW_ERR_LAUNCH (-4)
+#define DSW_ERR_ALIGN (-5)
+
+typedef void* dsw_stream_t; /* hipStream_t */
+
+/* Library version (major*10000 + minor*100 + patch). */
+int dsw_version(void);
+
+/* Text for an error code. */
+const char* dsw_strerror(int code);
+
+/* Sparse operator times node-major activations with a fused axpby epilogue, per sample:
+ *     Y[b,r,:] = alpha * sum_p vals[p] * X[b,colind[p],:] + beta * Z[b,r,:] + gamma * Z2[b,r,:]
+ * X: [B, v_in, C]; Y, Z, Z2: [B, v_out, C]; Z / Z2 may be NULL; Y may alias Z or Z2 (not X).
+ * Replaces torch.sparse.mm at layers.py:164 (alpha=1), :167 fused with "2*(...) - x0"
+ * (alpha=2, beta=-1), :962 (RemapBlock, rectangular operator), and their transposed autograd
+ * counterparts (pass the CSR of the transposed operator). */
+int dsw_spmm_csr(const int32_t* rowptr, const int32_t* colind, const float* vals,
+                 int64_t v_out, int64_t v_in, int64_t nnz,
+                 const void* X, void* Y, int64_t B, int64_t C,
+                 float alpha, const void* Z, float beta, const void* Z2, float gamma,
+                 int dtype, dsw_stream_t stream);
+
+/* Chebyshev basis T_1 .. T_{K-1} of X (T_0 = X is not copied):
+ *     T_1 = L X,  T_k = 2 L T_{k-1} - T_{k-2}        (layers.py:163-169)
+ * T: [K-1, B, V, C].  K <= 1 is a no-op. */
+int dsw_cheb_basis_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals,
+                       int64_t V, int64_t nnz, const void* X, void* T,
+                       int64_t B, int64_t C, int64_t K, int dtype, dsw_stream_t stream);
+
+/* Channel mix on the matrix cores:  Y[n,o] = bias[o] + sum_{k,f} T_k[n,f] * W[f,k,o]
+ * (layers.py:171-178 and the bias add at :375).  X = T_0 [N,Fin]; T = T_1.. [K-1,N,Fin];
+ * W: [Fin,K,Fout] (the reference's parameter layout); bias [Fout] or NULL; Y: [N,Fout]. */
+int dsw_cheb_mix_fwd(const void* X, const void* T, const void* W, const void* bias, void* Y,
+                     int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype,
+                     dsw_stream_t stream);
+
+/* Whole ConvCheb.forward (layers.py:365-376) = dsw_cheb_basis_fwd + dsw_cheb_mix_fwd.
+ * T ([K-1,B,V,Fin], may be NULL iff K == 1) receives the basis and is what backward needs. */
+int dsw_cheb_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals,
+                 int64_t V, int64_t nnz, const void* X, const void* W, const void* bias,
+                 void* Y, void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K,
+                 int dtype, dsw_stream_t stream);
+
+/* Scratch bytes dsw_cheb_bwd needs for this problem size. */
+int64_t dsw_cheb_bwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t Fout, int64_t K,
+                                     int dtype);
+
+/* Backward of ConvCheb (closed form of what autograd derives from layers.py:113-180,375):
+ *     dW[f,k,o] = sum_n T_k[n,f] dY[n,o];  db[o] = sum_n dY[n,o];
+ *     G_k = dY W[:,k,:]^T;  for j=K-1..1: G_{j-1} += (j>1 ? 2 : 1) L^T G_j - G_{j+1};  dX = G_0
+ * rowptr_t/colind_t/vals_t describe the CSR of L^T (for a symmetric L pass L itself).
+ * dX / dW / db may be NULL to skip them (db is only produced together with dW). */
+int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t,
+                 int64_t V, int64_t nnz, const void* X, const void* T, const void* W,
+                 const void* dY, void* dX, void* dW, void* db, void* workspace,
+                 int64_t workspace_bytes, int64_t B, int64_t Fin, int64_t Fout, int64_t K,
+                 int dtype, dsw_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSW_HIP_H */

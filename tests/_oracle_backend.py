@@ -1,0 +1,52 @@
+"""CPU stand-in for the HIP backend, built on the oracle.  TEST-ONLY (see oracle/cheb_oracle.py)."""
+import numpy as np
+import torch
+
+from oracle import cheb_oracle as orc
+
+
+def _csr_np(op):
+    return op.rowptr.cpu().numpy(), op.colind.cpu().numpy(), op.values.cpu().numpy()
+
+
+class OracleBackend:
+    name = "oracle"
+
+    def spmm(self, op, x, alpha=1.0, z=None, beta=0.0, z2=None, gamma=0.0, out=None):
+        rp, ci, va = _csr_np(op)
+        y = alpha * orc.remap_f64(rp, ci, va, op.shape, x.detach().float().numpy())
+        if z is not None:
+            y = y + beta * z.detach().double().numpy()
+        if z2 is not None:
+            y = y + gamma * z2.detach().double().numpy()
+        return torch.from_numpy(y).to(x.dtype)
+
+    def cheb_basis(self, op, x, K):
+        rp, ci, va = _csr_np(op)
+        L = orc._csr64(rp, ci, va, op.shape)
+        T = orc.cheb_basis_f64(L, x.detach().float().numpy(), K)
+        if K <= 1:
+            return torch.empty((0,) + tuple(x.shape), dtype=x.dtype)
+        return torch.from_numpy(np.stack(T[1:])).to(x.dtype)
+
+    def cheb_fwd(self, op, x, w, bias):
+        rp, ci, va = _csr_np(op)
+        y = orc.cheb_forward_f64(
+            rp, ci, va, x.detach().float().numpy(), w.detach().float().numpy(),
+            None if bias is None else bias.detach().float().numpy(),
+        )
+        K = w.shape[1]
+        T = self.cheb_basis(op, x, K) if K > 1 else None
+        return torch.from_numpy(y).to(x.dtype), T
+
+    def cheb_bwd(self, op, x, T, w, dy, need_dx, need_dw, need_db):
+        rp, ci, va = _csr_np(op)
+        dx, dw, db = orc.cheb_backward_f64(
+            rp, ci, va, x.detach().float().numpy(), w.detach().float().numpy(),
+            dy.detach().float().numpy(), has_bias=True,
+        )
+        return (
+            torch.from_numpy(dx).to(x.dtype) if need_dx else None,
+            torch.from_numpy(dw).to(w.dtype) if need_dw else None,
+            torch.from_numpy(db).to(w.dtype) if need_db else None,
+        )

@@ -1,0 +1,262 @@
+"""Host logic on CPU: C-ABI surface, operator caches, module API / state_dict, U-Net wiring (G5)."""
+import ctypes
+import re
+
+import numpy as np
+import pytest
+import torch
+from scipy import sparse
+
+from conftest import REPO, load_golden
+from oracle import cheb_oracle as orc
+import recipes
+
+
+def _header_symbols():
+    text = open(f"{REPO}/include/dsw_hip.h").read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dsw_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dsw_amd import _native
+
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    names = _header_symbols()
+    assert set(names) == set(_native.SIGNATURES), (names, sorted(_native.SIGNATURES))
+    for n in names:
+        assert hasattr(lib, n), n
+    lib = _native.load()
+    assert lib.dsw_version() >= 100
+    assert lib.dsw_strerror(0) == b"ok" and b"workspace" in lib.dsw_strerror(-3)
+    # argument validation needs no GPU: negative sizes / bad dtype are rejected before any launch
+    assert lib.dsw_spmm_csr(None, None, None, -1, 1, 0, None, None, 1, 1, 1.0, None, 0.0, None, 0.0, 0, None) == -1
+    assert lib.dsw_cheb_bwd_workspace_bytes(16, 49152, 32, 64, 3, 0) > 2 * 16 * 49152 * 32 * 4
+    assert lib.dsw_cheb_bwd_workspace_bytes(1, 1, 0, 1, 1, 0) < 0
+
+
+def test_cpu_tensors_fail_loudly():
+    from modules.layers import ConvCheb, prepare_torch_laplacian
+    from dsw_amd import sphere
+
+    lap = prepare_torch_laplacian(sphere.SphereHealpix(2, nest=True, k=8).L, lmax=2.0)
+    layer = ConvCheb(3, 4, 3, laplacian=lap)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layer(torch.zeros(1, 48, 3))
+
+
+def test_csr_operator_and_transpose():
+    from dsw_amd.functional import CsrOperator, get_operator
+
+    rp, ci, va = recipes.irregular_operator(97, seed=3, min_deg=1, max_deg=30)
+    coo = orc.coo_from_csr_arrays(rp, ci, va, (97, 97))
+    op = get_operator(coo)
+    assert get_operator(coo) is op  # cached
+    np.testing.assert_array_equal(op.rowptr.numpy(), rp)
+    np.testing.assert_array_equal(op.colind.numpy(), ci)
+    assert op.rowptr.dtype == torch.int32 and op.colind.dtype == torch.int32 and op.values.dtype == torch.float32
+    ref_t = sparse.csr_matrix((va, ci, rp), shape=(97, 97)).T.tocsr()
+    ref_t.sort_indices()
+    t = op.transpose()
+    np.testing.assert_array_equal(t.rowptr.numpy(), ref_t.indptr)
+    np.testing.assert_array_equal(t.colind.numpy(), ref_t.indices)
+    np.testing.assert_array_equal(t.values.numpy(), ref_t.data)
+    assert t.transpose() is op
+    # rectangular
+    m = sparse.random(13, 40, density=0.2, random_state=1, format="coo", dtype=np.float32)
+    opm = CsrOperator.from_sparse_coo(orc.coo_from_scipy(m).float())
+    assert opm.shape == (13, 40) and opm.transpose().shape == (40, 13)
+    # in-place update of the buffer invalidates the cache
+    coo2 = orc.coo_from_csr_arrays(rp, ci, va * 2, (97, 97))
+    coo.copy_(coo2)
+    assert get_operator(coo) is not op
+    np.testing.assert_allclose(get_operator(coo).values.numpy(), va * 2)
+
+
+def test_prepare_laplacian_matches_golden():
+    from modules.layers import convert_to_torch_sparse, prepare_torch_laplacian
+
+    g = load_golden("G4_prepare")
+    n = len(g["in_rowptr"]) - 1
+    L = sparse.csr_matrix((g["in_values"], g["in_colind"], g["in_rowptr"]), shape=(n, n))
+    t = prepare_torch_laplacian(L, lmax=float(g["lmax"][0]))
+    assert t.is_coalesced() and t.dtype == torch.float32 and t.indices().dtype == torch.int64
+    np.testing.assert_array_equal(t.indices().numpy(), g["out_indices"])
+    np.testing.assert_allclose(t.values().numpy(), g["out_values"], rtol=0, atol=1e-7)
+    # default path (ARPACK) differs only by the lmax estimate: spectrum must end up inside [-1, 1]
+    t2 = prepare_torch_laplacian(L)
+    dense = t2.to_dense().double().numpy()
+    ev = np.linalg.eigvalsh((dense + dense.T) / 2)
+    assert ev.min() >= -1.0 - 1e-4 and ev.max() <= 1.0
+    c = convert_to_torch_sparse(sparse.coo_matrix(L))
+    assert c.is_coalesced() and c.shape == (n, n)
+
+
+def test_convcheb_module_contract(oracle_backend):
+    from modules.layers import ConvCheb, GeneralConvBlock, conv_cheb, get_conv_fun
+
+    g = load_golden("G2_conv_K_sweep")
+    p = "ns_K3_"
+    B, V, Fin, Fout, K, has_bias, _ = [int(v) for v in g[p + "meta"]]
+    lap = orc.coo_from_csr_arrays(g[p + "rowptr"], g[p + "colind"], g[p + "values"], (V, V))
+    torch.manual_seed(0)
+    layer = GeneralConvBlock.getConvLayer(Fin, Fout, K, conv_type="graph", laplacian=lap, bias=True,
+                                          lonlat_ratio=None, periodic_padding=True)
+    assert isinstance(layer, ConvCheb) and get_conv_fun("graph") is ConvCheb
+    assert sorted(layer.state_dict().keys()) == ["bias", "laplacian", "weight"]
+    assert layer.state_dict()["laplacian"].is_sparse
+    assert tuple(layer.weight.shape) == (Fin, K, Fout) and float(layer.bias.detach().abs().sum()) == 0.0
+    assert "kernel_size=3" in repr(layer) and "bias=True" in repr(layer)
+    # Kaiming-normal fan-in init (statistical check on a wide layer)
+    wide = ConvCheb(64, 256, 3, laplacian=lap)
+    assert abs(float(wide.weight.detach().std()) - np.sqrt(2.0 / (64 * 3))) < 0.004
+    with pytest.raises(ValueError, match="unknown fan"):
+        wide.reset_parameters(fan="sideways")
+    # forward/backward through the autograd wiring (oracle stands in for the kernels on CPU)
+    layer.set_parameters(torch.from_numpy(g[p + "w"]), torch.from_numpy(g[p + "b"]))
+    x = torch.from_numpy(g[p + "x"]).permute(1, 0, 2).contiguous().permute(1, 0, 2)  # non-contiguous view
+    x.requires_grad_(True)
+    y = layer(x)
+    y += 0.0  # callers mutate the output in place
+    y.backward(torch.from_numpy(g[p + "gy"]))
+    assert orc.max_rel_err(y.detach(), g[p + "y"]) < 1e-5
+    assert orc.max_rel_err(x.grad, g[p + "dx"]) < 1e-5
+    assert orc.max_rel_err(layer.weight.grad, g[p + "dw"]) < 1e-5
+    assert orc.max_rel_err(layer.bias.grad, g[p + "db"]) < 1e-5
+    # functional form, error text, state_dict round trip, SWAG-style plain-tensor reassignment
+    y2 = conv_cheb(lap, x.detach(), layer.weight.detach())
+    assert orc.max_rel_err(y2 + layer.bias.detach(), g[p + "y"]) < 1e-5
+    err = str(load_golden("G7_errors")["fin_mismatch"])
+    with pytest.raises(ValueError) as ei:
+        layer(torch.zeros(1, V, Fin + 1))
+    assert str(ei.value).split(":")[0] == err.split(":")[0]
+    with pytest.raises(ValueError, match="conv_type is not supported"):
+        GeneralConvBlock.getConvLayer(4, 4, 3, conv_type="mesh", laplacian=lap)
+    other = ConvCheb(Fin, Fout, K, laplacian=lap.clone())
+    other.load_state_dict(layer.state_dict(), strict=True)
+    assert torch.equal(other.weight, layer.weight)
+    w_plain = layer._parameters.pop("weight").detach() * 2
+    layer.__setattr__("weight", w_plain)
+    y3 = layer(x.detach())
+    assert orc.max_rel_err(y3 - layer.bias.detach(), 2 * (torch.from_numpy(g[p + "y"]) - layer.bias.detach())) < 1e-5
+    assert layer.double().laplacian.dtype == torch.float64
+
+
+def test_remap_modules(oracle_backend):
+    from modules.layers import (GeneralAvgPool, GeneralAvgUnpool, GeneralMaxAreaPool, GeneralMaxAreaUnpool,
+                                PoolUnpoolBlock)
+    from dsw_amd import sphere
+
+    g = load_golden("G3_remap")
+    for tag in ("hier", "interp"):
+        pm = sparse.csr_matrix((g[f"{tag}_pool_values"], g[f"{tag}_pool_colind"], g[f"{tag}_pool_rowptr"]), shape=(192, 768))
+        um = sparse.csr_matrix((g[f"{tag}_unpool_values"], g[f"{tag}_unpool_colind"], g[f"{tag}_unpool_rowptr"]), shape=(768, 192))
+        pool, unpool = GeneralAvgPool(sparse.coo_matrix(pm)), GeneralAvgUnpool(sparse.coo_matrix(um))
+        assert list(pool.state_dict()) == ["remap_matrix"] and pool.remap_matrix.is_sparse
+        x = torch.from_numpy(g[f"{tag}_x"]).requires_grad_(True)
+        y, idx = pool(x)
+        assert idx is None and y.shape == (2, 192, 6)
+        y.backward(torch.from_numpy(g[f"{tag}_gyp"]))
+        assert orc.max_rel_err(y.detach(), g[f"{tag}_yp"]) < 1e-5
+        assert orc.max_rel_err(x.grad, g[f"{tag}_dxp"]) < 1e-5
+        xu = torch.from_numpy(g[f"{tag}_xu"]).requires_grad_(True)
+        yu = unpool(xu, None)  # decode() passes the (None) pool indices positionally
+        yu.backward(torch.from_numpy(g[f"{tag}_gyu"]))
+        assert orc.max_rel_err(yu.detach(), g[f"{tag}_yu"]) < 1e-5
+        assert orc.max_rel_err(xu.grad, g[f"{tag}_dxu"]) < 1e-5
+    gs, gd = sphere.SphereHealpix(4, nest=True, k=8), sphere.SphereHealpix(2, nest=True, k=8)
+    pool, unpool = PoolUnpoolBlock.getGeneralPoolUnpoolLayer(gd, gs, "interp")  # swapped on purpose
+    assert pool.remap_matrix.shape == (48, 192) and unpool.remap_matrix.shape == (192, 48)
+    pool, unpool = PoolUnpoolBlock.getGeneralPoolUnpoolLayer(gs, gd, "maxarea")
+    assert isinstance(pool, GeneralMaxAreaPool) and isinstance(unpool, GeneralMaxAreaUnpool)
+    assert float(pool.remap_matrix.values().sum()) == 48.0 and float(unpool.remap_matrix.values().sum()) == 48.0  # one fine cell per coarse cell (layers.py:1019-1036)
+    with pytest.raises(NotImplementedError):
+        PoolUnpoolBlock.getGeneralPoolUnpoolLayer(gs, gd, "learn")
+    with pytest.raises(ValueError, match="not supoorted"):
+        PoolUnpoolBlock.getGeneralPoolUnpoolLayer(gs, gd, "median")
+
+
+def build_g5_model(device="cpu"):
+    """UNetSpherical nside=8 with the fixture's operators and seeded parameters."""
+    import modules.my_models_graph as arch
+
+    g = load_golden("G5_unet_nside8")
+    V = 768
+    tensor_info = {
+        "dim_order": {"dynamic": ["sample", "time", "node", "feature"]},
+        "input_n_feature": 6, "output_n_feature": 2, "input_n_time": 3, "output_n_time": 1,
+        "input_shape_info": {"dynamic": {"node": V}}, "output_shape_info": {"dynamic": {"node": V}},
+    }
+    model = arch.UNetSpherical(tensor_info, sampling="healpix", sampling_kwargs={"subdivisions": 8, "nest": True},
+                               kernel_size_conv=3, conv_type="graph", graph_type="knn", knn=20, pool_method="interp")
+    # identical prepared operators on both sides (ARPACK lmax is nondeterministic)
+    laps = [orc.coo_from_csr_arrays(g[f"lap{i}_rowptr"], g[f"lap{i}_colind"], g[f"lap{i}_values"],
+                                    (len(g[f"lap{i}_rowptr"]) - 1,) * 2) for i in range(3)]
+    sizes = {lap.shape[0]: lap for lap in laps}
+    sd = model.state_dict()
+    for key in sd:
+        if key.endswith("laplacian"):
+            sd[key] = sizes[sd[key].shape[0]].clone()
+        elif key.endswith("remap_matrix"):
+            nm = key.split(".")[0]
+            sd[key] = orc.coo_from_csr_arrays(g[f"{nm}_rowptr"], g[f"{nm}_colind"], g[f"{nm}_values"], tuple(g[f"{nm}_shape"]))
+    names = sorted(n for n, _ in model.named_parameters())
+    for i, n in enumerate(names):
+        sd[n] = torch.from_numpy(recipes.unet_param_fill(i, n, tuple(sd[n].shape)))
+    model.load_state_dict(sd, strict=True)
+    return model.to(device), g, names
+
+
+def check_g5(model, g, names, device="cpu", tol=2e-5):
+    x = torch.from_numpy(recipes.rand(501, (2, 3, 768, 6))).to(device)
+    target = torch.from_numpy(recipes.rand(502, (2, 1, 768, 2))).to(device)
+    y = model(x)
+    loss = ((y - target) ** 2).mean()
+    loss.backward()
+    assert y.shape == (2, 1, 768, 2)
+    assert orc.max_rel_err(y.detach().cpu(), g["y"]) < tol
+    assert abs(loss.item() - float(g["loss"][0])) < tol * max(1.0, float(g["loss"][0]))
+    params = dict(model.named_parameters())
+    probes = np.stack([recipes.grad_probe(i, params[n].grad.detach().cpu().numpy()) for i, n in enumerate(names)])
+    ref = g["grad_probes"]
+    scale = np.abs(ref[:, :1]) + 1e-12  # per-tensor gradient l2 norm
+    assert np.max(np.abs(probes[:, 0] - ref[:, 0]) / scale[:, 0]) < 10 * tol
+    assert np.max(np.abs(probes[:, 2:] - ref[:, 2:]) / scale) < 10 * tol
+    # the dot-probe sums ~1e5 random-signed terms: compare against |g|*|r| ~ l2 * sqrt(n)
+    n_el = np.array([params[n].numel() for n in names], dtype=np.float64)
+    assert np.max(np.abs(probes[:, 1] - ref[:, 1]) / (scale[:, 0] * np.sqrt(n_el))) < 10 * tol
+
+
+def test_unet_matches_reference_fixture_on_cpu_wiring(oracle_backend):
+    model, g, names = build_g5_model()
+    assert list(model.state_dict().keys()) == [str(k) for k in g["state_keys"]]
+    assert names == [str(n) for n in g["param_names"]]
+    shapes = [str(tuple(p.shape)) for _, p in sorted(model.named_parameters())]
+    assert shapes == [str(s) for s in g["param_shapes"]]
+    assert sum(p.numel() for p in model.parameters()) == 1770122
+    check_g5(model, g, names)
+
+
+def test_config_driven_construction():
+    """Same ``architecture_name`` + inspect-filtered kwargs convention as utils_config.get_pytorch_model."""
+    import inspect
+    import modules.my_models_graph as arch
+
+    settings = {
+        "pretrained_model_name": None, "kernel_size_conv": 3, "bias": True, "batch_norm": False,
+        "batch_norm_before_activation": False, "activation": True, "activation_fun": "relu",
+        "pool_method": "Interp", "kernel_size_pooling": 4, "conv_type": "graph", "graph_type": "knn", "knn": 8,
+        "periodic_padding": "True", "sampling_name": "Healpix_x", "sampling": "healpix",
+        "sampling_kwargs": {"subdivisions": 4, "nest": True}, "architecture_name": "UNetSpherical",
+    }
+    settings["tensor_info"] = {
+        "dim_order": {"dynamic": ["sample", "time", "node", "feature"]},
+        "input_n_feature": 6, "output_n_feature": 2, "input_n_time": 3, "output_n_time": 1,
+        "input_shape_info": {"dynamic": {"node": 192}}, "output_shape_info": {"dynamic": {"node": 192}},
+    }
+    cls = getattr(arch, settings["architecture_name"])
+    args = inspect.getfullargspec(cls.__init__).args
+    model = cls(**{k: v for k, v in settings.items() if k in args})
+    assert len([k for k in model.state_dict() if k.endswith("laplacian")]) == 11
+    assert len([k for k in model.state_dict() if k.endswith("remap_matrix")]) == 4
+    assert model.pool1.remap_matrix.shape == (48, 192)

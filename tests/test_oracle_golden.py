@@ -1,0 +1,97 @@
+"""The oracle against the golden vectors recorded from the reference itself (CPU only)."""
+import numpy as np
+import pytest
+import torch
+from scipy import sparse
+
+from conftest import load_golden
+from oracle import cheb_oracle as orc
+
+TOL32 = 1e-5   # fp32 restatement vs reference fp32
+TOL64 = 2e-6   # fp64 closed form vs reference fp32 (reference's own fp32 error is < 1e-6)
+
+
+def _conv_case(g, prefix=""):
+    B, V, Fin, Fout, K, has_bias, _ = [int(v) for v in g[prefix + "meta"]]
+    rp, ci, va = g[prefix + "rowptr"], g[prefix + "colind"], g[prefix + "values"]
+    x, w, gy = g[prefix + "x"], g[prefix + "w"], g[prefix + "gy"]
+    b = g[prefix + "b"] if has_bias else None
+    return (B, V, Fin, Fout, K, has_bias), (rp, ci, va), (x, w, b, gy)
+
+
+def _check_conv(g, prefix=""):
+    (B, V, Fin, Fout, K, has_bias), (rp, ci, va), (x, w, b, gy) = _conv_case(g, prefix)
+    # restatement 1: same torch op sequence
+    lap = orc.coo_from_csr_arrays(rp, ci, va, (V, V))
+    y, dx, dw, db = orc.conv_cheb_fwd_bwd_torch(
+        lap, torch.from_numpy(x), torch.from_numpy(w), None if b is None else torch.from_numpy(b),
+        torch.from_numpy(gy),
+    )
+    assert orc.max_rel_err(y, g[prefix + "y"]) <= TOL32
+    assert orc.max_rel_err(dx, g[prefix + "dx"]) <= TOL32
+    assert orc.max_rel_err(dw, g[prefix + "dw"]) <= TOL32
+    if has_bias:
+        assert orc.max_rel_err(db, g[prefix + "db"]) <= TOL32
+    # restatement 2: fp64 closed form with hand-derived backward
+    y64 = orc.cheb_forward_f64(rp, ci, va, x, w, b)
+    dx64, dw64, db64 = orc.cheb_backward_f64(rp, ci, va, x, w, gy, has_bias=bool(has_bias))
+    assert orc.max_rel_err(g[prefix + "y"], y64) <= TOL64
+    assert orc.max_rel_err(g[prefix + "dx"], dx64) <= TOL64
+    assert orc.max_rel_err(g[prefix + "dw"], dw64) <= TOL64
+    if has_bias:
+        assert orc.max_rel_err(g[prefix + "db"], db64) <= TOL64
+
+
+@pytest.mark.parametrize("name", ["G1_conv_c1_k8", "G1_conv_c1_k20", "G6_conv_irregular"])
+def test_conv_fixtures(name):
+    _check_conv(load_golden(name))
+
+
+@pytest.mark.parametrize("kind", ["sym", "ns"])
+@pytest.mark.parametrize("K", [1, 2, 3, 5])
+def test_conv_K_sweep(kind, K):
+    _check_conv(load_golden("G2_conv_K_sweep"), f"{kind}_K{K}_")
+
+
+@pytest.mark.parametrize("tag", ["hier", "interp"])
+def test_remap_fixture(tag):
+    g = load_golden("G3_remap")
+    for which, xin, yout, gyin, dxout in (
+        ("pool", "x", "yp", "gyp", "dxp"),
+        ("unpool", "xu", "yu", "gyu", "dxu"),
+    ):
+        rp, ci, va = (g[f"{tag}_{which}_{k}"] for k in ("rowptr", "colind", "values"))
+        x, y_ref, gy, dx_ref = g[f"{tag}_{xin}"], g[f"{tag}_{yout}"], g[f"{tag}_{gyin}"], g[f"{tag}_{dxout}"]
+        shape = (y_ref.shape[1], x.shape[1])
+        m = orc.coo_from_csr_arrays(rp, ci, va, shape)
+        y = orc.remap_torch(m, torch.from_numpy(x))
+        assert orc.max_rel_err(y, y_ref) <= TOL32
+        assert orc.max_rel_err(y_ref, orc.remap_f64(rp, ci, va, shape, x)) <= TOL64
+        assert orc.max_rel_err(dx_ref, orc.remap_backward_f64(rp, ci, va, shape, gy)) <= TOL64
+        # invariants the reference asserts on its pooling matrices (layers.py:557-571): rows sum to 1
+        rows = np.add.reduceat(va, rp[:-1][np.diff(rp) > 0])
+        np.testing.assert_allclose(rows, 1.0, rtol=1e-5)
+
+
+def test_prepare_fixture():
+    g = load_golden("G4_prepare")
+    n = len(g["in_rowptr"]) - 1
+    L = sparse.csr_matrix((g["in_values"], g["in_colind"], g["in_rowptr"]), shape=(n, n))
+    t = orc.prepare_laplacian_fixed_lmax(L, float(g["lmax"][0]))
+    assert t.indices().dtype == torch.int64
+    np.testing.assert_array_equal(t.indices().numpy(), g["out_indices"])
+    np.testing.assert_allclose(t.values().numpy(), g["out_values"], rtol=0, atol=1e-7)
+    assert str(g["full_indices_dtype"]) == "torch.int64" and bool(g["full_is_sorted"])
+    # CSR round trip of the coalesced COO
+    rp, ci, va = orc.csr_arrays_from_coo(t)
+    back = orc.coo_from_csr_arrays(rp, ci, va, (n, n))
+    np.testing.assert_array_equal(back.indices().numpy(), t.indices().numpy())
+
+
+def test_error_fixture():
+    g = load_golden("G7_errors")
+    assert "Input tensor shape does not match the expected shape" in str(g["fin_mismatch"])
+    assert "conv_type is not supported" in str(g["bad_conv_type"])
+    lap = orc.coo_from_csr_arrays(np.array([0, 1, 2]), np.array([0, 1]), np.array([1.0, 1.0], dtype=np.float32), (2, 2))
+    with pytest.raises(ValueError, match="does not match the expected shape"):
+        orc.conv_cheb_torch(lap, torch.zeros(1, 2, 3), torch.zeros(4, 3, 2))
