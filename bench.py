@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""Benchmark of the ConvCheb hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload ns|c3|unet] [--knn 8|20]
+
+One "step" = one forward + backward pass of the hot path over one batch of synthetic HEALPix
+fields already resident in HBM (plus, for N > 1, the single flat-bucket RCCL all-reduce of the
+parameter gradients).  Metric (BASELINE.json): HEALPix nodes*channels/sec through ConvCheb (fwd+bwd)
+= B * V * Fin * n_gpus / t_step.  Scaling is weak: every rank owns a full per-GPU batch.
+
+Workloads
+  ns    north-star shape: nside=64 (V=49152), K=3, 32->64 channels, B=16 per GPU, fp32   (default)
+  c3    BASELINE configs[2]: nside=64, K=5, 64->128, B=16 per GPU, bf16 storage / fp32 accumulate
+  unet  BASELINE configs[1]: UNetSpherical nside=32, K=3, B=8 per GPU, fp32, interp pooling
+
+Rank 0 prints ONE JSON line.  At N=1 it also carries
+  roofline      the SpMM kernel: algorithmic bytes per launch / mean launch duration (HIP events on
+                the launch stream) against the 8 TB/s HBM peak; "traffic" from profiles/ PMC data
+  cpu_baseline  the oracle's torch restatement of the reference CPU path, timed on this box's cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(REPO, "deepsphere-weather_amd"), REPO):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
+
+WORKLOADS = {
+    "ns": dict(nside=64, K=3, fin=32, fout=64, batch=16, dtype="f32"),
+    "c3": dict(nside=64, K=5, fin=64, fout=128, batch=16, dtype="bf16"),
+    "unet": dict(nside=32, K=3, fin=18, fout=2, batch=8, dtype="f32"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
+    ap.add_argument("--knn", type=int, default=8, help="neighbours of the HEALPix k-NN stencil (8 or 20)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def make_layer(wl, knn, device, dtype):
+    from dsw_amd import sphere
+    from modules.layers import ConvCheb, prepare_torch_laplacian
+
+    graph = sphere.SphereHealpix(wl["nside"], nest=True, k=knn)
+    lap = prepare_torch_laplacian(graph.L, lmax=1.95)  # fixed lmax: identical operator on every rank
+    torch.manual_seed(10)  # seed_model_weights of the reference configs
+    layer = ConvCheb(wl["fin"], wl["fout"], wl["K"], laplacian=lap, bias=True)
+    return layer.to(device).to(dtype), lap
+
+
+def make_unet(wl, knn, device):
+    import modules.my_models_graph as arch
+
+    V = 12 * wl["nside"] ** 2
+    tensor_info = {
+        "dim_order": {"dynamic": ["sample", "time", "node", "feature"]},
+        "input_n_feature": 6, "output_n_feature": 2, "input_n_time": 3, "output_n_time": 1,
+        "input_shape_info": {"dynamic": {"node": V}}, "output_shape_info": {"dynamic": {"node": V}},
+    }
+    torch.manual_seed(10)
+    model = arch.UNetSpherical(tensor_info, sampling="healpix",
+                               sampling_kwargs={"subdivisions": wl["nside"], "nest": True},
+                               kernel_size_conv=wl["K"], conv_type="graph", graph_type="knn", knn=knn,
+                               pool_method="interp")
+    with torch.no_grad():  # ReZero starts at 0, which would zero every conv gradient
+        for n, p in model.named_parameters():
+            if n.endswith("rezero_weight"):
+                p.fill_(0.5)
+    return model.to(device)
+
+
+def spmm_algorithmic_bytes(E, Lb, K):
+    """forward recurrence [2 + 3(K-2)] E + (K-1) Lb, adjoint [3 + 4(K-2)] E + (K-1) Lb."""
+    fwd = (2 + 3 * (K - 2)) * E + (K - 1) * Lb
+    bwd = (3 + 4 * (K - 2)) * E + (K - 1) * Lb
+    return fwd, bwd
+
+
+def roofline_leg(layer, x, steps, warmup):
+    """Time exactly the SpMM launches of one fwd+bwd (K-1 basis hops + K-1 adjoint hops)."""
+    from dsw_amd import functional as F_
+
+    op = F_.get_operator(layer.laplacian)
+    opt = op.transpose()
+    K = layer.kernel_size
+    B, V, C = x.shape
+    es = x.element_size()
+    E = B * V * C * es
+    Lb = op.nnz * 8 + 4 * (V + 1)
+    hip = F_._HIP
+    T = torch.empty((K - 1, B, V, C), dtype=x.dtype, device=x.device)
+    G = [torch.randn_like(x) for _ in range(K)]
+
+    def launches():
+        hip.spmm(op, x, 1.0, out=T[0])
+        for k in range(2, K):
+            hip.spmm(op, T[k - 2], 2.0, x if k == 2 else T[k - 3], -1.0, out=T[k - 1])
+        for j in range(K - 1, 0, -1):
+            hip.spmm(opt, G[j], 1.0 if j == 1 else 2.0, G[j - 1], 1.0, G[j + 1] if j + 1 <= K - 1 else None, -1.0,
+                     out=G[j - 1])
+
+    for _ in range(warmup):
+        launches()
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record(stream)
+    for _ in range(steps):
+        launches()
+    t1.record(stream)
+    torch.cuda.synchronize()
+    n_launch = 2 * (K - 1)
+    avg_s = t0.elapsed_time(t1) * 1e-3 / (steps * n_launch)
+    fwd_b, bwd_b = spmm_algorithmic_bytes(E, Lb, K)
+    bytes_per_launch = (fwd_b + bwd_b) / n_launch
+    achieved = bytes_per_launch / avg_s / 1e9
+    # forward recurrence alone (the north-star gate)
+    t0.record(stream)
+    for _ in range(steps):
+        hip.spmm(op, x, 1.0, out=T[0])
+        for k in range(2, K):
+            hip.spmm(op, T[k - 2], 2.0, x if k == 2 else T[k - 3], -1.0, out=T[k - 1])
+    t1.record(stream)
+    torch.cuda.synchronize()
+    fwd_s = t0.elapsed_time(t1) * 1e-3 / steps
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "spmm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {
+        "bound": "hbm", "kernel": "spmm_csr (Chebyshev recurrence + adjoint, %d launches/step)" % n_launch,
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 2),
+        "fwd_recurrence_us": round(fwd_s * 1e6, 2),
+        "fwd_recurrence_frac": round(fwd_b / fwd_s / 1e9 / HBM_PEAK_GBS, 4),
+    }
+
+
+def cpu_baseline_leg(wl, lap, layer):
+    """The oracle's torch restatement of the reference CPU path (torch.sparse.mm + matmul), fp32."""
+    from oracle import cheb_oracle as orc
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    V = 12 * wl["nside"] ** 2
+    B = wl["batch"]
+    torch.manual_seed(1234)
+    x = torch.randn(B, V, wl["fin"])
+    gy = torch.randn(B, V, wl["fout"])
+    w = layer.weight.detach().float().cpu()
+    b = layer.bias.detach().float().cpu()
+    lap = lap.float().coalesce()
+    n_warm, n_iter = 2, 8
+    times = []
+    for i in range(n_warm + n_iter):
+        t = time.perf_counter()
+        orc.conv_cheb_fwd_bwd_torch(lap, x, w, b, gy)
+        dt = time.perf_counter() - t
+        if i >= n_warm:
+            times.append(dt)
+        if sum(times) > 30.0:
+            break
+    med = float(np.median(times))
+    return {
+        "value": B * V * wl["fin"] / med, "unit": "nodes*channels/s", "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": "oracle conv_cheb torch restatement (sparse COO mm + matmul, fp32), full %s shape "
+                  "[B=%d,V=%d,%d->%d,K=%d], median of %d fwd+bwd, %.1f ms" % (
+                      "workload", B, V, wl["fin"], wl["fout"], wl["K"], len(times), med * 1e3),
+    }
+
+
+def main():
+    args = parse()
+    from dsw_amd import _native
+    from dsw_amd.parallel import FlatGradAllReduce, init_from_env
+
+    rank, world, local = init_from_env()
+    assert torch.cuda.is_available(), "bench.py measures the HIP path; a ROCm device is required"
+    _native.load()
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    wl = WORKLOADS[args.workload]
+    dtype = torch.bfloat16 if wl["dtype"] == "bf16" else torch.float32
+    V = 12 * wl["nside"] ** 2
+    B = wl["batch"]
+    torch.manual_seed(1234 + rank)
+
+    if args.workload == "unet":
+        model = make_unet(wl, args.knn if args.knn != 8 else 20, device)
+        x = torch.randn(B, 3, V, 6, device=device)
+        target = torch.randn(B, 1, V, 2, device=device)
+        lap = None
+
+        def step():
+            model.zero_grad(set_to_none=True)
+            loss = ((model(x) - target) ** 2).mean()
+            loss.backward()
+    else:
+        model, lap = make_layer(wl, args.knn, device, dtype)
+        x = torch.randn(B, V, wl["fin"], device=device, dtype=dtype).requires_grad_(True)
+        gy = torch.randn(B, V, wl["fout"], device=device, dtype=dtype)
+
+        def step():
+            model.zero_grad(set_to_none=True)
+            x.grad = None
+            model(x).backward(gy)
+
+    sync_grads = FlatGradAllReduce(model.parameters())
+
+    def full_step():
+        step()
+        sync_grads()
+
+    for _ in range(args.warmup):
+        full_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms = elapsed / args.steps * 1e3
+    units = B * V * wl["fin"] * world  # node-channels through the path per step, whole job
+    out = {
+        "metric": "HEALPix nodes*channels/sec through ConvCheb K=%d (fwd+bwd)" % wl["K"],
+        "value": units / (elapsed / args.steps), "unit": "nodes*channels/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": wl["dtype"], "data": "synthetic",
+        "config": {
+            "workload": {
+                "ns": "single ConvCheb layer, HEALPix nside=64 nested (V=49152), K=3, 32->64 ch, B=16/GPU, fp32 (north-star shape)",
+                "c3": "single ConvCheb layer, HEALPix nside=64 nested, K=5, 64->128 ch, B=16/GPU, bf16 storage + fp32 accumulate",
+                "unet": "UNetSpherical, HEALPix nside=32 nested, K=3, B=8/GPU, fp32, interp pooling (11 ConvCheb + 4 RemapBlock)",
+            }[args.workload],
+            "knn": args.knn if args.workload != "unet" else (args.knn if args.knn != 8 else 20),
+            "batch_per_gpu": B, "global_batch": B * world, "nodes": V,
+            "parallelism": "dp%d (batch shards, flat-bucket RCCL grad all-reduce)" % world,
+        },
+    }
+    if rank == 0 and world == 1 and args.workload != "unet":
+        if not args.no_roofline:
+            out["roofline"] = roofline_leg(model, x.detach(), max(10, args.steps), 5)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_leg(wl, lap, model)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
