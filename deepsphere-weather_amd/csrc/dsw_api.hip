@@ -10,7 +10,7 @@ int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* 
                        int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream);
 int dsw_mix_dgrad_launch(const void* dY, const void* W, void* G0, void* Grest, int64_t N, int64_t Fin,
                          int64_t Fout, int64_t K, int dtype, hipStream_t stream);
-int64_t dsw_wgrad_slabs(int64_t N, int64_t* rows_per_slab);
+int64_t dsw_wgrad_slabs(int64_t N, int64_t Fin, int64_t Fout, int64_t K);
 int dsw_wgrad_launch(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
                      int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream);
 
@@ -89,7 +89,7 @@ int64_t dsw_cheb_bwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t 
     if (B < 0 || V < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
     const int64_t N = B * V;
     const int64_t g = round_up((K - 1) * N * Fin * elem_size(dtype), 256);
-    const int64_t S = dsw_wgrad_slabs(N, nullptr);
+    const int64_t S = dsw_wgrad_slabs(N, Fin, Fout, K);
     const int64_t p = round_up((S > 0 ? S : 1) * (K * Fin + 1) * Fout * 4, 256);
     return g + p + 256;
 }

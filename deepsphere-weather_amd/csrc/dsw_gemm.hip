@@ -14,6 +14,7 @@
 // consumed in 8-wide groups, lane-half h taking elements 4h..4h+3) - irrelevant at fp32 tolerance.
 // bf16 storage is supported by widening to fp32 while staging through LDS (fp32 accumulate).
 #include "dsw_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -21,7 +22,6 @@ constexpr int BM = 128;       // rows of the tall operand per workgroup (4 waves
 constexpr int BN = 64;        // output columns per workgroup (2 MFMA tiles per wave)
 constexpr int BK = 32;        // reduction chunk staged in LDS
 constexpr int LDA = BK + 4;   // +4 floats: conflict-free ds_read_b128 of 16 rows (stride 36 words)
-constexpr int LDB = BN;
 
 template <bool BF16>
 static __device__ __forceinline__ float ld1(const void* p, size_t i) {
@@ -56,7 +56,8 @@ struct TsGemmParams {
     // small operand: element (a-plane p, c-plane q, kd, n) at Bsrc[p*b_sp + q*b_sq + kd*b_skd + n*b_sn]
     const void* Bsrc;
     long b_sp, b_sq, b_skd, b_sn;
-    // output: n_planes_c planes of [M, ldc]; plane 0 = C0, plane q>0 = C1 + (q-1)*c_plane_stride
+    // output: n_planes_c planes of [M, ldc]; plane 0 = C0, plane q>0 = C1 + (q-1)*c_plane_stride.
+    // Output columns are addressed flattened: j = q * n_per_plane + n.
     void* C0;
     void* C1;
     size_t c_plane_stride;
@@ -66,121 +67,198 @@ struct TsGemmParams {
     const void* bias;       // [n_per_plane] or null (same dtype as the data)
     long M;
     int a_vec;              // 1 if float4/bf16x4 loads of A are legal
-    int b_vec;              // 1 if b_sn == 1 and 4-wide loads of B are legal
 };
 
-// C[q] (M x n_per_plane) = sum_p A[p] (M x kd) * B[p,q] (kd x n_per_plane) (+ bias)
-template <bool BF16>
+// C (M x n_total) = sum_p A[p] (M x kd) * B[p] (kd x n_total) (+ bias),  n_total = n_planes_c * n_per_plane.
+// Workgroup tile: 128 rows x 32*NT columns; wave w owns rows [32w, 32w+32) and NT 32x32 MFMA tiles.
+// RESIDENT: the whole B panel of the column tile lives in LDS for the lifetime of the workgroup,
+// which then walks row tiles blockIdx.x, +gridDim.x, ... with a register prefetch that runs across
+// tile boundaries.  Otherwise B is streamed chunk by chunk next to A.
+// ALIGNED: A rows are 16-byte aligned and kd_per_plane % 32 == 0 (no column bounds checks).
+// PF: depth of the register prefetch ring for A (chunks in flight per workgroup).  One chunk is
+// 16 KB; HBM latency under load is ~2-3 us while a chunk's MFMAs take < 1 us, so a single
+// chunk in flight leaves the matrix pipe idle most of the time (measured: 3 TB/s effective).
+template <bool BF16, int NT, bool RESIDENT, bool ALIGNED>
 __global__ __launch_bounds__(256) void ts_gemm_kernel(const TsGemmParams P) {
-    __shared__ __attribute__((aligned(16))) float As[BM * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+    constexpr int BNT = 32 * NT;
+    constexpr int PF = RESIDENT ? 3 : 2;   // streaming B doubles the ring's registers: keep it shallow
+    constexpr int NRB = RESIDENT ? 1 : (BK * BNT) / 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;               // [BM][LDA]
+    float* Bs = smem + BM * LDA;    // RESIDENT: [n_planes_a * chunks * BK][BNT]; else [BK][BNT]
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int half = lane >> 5, l31 = lane & 31;
-    const long row0 = (long)blockIdx.x * BM;
-    const int ntile_per_plane = (P.n_per_plane + BN - 1) / BN;
-    const int q = blockIdx.y / ntile_per_plane;              // output plane
-    const int col0 = (blockIdx.y - q * ntile_per_plane) * BN;  // first column in that plane
-
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-
-    // A staging: thread -> rows ar + 32*i (i<4), 4 columns at ac4
-    const int ar = tid >> 3, ac4 = (tid & 7) * 4;
-    // B staging: thread -> reduction rows br + 16*i (i<2), 4 columns at bc4
-    const int br = tid >> 4, bc4 = (tid & 15) * 4;
-
+    const int n_total = P.n_planes_c * P.n_per_plane;
+    const int col0 = blockIdx.y * BNT;
     const int chunks = (P.kd_per_plane + BK - 1) / BK;
-    const int total = P.n_planes_a * chunks;
+    const int total = P.n_planes_a * chunks;            // reduction chunks per row tile
+    const long row_tiles = (P.M + BM - 1) / BM;
 
-    float4 ra[4], rb[2];
-    auto fetch = [&](int it) {
-        const int p = it / chunks;
-        const int k0 = (it - p * chunks) * BK;
+    // B element for (reduction chunk it_c, row kk of the chunk, column jj of the tile)
+    auto load_b = [&](int it_c, int kk, int jj) -> float {
+        const int p = it_c / chunks;
+        const int kd = (it_c - p * chunks) * BK + kk;
+        const int j = col0 + jj;
+        if (kd >= P.kd_per_plane || j >= n_total) return 0.f;
+        const int q = j / P.n_per_plane, n = j - q * P.n_per_plane;
+        return ld1<BF16>(P.Bsrc, (size_t)((long)p * P.b_sp + (long)q * P.b_sq + (long)kd * P.b_skd + (long)n * P.b_sn));
+    };
+
+    if constexpr (RESIDENT) {
+        const int nelem = total * BK * BNT;
+        for (int e = tid; e < nelem; e += 256) {
+            const int r = e / BNT, jj = e - r * BNT;
+            Bs[e] = load_b(r / BK, r % BK, jj);
+        }
+    }
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    // per-lane output column of each MFMA tile: plane, in-plane column, bias (loaded once, so the
+    // epilogue issues no loads and therefore never drains the prefetch ring)
+    bool col_ok[NT];
+    char* col_ptr[NT];
+    float col_bias[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int j = col0 + 32 * nt + l31;
+        col_ok[nt] = j < n_total;
+        const int q = col_ok[nt] ? j / P.n_per_plane : 0;
+        const int n = col_ok[nt] ? j - q * P.n_per_plane : 0;
+        char* base = static_cast<char*>((q == 0) ? P.C0 : P.C1);
+        const size_t cbase = (q == 0) ? 0 : (size_t)(q - 1) * P.c_plane_stride;
+        col_ptr[nt] = base + (cbase + (size_t)n) * (BF16 ? 2 : 4);
+        col_bias[nt] = (P.bias != nullptr) ? ld1<BF16>(P.bias, n) : 0.f;
+    }
+
+    const int ar = tid >> 3, ac4 = (tid & 7) * 4;   // A staging: rows ar + 32*i (i<4), 4 columns at ac4
+    float4 ra[PF][4];
+    float rb[PF][NRB];
+
+    const long my_tiles = RESIDENT ? (row_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 1;
+    const long n_iter = my_tiles * total;
+
+    // Branch-free in the ALIGNED case (row index clamped instead of predicated): hipcc only keeps
+    // counted s_waitcnt vmcnt(N) - i.e. leaves the younger ring slots in flight - in straight-line code.
+    auto fetch = [&](long it, float4 (&dra)[4], float (&drb)[NRB]) {
+        const long ti = it / total;
+        const int c = (int)(it - ti * total);
+        const long row0 = ((long)blockIdx.x + ti * gridDim.x) * BM;
+        const int p = c / chunks;
+        const int k0 = (c - p * chunks) * BK;
         const void* A = (p == 0) ? P.A0 : P.A1;
         const size_t abase = (p == 0) ? 0 : (size_t)(p - 1) * P.a_plane_stride;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const long r = row0 + ar + 32 * i;
+            long r = row0 + ar + 32 * i;
             const int kc = k0 + ac4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < P.M) {
-                const size_t off = abase + (size_t)r * P.lda + kc;
-                if (P.a_vec && kc + 3 < P.kd_per_plane) {
-                    v = ld4<BF16>(A, off);
-                } else {
-                    if (kc + 0 < P.kd_per_plane) v.x = ld1<BF16>(A, off + 0);
-                    if (kc + 1 < P.kd_per_plane) v.y = ld1<BF16>(A, off + 1);
-                    if (kc + 2 < P.kd_per_plane) v.z = ld1<BF16>(A, off + 2);
-                    if (kc + 3 < P.kd_per_plane) v.w = ld1<BF16>(A, off + 3);
+            if constexpr (ALIGNED) {
+                r = r < P.M ? r : P.M - 1;  // rows >= M are computed on a copy of the last row, never stored
+                dra[i] = ld4<BF16>(A, abase + (size_t)r * P.lda + kc);
+            } else {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < P.M) {
+                    const size_t off = abase + (size_t)r * P.lda + kc;
+                    if (P.a_vec && kc + 3 < P.kd_per_plane) {
+                        v = ld4<BF16>(A, off);
+                    } else {
+                        if (kc + 0 < P.kd_per_plane) v.x = ld1<BF16>(A, off + 0);
+                        if (kc + 1 < P.kd_per_plane) v.y = ld1<BF16>(A, off + 1);
+                        if (kc + 2 < P.kd_per_plane) v.z = ld1<BF16>(A, off + 2);
+                        if (kc + 3 < P.kd_per_plane) v.w = ld1<BF16>(A, off + 3);
+                    }
                 }
+                dra[i] = v;
             }
-            ra[i] = v;
         }
+        if constexpr (!RESIDENT) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int kd = k0 + br + 16 * i;
-            const int n = col0 + bc4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kd < P.kd_per_plane) {
-                const long off = (long)p * P.b_sp + (long)q * P.b_sq + (long)kd * P.b_skd + (long)n * P.b_sn;
-                if (P.b_vec && n + 3 < P.n_per_plane) {
-                    v = ld4<BF16>(P.Bsrc, (size_t)off);
-                } else {
-                    if (n + 0 < P.n_per_plane) v.x = ld1<BF16>(P.Bsrc, (size_t)(off + 0 * P.b_sn));
-                    if (n + 1 < P.n_per_plane) v.y = ld1<BF16>(P.Bsrc, (size_t)(off + 1 * P.b_sn));
-                    if (n + 2 < P.n_per_plane) v.z = ld1<BF16>(P.Bsrc, (size_t)(off + 2 * P.b_sn));
-                    if (n + 3 < P.n_per_plane) v.w = ld1<BF16>(P.Bsrc, (size_t)(off + 3 * P.b_sn));
-                }
+            for (int i = 0; i < NRB; ++i) {
+                const int e = tid + 256 * i;
+                drb[i] = load_b(c, e / BNT, e % BNT);
             }
-            rb[i] = v;
         }
     };
 
-    fetch(0);
-    for (int it = 0; it < total; ++it) {
-        __syncthreads();  // previous chunk fully consumed
+    if (n_iter <= 0) return;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) fetch(u < n_iter ? u : n_iter - 1, ra[u], rb[u]);
+
+    const long n_pad = (n_iter + PF - 1) / PF * PF;   // padded iterations redo the last chunk; never stored
+    // one ring stage; `U` is a compile-time slot index so that ra[u] / rb[u] stay in registers
+    auto stage = [&](auto U, const long it) {
+        constexpr int u = decltype(U)::value;
+        const long ti = it / total;
+        const int c = (int)(it - ti * total);
+        __syncthreads();  // previous chunk fully consumed (and, first time, the resident B panel written)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(&As[(ar + 32 * i) * LDA + ac4]) = ra[i];
+            *reinterpret_cast<float4*>(&As[(ar + 32 * i) * LDA + ac4]) = ra[u][i];
+        if constexpr (!RESIDENT) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<float4*>(&Bs[(br + 16 * i) * LDB + bc4]) = rb[i];
+            for (int i = 0; i < NRB; ++i) Bs[tid + 256 * i] = rb[u][i];
+        }
         __syncthreads();
-        if (it + 1 < total) fetch(it + 1);  // global loads in flight under the MFMAs
+        {   // refill this ring slot (clamped: the tail re-reads the last chunk instead of branching)
+            const long nx = it + PF;
+            fetch(nx < n_iter ? nx : n_iter - 1, ra[u], rb[u]);
+        }
 
         const float* arow = &As[(wave * 32 + l31) * LDA + 4 * half];
+        const float* bchunk = RESIDENT ? (Bs + (size_t)c * BK * BNT) : Bs;
 #pragma unroll
-        for (int c = 0; c < BK / 8; ++c) {
-            const float4 a = *reinterpret_cast<const float4*>(arow + 8 * c);
+        for (int cc = 0; cc < BK / 8; ++cc) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + 8 * cc);
             const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int kk = 8 * c + 4 * half + t;
-                const float b0 = Bs[kk * LDB + l31];
-                const float b1 = Bs[kk * LDB + 32 + l31];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], b1, acc1, 0, 0, 0);
+                const int kk = 8 * cc + 4 * half + t;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float b = bchunk[kk * BNT + 32 * nt + l31];
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], b, acc[nt], 0, 0, 0);
+                }
             }
         }
-    }
 
-    // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
-    void* C = (q == 0) ? P.C0 : P.C1;
-    const size_t cbase = (q == 0) ? 0 : (size_t)(q - 1) * P.c_plane_stride;
-    const int cA = col0 + l31, cB = col0 + 32 + l31;
-    const float biasA = (P.bias != nullptr && cA < P.n_per_plane) ? ld1<BF16>(P.bias, cA) : 0.f;
-    const float biasB = (P.bias != nullptr && cB < P.n_per_plane) ? ld1<BF16>(P.bias, cB) : 0.f;
+        if (c == total - 1 && it < n_iter) {
+            // epilogue: C/D layout of a 32x32 tile: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+            const long row0 = ((long)blockIdx.x + ti * gridDim.x) * BM;
+            const bool full_rows = row0 + BM <= P.M;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const long r = row0 + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
-        if (r < P.M) {
-            const size_t off = cbase + (size_t)r * P.ldc;
-            if (cA < P.n_per_plane) st1<BF16>(C, off + cA, acc0[i] + biasA);
-            if (cB < P.n_per_plane) st1<BF16>(C, off + cB, acc1[i] + biasB);
+            for (int nt = 0; nt < NT; ++nt) {
+                const bool jok = col_ok[nt];
+                char* C = col_ptr[nt];          // points at (row 0, this lane's column) of the right plane
+                const float bias = col_bias[nt];
+                const long rbase = row0 + wave * 32 + 4 * half;
+                if (full_rows) {
+                    if (jok) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            st1<BF16>(C, (size_t)(rbase + (i & 3) + 8 * (i >> 2)) * P.ldc, acc[nt][i] + bias);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const long r = rbase + (i & 3) + 8 * (i >> 2);
+                        if (jok && r < P.M) st1<BF16>(C, (size_t)r * P.ldc, acc[nt][i] + bias);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+            }
         }
+    };
+    for (long base = 0; base < n_pad; base += PF) {
+        stage(std::integral_constant<int, 0>{}, base);
+        stage(std::integral_constant<int, 1>{}, base + 1);
+        if constexpr (PF > 2) stage(std::integral_constant<int, 2>{}, base + 2);
     }
 }
 
@@ -202,15 +280,21 @@ struct WgradParams {
     int t_vec, dy_vec;
 };
 
-template <bool BF16>
-__global__ __launch_bounds__(256) void cheb_wgrad_kernel(const WgradParams P) {
-    __shared__ __attribute__((aligned(16))) float Ts[4][WR * 32];
+// NW waves per workgroup = number of 32-row (k, f) tiles it covers (1..4): no idle waves when
+// K * ceil(Fin/32) is not a multiple of 4 (north-star: 3 tiles -> 3-wave workgroups).
+// ALIGNED: Fin % 32 == 0, Fout-tile full and 16-byte aligned rows (no column bounds checks).
+template <bool BF16, int NW, bool ALIGNED>
+__global__ __launch_bounds__(64 * NW) void cheb_wgrad_kernel(const WgradParams P) {
+    constexpr int NT_ = 64 * NW;                       // threads
+    constexpr int RD = (WR * BN / 4 + NT_ - 1) / NT_;  // float4 of the dY tile per thread
+    constexpr int PF = 3;                              // prefetch ring depth (chunks in flight)
+    __shared__ __attribute__((aligned(16))) float Ts[NW][WR * 32];
     __shared__ __attribute__((aligned(16))) float Ds[WR * BN];
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int half = lane >> 5, l31 = lane & 31;
-    const int tile = blockIdx.y * 4 + wave;
+    const int tile = blockIdx.y * NW + wave;
     const int ntiles = P.K * P.tiles_per_plane;
     const bool active = tile < ntiles;
     const int k = active ? tile / P.tiles_per_plane : 0;
@@ -228,76 +312,109 @@ __global__ __launch_bounds__(256) void cheb_wgrad_kernel(const WgradParams P) {
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
     float colsum = 0.f;
 
-    const int tr = lane >> 3, tc4 = (lane & 7) * 4;   // T tile: rows tr + 8*i (i<4)
-    const int dr = tid >> 4, dc4 = (tid & 15) * 4;    // dY tile: rows dr + 16*i (i<2)
+    const int tr = lane >> 3, tc4 = (lane & 7) * 4;   // T tile (per wave): rows tr + 8*i (i<4)
 
-    float4 rt[4], rd[2];
-    auto fetch = [&](long n0) {
+    float4 rt[PF][4], rd[PF][RD];
+    // ALIGNED: N % 32 == 0, so every chunk is complete and loads are unconditional (inactive waves
+    // load tile 0's data and discard it) -> straight-line code, counted vmcnt, ring stays in flight.
+    auto fetch = [&](long n0, float4 (&drt)[4], float4 (&drd)[RD]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long r = n0 + tr + 8 * i;
             const int f = f0 + tc4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (active && r < n_end) {
-                const size_t off = abase + (size_t)r * P.Fin + f;
-                if (P.t_vec && f + 3 < P.Fin) {
-                    v = ld4<BF16>(A, off);
-                } else {
-                    if (f + 0 < P.Fin) v.x = ld1<BF16>(A, off + 0);
-                    if (f + 1 < P.Fin) v.y = ld1<BF16>(A, off + 1);
-                    if (f + 2 < P.Fin) v.z = ld1<BF16>(A, off + 2);
-                    if (f + 3 < P.Fin) v.w = ld1<BF16>(A, off + 3);
+            if constexpr (ALIGNED) {
+                drt[i] = ld4<BF16>(A, abase + (size_t)r * P.Fin + f);
+            } else {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (active && r < n_end) {
+                    const size_t off = abase + (size_t)r * P.Fin + f;
+                    if (P.t_vec && f + 3 < P.Fin) {
+                        v = ld4<BF16>(A, off);
+                    } else {
+                        if (f + 0 < P.Fin) v.x = ld1<BF16>(A, off + 0);
+                        if (f + 1 < P.Fin) v.y = ld1<BF16>(A, off + 1);
+                        if (f + 2 < P.Fin) v.z = ld1<BF16>(A, off + 2);
+                        if (f + 3 < P.Fin) v.w = ld1<BF16>(A, off + 3);
+                    }
                 }
+                drt[i] = v;
             }
-            rt[i] = v;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const long r = n0 + dr + 16 * i;
-            const int o = o0 + dc4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < n_end) {
-                const size_t off = (size_t)r * P.Fout + o;
-                if (P.dy_vec && o + 3 < P.Fout) {
-                    v = ld4<BF16>(P.dY, off);
-                } else {
-                    if (o + 0 < P.Fout) v.x = ld1<BF16>(P.dY, off + 0);
-                    if (o + 1 < P.Fout) v.y = ld1<BF16>(P.dY, off + 1);
-                    if (o + 2 < P.Fout) v.z = ld1<BF16>(P.dY, off + 2);
-                    if (o + 3 < P.Fout) v.w = ld1<BF16>(P.dY, off + 3);
+        for (int i = 0; i < RD; ++i) {
+            int e = tid + NT_ * i;                       // float4 index inside the [WR][BN] tile
+            if constexpr (ALIGNED) {
+                if ((WR * BN / 4) % NT_ != 0) e = e < WR * BN / 4 ? e : WR * BN / 4 - 1;
+                const int dr = e >> 4, dc4 = (e & 15) * 4;
+                drd[i] = ld4<BF16>(P.dY, (size_t)(n0 + dr) * P.Fout + o0 + dc4);
+            } else {
+                const int dr = e >> 4, dc4 = (e & 15) * 4;
+                const long r = n0 + dr;
+                const int o = o0 + dc4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < WR * BN / 4 && r < n_end) {
+                    const size_t off = (size_t)r * P.Fout + o;
+                    if (P.dy_vec && o + 3 < P.Fout) {
+                        v = ld4<BF16>(P.dY, off);
+                    } else {
+                        if (o + 0 < P.Fout) v.x = ld1<BF16>(P.dY, off + 0);
+                        if (o + 1 < P.Fout) v.y = ld1<BF16>(P.dY, off + 1);
+                        if (o + 2 < P.Fout) v.z = ld1<BF16>(P.dY, off + 2);
+                        if (o + 3 < P.Fout) v.w = ld1<BF16>(P.dY, off + 3);
+                    }
                 }
+                drd[i] = v;
             }
-            rd[i] = v;
         }
     };
 
-    if (n_begin < n_end) fetch(n_begin);
-    for (long n0 = n_begin; n0 < n_end; n0 += WR) {
+    const long n_chunks = (n_end - n_begin + WR - 1) / WR;
+    if (n_chunks > 0) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            fetch(n_begin + (long)(u < n_chunks ? u : n_chunks - 1) * WR, rt[u], rd[u]);
+    }
+    const long n_pad = (n_chunks + PF - 1) / PF * PF;   // padded chunks re-read the last one, unused
+    auto stage = [&](auto U, const long ci) {
+        constexpr int u = decltype(U)::value;
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(&Ts[wave][(tr + 8 * i) * 32 + tc4]) = rt[i];
+            *reinterpret_cast<float4*>(&Ts[wave][(tr + 8 * i) * 32 + tc4]) = rt[u][i];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<float4*>(&Ds[(dr + 16 * i) * BN + dc4]) = rd[i];
+        for (int i = 0; i < RD; ++i) {
+            const int e = tid + NT_ * i;
+            if (e < WR * BN / 4) *reinterpret_cast<float4*>(&Ds[e * 4]) = rd[u][i];
+        }
         __syncthreads();
-        if (n0 + WR < n_end) fetch(n0 + WR);
-
-        if (active) {
+        {
+            const long nx = ci + PF;
+            fetch(n_begin + (nx < n_chunks ? nx : n_chunks - 1) * WR, rt[u], rd[u]);
+        }
+        if (ci < n_chunks) {
+            if (active) {
 #pragma unroll
-            for (int s = 0; s < WR / 2; ++s) {
-                const int n = 2 * s + half;
-                const float a = Ts[wave][n * 32 + l31];       // A^T[f][n]
-                const float b0 = Ds[n * BN + l31];             // dY[n][o]
-                const float b1 = Ds[n * BN + 32 + l31];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+                for (int s = 0; s < WR / 2; ++s) {
+                    const int n = 2 * s + half;
+                    const float a = Ts[wave][n * 32 + l31];       // A^T[f][n]
+                    const float b0 = Ds[n * BN + l31];             // dY[n][o]
+                    const float b1 = Ds[n * BN + 32 + l31];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+                }
+            }
+            if (blockIdx.y == 0 && tid < BN) {
+                float cs = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < WR; ++r) cs += Ds[r * BN + tid];
+                colsum += cs;
             }
         }
-        if (blockIdx.y == 0 && tid < BN) {
-#pragma unroll
-            for (int r = 0; r < WR; ++r) colsum += Ds[r * BN + tid];
-        }
+    };
+    for (long cb = 0; cb < n_pad; cb += PF) {
+        stage(std::integral_constant<int, 0>{}, cb);
+        stage(std::integral_constant<int, 1>{}, cb + 1);
+        stage(std::integral_constant<int, 2>{}, cb + 2);
     }
 
     float* out = P.partial + (size_t)blockIdx.x * (size_t)(Kd + 1) * P.Fout;
@@ -316,38 +433,90 @@ __global__ __launch_bounds__(256) void cheb_wgrad_kernel(const WgradParams P) {
     if (blockIdx.y == 0 && tid < BN && o0 + tid < P.Fout) out[(size_t)Kd * P.Fout + o0 + tid] = colsum;
 }
 
-// dW[f, k, o] = sum_s partial[s][k*Fin + f][o];  db[o] = sum_s partial[s][Kd][o]  (deterministic order)
+// dW[f, k, o] = sum_s partial[s][k*Fin + f][o];  db[o] = sum_s partial[s][Kd][o]
+// 256 threads = 32 outputs x 8 slab groups; fixed summation order -> bit-reproducible.
 template <bool BF16>
 __global__ __launch_bounds__(256) void cheb_wgrad_reduce_kernel(const float* __restrict__ partial, int S,
                                                                 int Fin, int Fout, int K, void* dW,
                                                                 void* db) {
+    __shared__ float red[8][32];
     const int Kd = K * Fin;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)(Kd + 1) * Fout;
-    if (idx >= total) return;
+    const int lane_o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const long idx = (long)blockIdx.x * 32 + lane_o;
     const size_t slab = (size_t)(Kd + 1) * Fout;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int s = 0;
-    for (; s + 4 <= S; s += 4) {
-        s0 += partial[(size_t)(s + 0) * slab + idx];
-        s1 += partial[(size_t)(s + 1) * slab + idx];
-        s2 += partial[(size_t)(s + 2) * slab + idx];
-        s3 += partial[(size_t)(s + 3) * slab + idx];
+    float s0 = 0.f, s1 = 0.f;
+    if (idx < total) {
+        int s = grp;
+        for (; s + 8 < S; s += 16) {
+            s0 += partial[(size_t)s * slab + idx];
+            s1 += partial[(size_t)(s + 8) * slab + idx];
+        }
+        if (s < S) s0 += partial[(size_t)s * slab + idx];
     }
-    for (; s < S; ++s) s0 += partial[(size_t)s * slab + idx];
-    const float v = (s0 + s1) + (s2 + s3);
-    const int kd = (int)(idx / Fout), o = (int)(idx - (long)kd * Fout);
-    if (kd == Kd) {
-        if (db != nullptr) st1<BF16>(db, o, v);
-    } else {
-        const int k = kd / Fin, f = kd - k * Fin;
-        st1<BF16>(dW, ((size_t)f * K + k) * Fout + o, v);
+    red[grp][lane_o] = s0 + s1;
+    __syncthreads();
+    if (grp == 0 && idx < total) {
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) v += red[g][lane_o];
+        const int kd = (int)(idx / Fout), o = (int)(idx - (long)kd * Fout);
+        if (kd == Kd) {
+            if (db != nullptr) st1<BF16>(db, o, v);
+        } else {
+            const int k = kd / Fin, f = kd - k * Fin;
+            st1<BF16>(dW, ((size_t)f * K + k) * Fout + o, v);
+        }
     }
 }
 
 }  // namespace
 
 // ------------------------------- host-side launchers (internal) ------------------------------
+template <bool BF16, int NT>
+static int launch_ts_gemm_nt(const TsGemmParams& P, int col_tiles, hipStream_t stream) {
+    constexpr int BNT = 32 * NT;
+    const int chunks = (P.kd_per_plane + BK - 1) / BK;
+    const long row_tiles = (P.M + BM - 1) / BM;
+    const size_t a_bytes = (size_t)BM * LDA * 4;
+    const size_t b_res = (size_t)P.n_planes_a * chunks * BK * BNT * 4;
+    const bool resident = b_res <= 44 * 1024;   // A tile (18 KiB) + B panel stay under the 64 KiB default LDS limit
+    const bool aligned = P.a_vec && (P.kd_per_plane % BK == 0);
+    if (resident) {
+        const size_t lds = a_bytes + b_res;
+        int per_cu = 0;
+        const void* kfn = aligned ? (const void*)ts_gemm_kernel<BF16, NT, true, true>
+                                  : (const void*)ts_gemm_kernel<BF16, NT, true, false>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, lds) != hipSuccess || per_cu < 1)
+            per_cu = 1;   // grid = resident workgroups only: the persistent loop has no tail wave
+        long gx = 256L * per_cu / col_tiles;
+        if (gx < 1) gx = 1;
+        if (gx > row_tiles) gx = row_tiles;
+        dim3 grid((unsigned)gx, (unsigned)col_tiles);
+        if (aligned) hipLaunchKernelGGL((ts_gemm_kernel<BF16, NT, true, true>), grid, dim3(256), lds, stream, P);
+        else hipLaunchKernelGGL((ts_gemm_kernel<BF16, NT, true, false>), grid, dim3(256), lds, stream, P);
+    } else {
+        const size_t lds = a_bytes + (size_t)BK * BNT * 4;
+        dim3 grid((unsigned)row_tiles, (unsigned)col_tiles);
+        if (aligned) hipLaunchKernelGGL((ts_gemm_kernel<BF16, NT, false, true>), grid, dim3(256), lds, stream, P);
+        else hipLaunchKernelGGL((ts_gemm_kernel<BF16, NT, false, false>), grid, dim3(256), lds, stream, P);
+    }
+    return dsw_check_launch();
+}
+
+template <bool BF16>
+static int launch_ts_gemm(const TsGemmParams& P, hipStream_t stream) {
+    const int n_total = P.n_planes_c * P.n_per_plane;
+    if (n_total <= 32) return launch_ts_gemm_nt<BF16, 1>(P, 1, stream);
+    if (n_total <= 64) return launch_ts_gemm_nt<BF16, 2>(P, 1, stream);
+    if (n_total <= 96) return launch_ts_gemm_nt<BF16, 3>(P, 1, stream);
+    if (n_total <= 128) return launch_ts_gemm_nt<BF16, 4>(P, 1, stream);
+    // wide outputs: 128-column tiles, or 96 when that wastes fewer padded columns
+    const int t128 = (n_total + 127) / 128, t96 = (n_total + 95) / 96;
+    if (t96 * 96 < t128 * 128) return launch_ts_gemm_nt<BF16, 3>(P, t96, stream);
+    return launch_ts_gemm_nt<BF16, 4>(P, t128, stream);
+}
+
 int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* bias, void* Y, int64_t N,
                        int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream) {
     if (N == 0) return DSW_OK;
@@ -361,12 +530,9 @@ int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* 
     P.bias = bias; P.M = N;
     const uintptr_t am = (uintptr_t)(4 * es) - 1;
     P.a_vec = (Fin % 4 == 0) && (((uintptr_t)X & am) == 0) && (K == 1 || ((uintptr_t)T & am) == 0);
-    P.b_vec = (Fout % 4 == 0) && (((uintptr_t)W & am) == 0);
-    dim3 grid((unsigned)((N + BM - 1) / BM), (unsigned)((Fout + BN - 1) / BN));
-    if (dtype == DSW_F32) hipLaunchKernelGGL(ts_gemm_kernel<false>, grid, dim3(256), 0, stream, P);
-    else if (dtype == DSW_BF16) hipLaunchKernelGGL(ts_gemm_kernel<true>, grid, dim3(256), 0, stream, P);
-    else return DSW_ERR_BAD_DTYPE;
-    return dsw_check_launch();
+    if (dtype == DSW_F32) return launch_ts_gemm<false>(P, stream);
+    if (dtype == DSW_BF16) return launch_ts_gemm<true>(P, stream);
+    return DSW_ERR_BAD_DTYPE;
 }
 
 // G_0 -> dX buffer, G_1.. -> Gws planes
@@ -383,22 +549,34 @@ int dsw_mix_dgrad_launch(const void* dY, const void* W, void* G0, void* Grest, i
     P.bias = nullptr; P.M = N;
     const uintptr_t am = (uintptr_t)(4 * es) - 1;
     P.a_vec = (Fout % 4 == 0) && (((uintptr_t)dY & am) == 0);
-    P.b_vec = 0;
-    const int ntile = (int)((Fin + BN - 1) / BN);
-    dim3 grid((unsigned)((N + BM - 1) / BM), (unsigned)(K * ntile));
-    if (dtype == DSW_F32) hipLaunchKernelGGL(ts_gemm_kernel<false>, grid, dim3(256), 0, stream, P);
-    else if (dtype == DSW_BF16) hipLaunchKernelGGL(ts_gemm_kernel<true>, grid, dim3(256), 0, stream, P);
-    else return DSW_ERR_BAD_DTYPE;
-    return dsw_check_launch();
+    if (dtype == DSW_F32) return launch_ts_gemm<false>(P, stream);
+    if (dtype == DSW_BF16) return launch_ts_gemm<true>(P, stream);
+    return DSW_ERR_BAD_DTYPE;
 }
 
-// number of row slabs used by wgrad for a given N (also sizes the partial workspace)
-int64_t dsw_wgrad_slabs(int64_t N, int64_t* rows_per_slab) {
-    const int64_t target = 1024;                       // ~4 workgroups per CU
-    int64_t rps = (N + target - 1) / target;
+// Upper bound of row slabs wgrad may use (sizes the partial workspace; the launch picks the actual
+// count from the kernel's occupancy so that every slab's workgroup is resident: no tail wave).
+// Partials are capped at 64 MiB: wide layers get their parallelism from the (k,f) x o tiling instead.
+static int64_t wgrad_max_slabs(int64_t Fin, int64_t Fout, int64_t K) {
+    const int64_t slab_bytes = (K * Fin + 1) * Fout * 4;
+    int64_t m = (64LL << 20) / slab_bytes;
+    if (m > 2048) m = 2048;
+    if (m < 1) m = 1;
+    return m;
+}
+
+static int64_t wgrad_rows_per_slab(int64_t N, int64_t target_slabs, int64_t max_slabs) {
+    if (target_slabs > max_slabs) target_slabs = max_slabs;
+    if (target_slabs < 1) target_slabs = 1;
+    int64_t rps = (N + target_slabs - 1) / target_slabs;
     rps = ((rps + WR - 1) / WR) * WR;
     if (rps < 4 * WR) rps = 4 * WR;
-    if (rows_per_slab) *rows_per_slab = rps;
+    return rps;
+}
+
+int64_t dsw_wgrad_slabs(int64_t N, int64_t Fin, int64_t Fout, int64_t K) {
+    const int64_t m = wgrad_max_slabs(Fin, Fout, K);
+    const int64_t rps = wgrad_rows_per_slab(N, m, m);
     return N > 0 ? (N + rps - 1) / rps : 0;
 }
 
@@ -408,7 +586,7 @@ int dsw_wgrad_launch(const void* X, const void* T, const void* dY, void* dW, voi
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     const int es = dtype == DSW_BF16 ? 2 : 4;
     int64_t rps = 0;
-    const int64_t S = dsw_wgrad_slabs(N, &rps);
+    int64_t S = N > 0 ? 1 : 0;
     if (S > 0) {
         WgradParams P;
         P.X = X; P.T = T; P.plane_stride = (size_t)N * Fin; P.dY = dY; P.partial = partial;
@@ -418,14 +596,45 @@ int dsw_wgrad_launch(const void* X, const void* T, const void* dY, void* dW, voi
         P.t_vec = (Fin % 4 == 0) && (((uintptr_t)X & am) == 0) && (K == 1 || ((uintptr_t)T & am) == 0);
         P.dy_vec = (Fout % 4 == 0) && (((uintptr_t)dY & am) == 0);
         const int ntiles = (int)K * P.tiles_per_plane;
-        dim3 grid((unsigned)S, (unsigned)((ntiles + 3) / 4), (unsigned)((Fout + BN - 1) / BN));
-        if (dtype == DSW_F32) hipLaunchKernelGGL(cheb_wgrad_kernel<false>, grid, dim3(256), 0, stream, P);
-        else hipLaunchKernelGGL(cheb_wgrad_kernel<true>, grid, dim3(256), 0, stream, P);
+        // waves per workgroup: spread the (k, f) tiles evenly over the fewest groups of <= 4
+        const int groups = (ntiles + 3) / 4;
+        const int nw = (ntiles + groups - 1) / groups;
+        const bool aligned = P.t_vec && P.dy_vec && (Fin % 32 == 0) && (Fout % BN == 0) && (N % WR == 0);
+        const int64_t otiles = (Fout + BN - 1) / BN;
+        // slabs = resident workgroups (occupancy query), so the launch is a single full wave of work
+#define DSW_WGRAD_LAUNCH(BF, NW_)                                                                          \
+    do {                                                                                                   \
+        const void* kfn = aligned ? (const void*)cheb_wgrad_kernel<BF, NW_, true>                          \
+                                  : (const void*)cheb_wgrad_kernel<BF, NW_, false>;                        \
+        int occ = 0;                                                                                       \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, 64 * NW_, 0) != hipSuccess || occ < 1) \
+            occ = 1;                                                                                       \
+        int64_t want = 256L * occ / (groups * otiles);                                                     \
+        if (want < 32) want = 32;                                                                          \
+        rps = wgrad_rows_per_slab(N, want, wgrad_max_slabs(Fin, Fout, K));                                                                \
+        S = (N + rps - 1) / rps;                                                                           \
+        P.rows_per_slab = rps;                                                                             \
+        dim3 grid((unsigned)S, (unsigned)groups, (unsigned)otiles);                                        \
+        if (aligned) hipLaunchKernelGGL((cheb_wgrad_kernel<BF, NW_, true>), grid, dim3(64 * NW_), 0, stream, P); \
+        else hipLaunchKernelGGL((cheb_wgrad_kernel<BF, NW_, false>), grid, dim3(64 * NW_), 0, stream, P);  \
+    } while (0)
+        if (dtype == DSW_F32) {
+            if (nw == 1) DSW_WGRAD_LAUNCH(false, 1);
+            else if (nw == 2) DSW_WGRAD_LAUNCH(false, 2);
+            else if (nw == 3) DSW_WGRAD_LAUNCH(false, 3);
+            else DSW_WGRAD_LAUNCH(false, 4);
+        } else {
+            if (nw == 1) DSW_WGRAD_LAUNCH(true, 1);
+            else if (nw == 2) DSW_WGRAD_LAUNCH(true, 2);
+            else if (nw == 3) DSW_WGRAD_LAUNCH(true, 3);
+            else DSW_WGRAD_LAUNCH(true, 4);
+        }
+#undef DSW_WGRAD_LAUNCH
         int rc = dsw_check_launch();
         if (rc != DSW_OK) return rc;
     }
     const long total = (long)(K * Fin + 1) * Fout;
-    dim3 rgrid((unsigned)((total + 255) / 256));
+    dim3 rgrid((unsigned)((total + 31) / 32));
     if (dtype == DSW_F32)
         hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, stream, partial, (int)S,
                            (int)Fin, (int)Fout, (int)K, dW, db);

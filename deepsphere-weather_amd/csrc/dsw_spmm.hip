@@ -15,6 +15,8 @@
 //   * rows are consecutive in a workgroup, so in HEALPix nested order (Morton curve per face) the
 //     gathered neighbours of a 32..256-row tile mostly hit the CU's L1 / the XCD's L2.
 #include "dsw_common.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -75,13 +77,26 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit(
     const int* __restrict__ rowptr, const int* __restrict__ colind, const float* __restrict__ vals,
     const void* __restrict__ X, void* Y, const void* Z, const void* Z2,
     float alpha, float beta, float gamma,
-    int v_out, int v_in, int C, int cpr, int B) {
+    int v_out, int v_in, int C, int cpr, int B, long row_blocks, int xcd_swizzle) {
     using V = Vec<BF16, VEC>;
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // XCD-aware block order: hardware block i runs on XCD i % 8 (each XCD has a private 4 MiB L2).
+    // Remap so that every XCD walks ONE contiguous range of (batch group, row block) pairs: the
+    // neighbour rows a block gathers were then fetched into the same L2 by its predecessors,
+    // instead of every XCD pulling its own copy of every halo row from HBM / Infinity Cache.
+    const long nwg = gridDim.x;
+    const long orig = blockIdx.x;
+    long wg = orig;
+    if (xcd_swizzle) {
+        const long q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const long bgrp = wg / row_blocks;
+    const long rblk = wg - bgrp * row_blocks;
+    const long gid = rblk * blockDim.x + threadIdx.x;
     const int row = (int)(gid / cpr);
     if (row >= v_out) return;
     const int c0 = (int)(gid - (long)row * cpr) * VEC;
-    const int b0 = blockIdx.y * NB;
+    const int b0 = (int)bgrp * NB;
 
     float acc[NB][VEC];
 #pragma unroll
@@ -147,15 +162,120 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit(
     }
 }
 
+// LDS-tiled variant: a workgroup owns R consecutive rows of ONE sample.  It first copies the
+// R x C block X[b, r0:r0+R, :] (contiguous in HBM, fully coalesced 16-B loads) into LDS, then every
+// (row, chunk) lane gathers its neighbours from LDS when the column falls inside the tile and from
+// global memory (L2) otherwise.  On HEALPix nested order a 256-row tile is a 16x16 pixel patch, so
+// ~90 % (k=8) of the gathers are LDS reads and each input row crosses the L1/L2 path once instead
+// of k+1 times.  Requires a square-ish operator only in the sense that tile rows index X rows
+// (v_in >= v_out is not needed: columns outside [r0, r0+R) simply take the global path).
+template <bool BF16, int VEC>
+__global__ __launch_bounds__(256) void spmm_csr_tiled(
+    const int* __restrict__ rowptr, const int* __restrict__ colind, const float* __restrict__ vals,
+    const void* __restrict__ X, void* Y, const void* Z, const void* Z2,
+    float alpha, float beta, float gamma,
+    int v_out, int v_in, int C, int cpr, int R, int B) {
+    using V = Vec<BF16, VEC>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
+    constexpr int ES = BF16 ? 2 : 4;
+    const int b = blockIdx.x % B;             // samples of one tile are neighbours in launch order
+    const int r0 = (blockIdx.x / B) * R;
+    const int rows_here = min(R, v_out - r0);
+    const size_t xs = (size_t)v_in * C;
+    const char* xb = static_cast<const char*>(X) + (size_t)b * xs * ES;
+
+    // phase 1: stage the tile's own input rows (those that exist in X)
+    const int stage_rows = max(0, min(R, v_in - r0));
+    const int n16 = stage_rows * C * ES / 16;
+    const uint4* src = reinterpret_cast<const uint4*>(xb + (size_t)r0 * C * ES);
+    uint4* dst = reinterpret_cast<uint4*>(tile_raw);
+    for (int i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
+    __syncthreads();
+
+    const int rows_per_pass = 256 / cpr;
+    const int lrow = threadIdx.x / cpr;
+    const int c0 = (threadIdx.x - lrow * cpr) * VEC;
+    if (lrow >= rows_per_pass) return;  // 256 % cpr leftover lanes
+    const size_t ys = (size_t)v_out * C;
+    for (int rr = lrow; rr < rows_here; rr += rows_per_pass) {
+        const int row = r0 + rr;
+        float acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+        const int s = rowptr[row], e = rowptr[row + 1];
+        int p = s;
+        for (; p + 2 <= e; p += 2) {
+            const int col0 = colind[p], col1 = colind[p + 1];
+            const float a0 = vals[p], a1 = vals[p + 1];
+            float x0[VEC], x1[VEC];
+            const unsigned l0 = (unsigned)(col0 - r0), l1 = (unsigned)(col1 - r0);
+            if (l0 < (unsigned)stage_rows) V::load(tile_raw, (size_t)l0 * C + c0, x0);
+            else V::load(xb, (size_t)col0 * C + c0, x0);
+            if (l1 < (unsigned)stage_rows) V::load(tile_raw, (size_t)l1 * C + c0, x1);
+            else V::load(xb, (size_t)col1 * C + c0, x1);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                acc[j] = fmaf(a0, x0[j], acc[j]);
+                acc[j] = fmaf(a1, x1[j], acc[j]);
+            }
+        }
+        if (p < e) {
+            const int col0 = colind[p];
+            const float a0 = vals[p];
+            float x0[VEC];
+            const unsigned l0 = (unsigned)(col0 - r0);
+            if (l0 < (unsigned)stage_rows) V::load(tile_raw, (size_t)l0 * C + c0, x0);
+            else V::load(xb, (size_t)col0 * C + c0, x0);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] = fmaf(a0, x0[j], acc[j]);
+        }
+        const size_t off = (size_t)b * ys + (size_t)row * C + c0;
+        float o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = alpha * acc[j];
+        if (Z != nullptr) {
+            float z[VEC];
+            V::load(Z, off, z);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] = fmaf(beta, z[j], o[j]);
+        }
+        if (Z2 != nullptr) {
+            float z[VEC];
+            V::load(Z2, off, z);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] = fmaf(gamma, z[j], o[j]);
+        }
+        V::store(Y, off, o);
+    }
+}
+
+template <bool BF16, int VEC>
+int launch_tiled(const int* rowptr, const int* colind, const float* vals, const void* X, void* Y,
+                 const void* Z, const void* Z2, float alpha, float beta, float gamma, int v_out, int v_in,
+                 int C, int B, int R, hipStream_t stream) {
+    const int cpr = C / VEC;
+    const int es = BF16 ? 2 : 4;
+    const long tiles = (v_out + R - 1) / R;
+    dim3 grid((unsigned)(tiles * B));
+    const size_t lds = (size_t)R * C * es;
+    hipLaunchKernelGGL((spmm_csr_tiled<BF16, VEC>), grid, dim3(256), lds, stream, rowptr, colind, vals, X, Y,
+                       Z, Z2, alpha, beta, gamma, v_out, v_in, C, cpr, R, B);
+    return dsw_check_launch();
+}
+
 template <bool BF16, int VEC, int NB>
 int launch_rowsplit(const int* rowptr, const int* colind, const float* vals, const void* X, void* Y,
                     const void* Z, const void* Z2, float alpha, float beta, float gamma, int v_out,
                     int v_in, int C, int B, hipStream_t stream) {
     const int cpr = C / VEC;
     const long threads = (long)v_out * cpr;
-    dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((B + NB - 1) / NB));
+    const long row_blocks = (threads + 255) / 256;
+    const long bgroups = (B + NB - 1) / NB;
+    static const char* sw = getenv("DSW_SPMM_XCD");  // "0" disables the XCD-aware block order (diagnostics)
+    const int swz = (sw && sw[0] == '0') ? 0 : 1;
+    dim3 grid((unsigned)(row_blocks * bgroups));
     hipLaunchKernelGGL((spmm_csr_rowsplit<BF16, VEC, NB>), grid, dim3(256), 0, stream, rowptr, colind,
-                       vals, X, Y, Z, Z2, alpha, beta, gamma, v_out, v_in, C, cpr, B);
+                       vals, X, Y, Z, Z2, alpha, beta, gamma, v_out, v_in, C, cpr, B, row_blocks, swz);
     return dsw_check_launch();
 }
 
@@ -172,8 +292,33 @@ int dsw_spmm_launch(const int* rowptr, const int* colind, const float* vals, int
     const bool al = dsw_aligned16(X) && dsw_aligned16(Y) && (Z == nullptr || dsw_aligned16(Z)) &&
                     (Z2 == nullptr || dsw_aligned16(Z2));
     const int vo = (int)v_out, vi = (int)v_in, c = (int)C, b = (int)B;
+    // kernel choice: LDS-tiled when a >=64-row tile of one sample fits 32 KiB and lanes divide evenly
+    static const char* force = getenv("DSW_SPMM_KERNEL");  // "rowsplit" | "tiled" (diagnostics only)
+    const int es = dtype == DSW_BF16 ? 2 : 4;
+    const int vec = dtype == DSW_BF16 ? 8 : 4;
+    int tile_rows = 0;
+    if (al && vo == vi && c % vec == 0 && c / vec <= 256) {  // square operators only: tile rows == tile columns
+        static const char* tb = getenv("DSW_SPMM_TILE_BYTES");
+        const long tile_bytes = tb ? atol(tb) : 32768;
+        long r = tile_bytes / ((long)c * es);
+        if (r > 1024) r = 1024;
+        const int rpp = 256 / (c / vec);
+        r = (r / rpp) * rpp;
+        if (r >= 64) tile_rows = (int)r;
+    }
+    const bool want_tiled = force ? (strcmp(force, "tiled") == 0) : false;
+    if (tile_rows > 0 && want_tiled && (long)((vo + tile_rows - 1) / tile_rows) * b < 2147483647L) {
+        if (dtype == DSW_F32)
+            return launch_tiled<false, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, tile_rows, stream);
+        if (dtype == DSW_BF16)
+            return launch_tiled<true, 8>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, tile_rows, stream);
+    }
+    static const char* nbs = getenv("DSW_SPMM_NB");  // diagnostics: samples per thread
+    const int nbf = nbs ? atoi(nbs) : 0;
     if (dtype == DSW_F32) {
         if (al && c % 4 == 0) {
+            if (nbf == 1) return launch_rowsplit<false, 4, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream);
+            if (nbf == 2) return launch_rowsplit<false, 4, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream);
             if (b >= 4) return launch_rowsplit<false, 4, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream);
             if (b >= 2) return launch_rowsplit<false, 4, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream);
             return launch_rowsplit<false, 4, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream);
