@@ -93,6 +93,12 @@ def spmm_algorithmic_bytes(E, Lb, K):
     return fwd, bwd
 
 
+def _native_lib():
+    from dsw_amd import _native
+
+    return _native.load()
+
+
 def roofline_leg(layer, x, steps, warmup):
     """Time exactly the SpMM launches of one fwd+bwd (K-1 basis hops + K-1 adjoint hops)."""
     from dsw_amd import functional as F_
@@ -104,17 +110,26 @@ def roofline_leg(layer, x, steps, warmup):
     es = x.element_size()
     E = B * V * C * es
     Lb = op.nnz * 8 + 4 * (V + 1)
-    hip = F_._HIP
+    lib = _native_lib()
+    dcode = 1 if x.dtype == torch.bfloat16 else 0
+    st = torch.cuda.current_stream().cuda_stream
     T = torch.empty((K - 1, B, V, C), dtype=x.dtype, device=x.device)
-    G = [torch.randn_like(x) for _ in range(K)]
+    G0 = torch.randn_like(x)
+    Gr = torch.randn((K - 1, B, V, C), dtype=x.dtype, device=x.device)
+
+    def fwd():   # K-1 launches: T_1 = L x, T_k = 2 L T_{k-1} - T_{k-2}
+        rc = lib.dsw_cheb_basis_fwd(op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz,
+                                    x.data_ptr(), T.data_ptr(), B, C, K, dcode, st)
+        assert rc == 0
+
+    def adj():   # K-1 launches: G_{j-1} += (2|1) L^T G_j - G_{j+1}
+        rc = lib.dsw_cheb_basis_adj(opt.rowptr.data_ptr(), opt.colind.data_ptr(), opt.values.data_ptr(), V, opt.nnz,
+                                    G0.data_ptr(), Gr.data_ptr(), B, C, K, dcode, st)
+        assert rc == 0
 
     def launches():
-        hip.spmm(op, x, 1.0, out=T[0])
-        for k in range(2, K):
-            hip.spmm(op, T[k - 2], 2.0, x if k == 2 else T[k - 3], -1.0, out=T[k - 1])
-        for j in range(K - 1, 0, -1):
-            hip.spmm(opt, G[j], 1.0 if j == 1 else 2.0, G[j - 1], 1.0, G[j + 1] if j + 1 <= K - 1 else None, -1.0,
-                     out=G[j - 1])
+        fwd()
+        adj()
 
     for _ in range(warmup):
         launches()
@@ -134,9 +149,7 @@ def roofline_leg(layer, x, steps, warmup):
     # forward recurrence alone (the north-star gate)
     t0.record(stream)
     for _ in range(steps):
-        hip.spmm(op, x, 1.0, out=T[0])
-        for k in range(2, K):
-            hip.spmm(op, T[k - 2], 2.0, x if k == 2 else T[k - 3], -1.0, out=T[k - 1])
+        fwd()
     t1.record(stream)
     torch.cuda.synchronize()
     fwd_s = t0.elapsed_time(t1) * 1e-3 / steps

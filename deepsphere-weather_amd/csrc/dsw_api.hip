@@ -5,7 +5,10 @@
 // internal launchers (dsw_spmm.hip / dsw_gemm.hip)
 int dsw_spmm_launch(const int* rowptr, const int* colind, const float* vals, int64_t v_out, int64_t v_in,
                     const void* X, void* Y, int64_t B, int64_t C, float alpha, const void* Z, float beta,
-                    const void* Z2, float gamma, int dtype, hipStream_t stream);
+                    const void* Z2, float gamma, int dtype, hipStream_t stream, int hints = 0);
+// hints: bit1 = the epilogue operands Z / Z2 are cold (not produced by the previous launch): stream them
+// with non-temporal loads so they do not evict the gathered rows from L2 / Infinity Cache
+#define DSW_SPMM_HINT_COLD_Z 2
 int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* bias, void* Y, int64_t N,
                        int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream);
 int dsw_mix_dgrad_launch(const void* dY, const void* W, void* G0, void* Grest, int64_t N, int64_t Fin,
@@ -65,6 +68,28 @@ int dsw_cheb_basis_fwd(const int32_t* rowptr, const int32_t* colind, const float
     return rc;
 }
 
+int dsw_cheb_basis_adj(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t, int64_t V,
+                       int64_t nnz, void* G0, void* Grest, int64_t B, int64_t C, int64_t K, int dtype,
+                       dsw_stream_t stream) {
+    if (K <= 1) return K == 1 ? DSW_OK : DSW_ERR_BAD_ARG;
+    if (V < 0 || B < 0 || C < 0 || nnz < 0) return DSW_ERR_BAD_ARG;
+    if (V == 0 || B == 0 || C == 0) return DSW_OK;
+    if (!rowptr_t || !G0 || !Grest) return DSW_ERR_BAD_ARG;
+    if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
+    const int64_t plane = B * V * C * elem_size(dtype);
+    char* G = static_cast<char*>(Grest);
+    int rc = DSW_OK;
+    for (int64_t j = K - 1; j >= 1 && rc == DSW_OK; --j) {
+        void* gm1 = (j == 1) ? G0 : static_cast<void*>(G + (j - 2) * plane);   // G_{j-1}
+        const void* gj = G + (j - 1) * plane;                                 // G_j
+        const void* gp1 = (j + 1 <= K - 1) ? (G + j * plane) : nullptr;       // G_{j+1}
+        // G_{j-1} / G_{j+1} were written by the dgrad GEMM, not by the previous launch: cold operands
+        rc = dsw_spmm_launch(rowptr_t, colind_t, vals_t, V, V, gj, gm1, B, C, (j == 1) ? 1.f : 2.f, gm1, 1.f, gp1,
+                             -1.f, dtype, (hipStream_t)stream, DSW_SPMM_HINT_COLD_Z);
+    }
+    return rc;
+}
+
 int dsw_cheb_mix_fwd(const void* X, const void* T, const void* W, const void* bias, void* Y, int64_t N,
                      int64_t Fin, int64_t Fout, int64_t K, int dtype, dsw_stream_t stream) {
     if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
@@ -114,13 +139,8 @@ int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* 
     if (dX != nullptr && N > 0) {
         if (K > 1 && !rowptr_t) return DSW_ERR_BAD_ARG;
         rc = dsw_mix_dgrad_launch(dY, W, dX, G, N, Fin, Fout, K, dtype, s);
-        for (int64_t j = K - 1; j >= 1 && rc == DSW_OK; --j) {
-            void* gm1 = (j == 1) ? dX : static_cast<void*>(G + (j - 2) * plane);   // G_{j-1}
-            const void* gj = G + (j - 1) * plane;                                 // G_j
-            const void* gp1 = (j + 1 <= K - 1) ? (G + j * plane) : nullptr;       // G_{j+1}
-            rc = dsw_spmm_launch(rowptr_t, colind_t, vals_t, V, V, gj, gm1, B, Fin, (j == 1) ? 1.f : 2.f, gm1,
-                                 1.f, gp1, -1.f, dtype, s);
-        }
+        if (rc == DSW_OK && K > 1)
+            rc = dsw_cheb_basis_adj(rowptr_t, colind_t, vals_t, V, nnz, dX, G, B, Fin, K, dtype, stream);
         if (rc != DSW_OK) return rc;
     }
     if (dW != nullptr) {

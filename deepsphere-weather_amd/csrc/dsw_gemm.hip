@@ -13,61 +13,14 @@
 // The summation order over the reduction index differs from a k-ascending loop (operands are
 // consumed in 8-wide groups, lane-half h taking elements 4h..4h+3) - irrelevant at fp32 tolerance.
 // bf16 storage is supported by widening to fp32 while staging through LDS (fp32 accumulate).
-#include "dsw_common.h"
-#include <type_traits>
+#include "dsw_gemm_common.h"
+
+using namespace dsw_gemm;
+
+// x3-split fp32 GEMM on the bf16 matrix pipe (dsw_gemm_x3.hip); returns 1 if it took the launch
+int dsw_ts_gemm_x3_try_launch(const TsGemmParams& P, int nt, int col_tiles, hipStream_t stream, int* rc);
 
 namespace {
-
-constexpr int BM = 128;       // rows of the tall operand per workgroup (4 waves x 32)
-constexpr int BN = 64;        // output columns per workgroup (2 MFMA tiles per wave)
-constexpr int BK = 32;        // reduction chunk staged in LDS
-constexpr int LDA = BK + 4;   // +4 floats: conflict-free ds_read_b128 of 16 rows (stride 36 words)
-
-template <bool BF16>
-static __device__ __forceinline__ float ld1(const void* p, size_t i) {
-    if constexpr (BF16) return bf16_to_f32(static_cast<const uint16_t*>(p)[i]);
-    else return static_cast<const float*>(p)[i];
-}
-template <bool BF16>
-static __device__ __forceinline__ void st1(void* p, size_t i, float v) {
-    if constexpr (BF16) static_cast<uint16_t*>(p)[i] = f32_to_bf16(v);
-    else static_cast<float*>(p)[i] = v;
-}
-// 4 consecutive elements; `vec` promises 4-element alignment and in-bounds
-template <bool BF16>
-static __device__ __forceinline__ float4 ld4(const void* p, size_t i) {
-    if constexpr (BF16) {
-        const uint2 t = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(p) + i);
-        return make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u),
-                           __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u));
-    } else {
-        return *reinterpret_cast<const float4*>(static_cast<const float*>(p) + i);
-    }
-}
-
-struct TsGemmParams {
-    // tall operand A: n_planes_a planes of [M, lda]; plane 0 = A0, plane p>0 = A1 + (p-1)*a_plane_stride
-    const void* A0;
-    const void* A1;
-    size_t a_plane_stride;  // elements
-    int lda;
-    int n_planes_a;
-    int kd_per_plane;       // reduction extent inside one plane
-    // small operand: element (a-plane p, c-plane q, kd, n) at Bsrc[p*b_sp + q*b_sq + kd*b_skd + n*b_sn]
-    const void* Bsrc;
-    long b_sp, b_sq, b_skd, b_sn;
-    // output: n_planes_c planes of [M, ldc]; plane 0 = C0, plane q>0 = C1 + (q-1)*c_plane_stride.
-    // Output columns are addressed flattened: j = q * n_per_plane + n.
-    void* C0;
-    void* C1;
-    size_t c_plane_stride;
-    int ldc;
-    int n_planes_c;
-    int n_per_plane;        // valid columns per output plane
-    const void* bias;       // [n_per_plane] or null (same dtype as the data)
-    long M;
-    int a_vec;              // 1 if float4/bf16x4 loads of A are legal
-};
 
 // C (M x n_total) = sum_p A[p] (M x kd) * B[p] (kd x n_total) (+ bias),  n_total = n_planes_c * n_per_plane.
 // Workgroup tile: 128 rows x 32*NT columns; wave w owns rows [32w, 32w+32) and NT 32x32 MFMA tiles.
@@ -81,7 +34,7 @@ struct TsGemmParams {
 template <bool BF16, int NT, bool RESIDENT, bool ALIGNED>
 __global__ __launch_bounds__(256) void ts_gemm_kernel(const TsGemmParams P) {
     constexpr int BNT = 32 * NT;
-    constexpr int PF = RESIDENT ? 3 : 2;   // streaming B doubles the ring's registers: keep it shallow
+    constexpr int PF = RESIDENT ? DSW_GEMM_PF : 2;   // streaming B doubles the ring's registers: keep it shallow
     constexpr int NRB = RESIDENT ? 1 : (BK * BNT) / 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;               // [BM][LDA]
@@ -137,7 +90,13 @@ __global__ __launch_bounds__(256) void ts_gemm_kernel(const TsGemmParams P) {
         col_bias[nt] = (P.bias != nullptr) ? ld1<BF16>(P.bias, n) : 0.f;
     }
 
-    const int ar = tid >> 3, ac4 = (tid & 7) * 4;   // A staging: rows ar + 32*i (i<4), 4 columns at ac4
+    // A staging.  RESIDENT: every wave stages exactly the 32 rows it consumes (rows wave*32 + (lane>>3)
+    // + 8*i), so the LDS hand-off is wave-local and the main loop needs NO workgroup barrier - waves
+    // drift apart and overlap each other's load / LDS / MFMA phases.  Streaming-B mode shares the B
+    // chunk across waves and keeps the two barriers (rows ar + 32*i).
+    const int ar = RESIDENT ? (wave * 32 + (lane >> 3)) : (tid >> 3);
+    constexpr int AR_STEP = RESIDENT ? 8 : 32;
+    const int ac4 = (tid & 7) * 4;
     float4 ra[PF][4];
     float rb[PF][NRB];
 
@@ -146,7 +105,7 @@ __global__ __launch_bounds__(256) void ts_gemm_kernel(const TsGemmParams P) {
 
     // Branch-free in the ALIGNED case (row index clamped instead of predicated): hipcc only keeps
     // counted s_waitcnt vmcnt(N) - i.e. leaves the younger ring slots in flight - in straight-line code.
-    auto fetch = [&](long it, float4 (&dra)[4], float (&drb)[NRB]) {
+    auto fetch = [&](long it, float4 (&dra)[4], float (&drb)[NRB]) __attribute__((always_inline)) {
         const long ti = it / total;
         const int c = (int)(it - ti * total);
         const long row0 = ((long)blockIdx.x + ti * gridDim.x) * BM;
@@ -156,7 +115,7 @@ __global__ __launch_bounds__(256) void ts_gemm_kernel(const TsGemmParams P) {
         const size_t abase = (p == 0) ? 0 : (size_t)(p - 1) * P.a_plane_stride;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            long r = row0 + ar + 32 * i;
+            long r = row0 + ar + AR_STEP * i;
             const int kc = k0 + ac4;
             if constexpr (ALIGNED) {
                 r = r < P.M ? r : P.M - 1;  // rows >= M are computed on a copy of the last row, never stored
@@ -186,48 +145,69 @@ __global__ __launch_bounds__(256) void ts_gemm_kernel(const TsGemmParams P) {
         }
     };
 
+    if constexpr (RESIDENT) __syncthreads();   // B panel written by all waves (the only workgroup barrier)
     if (n_iter <= 0) return;
 #pragma unroll
     for (int u = 0; u < PF; ++u) fetch(u < n_iter ? u : n_iter - 1, ra[u], rb[u]);
 
     const long n_pad = (n_iter + PF - 1) / PF * PF;   // padded iterations redo the last chunk; never stored
     // one ring stage; `U` is a compile-time slot index so that ra[u] / rb[u] stay in registers
-    auto stage = [&](auto U, const long it) {
+    auto stage = [&](auto U, const long it) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value;
         const long ti = it / total;
         const int c = (int)(it - ti * total);
-        __syncthreads();  // previous chunk fully consumed (and, first time, the resident B panel written)
+        if constexpr (RESIDENT) {
+            // wave-local WAR: this wave's fragment reads of the previous chunk precede the overwrite
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            __syncthreads();  // previous chunk fully consumed by every wave
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(&As[(ar + 32 * i) * LDA + ac4]) = ra[u][i];
-        if constexpr (!RESIDENT) {
+            *reinterpret_cast<float4*>(&As[(ar + AR_STEP * i) * LDA + ac4]) = ra[u][i];
+        if constexpr (RESIDENT) {
+            // wave-local RAW: the ds_writes above are visible to this wave's lanes before the reads
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
 #pragma unroll
             for (int i = 0; i < NRB; ++i) Bs[tid + 256 * i] = rb[u][i];
+            __syncthreads();
         }
-        __syncthreads();
         {   // refill this ring slot (clamped: the tail re-reads the last chunk instead of branching)
             const long nx = it + PF;
             fetch(nx < n_iter ? nx : n_iter - 1, ra[u], rb[u]);
         }
 
+        // LDS -> registers for the whole chunk first (A: 4 x b128, B: 16*NT x b32), then the MFMAs run
+        // back to back; just-in-time operand reads would expose the LDS latency 16 times per chunk.
         const float* arow = &As[(wave * 32 + l31) * LDA + 4 * half];
-        const float* bchunk = RESIDENT ? (Bs + (size_t)c * BK * BNT) : Bs;
+        const float* bchunk = (RESIDENT ? (Bs + (size_t)c * BK * BNT) : Bs) + (4 * half) * BNT + l31;
+        float4 a4[BK / 8];
+        float bv[BK / 8][4][NT];
+#pragma unroll
+        for (int cc = 0; cc < BK / 8; ++cc) a4[cc] = *reinterpret_cast<const float4*>(arow + 8 * cc);
+#pragma unroll
+        for (int cc = 0; cc < BK / 8; ++cc)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[cc][t][nt] = bchunk[(8 * cc + t) * BNT + 32 * nt];
+        __builtin_amdgcn_sched_barrier(0);   // keep the operand reads clustered ahead of the MFMA burst
+        if (P.dbg != 2)
 #pragma unroll
         for (int cc = 0; cc < BK / 8; ++cc) {
-            const float4 a = *reinterpret_cast<const float4*>(arow + 8 * cc);
-            const float av[4] = {a.x, a.y, a.z, a.w};
+            const float av[4] = {a4[cc].x, a4[cc].y, a4[cc].z, a4[cc].w};
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int kk = 8 * cc + 4 * half + t;
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float b = bchunk[kk * BNT + 32 * nt + l31];
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], b, acc[nt], 0, 0, 0);
-                }
-            }
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[cc][t][nt], acc[nt], 0, 0, 0);
         }
 
-        if (c == total - 1 && it < n_iter) {
+        if (c == total - 1 && it < n_iter && P.dbg != 1) {
             // epilogue: C/D layout of a 32x32 tile: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
             const long row0 = ((long)blockIdx.x + ti * gridDim.x) * BM;
             const bool full_rows = row0 + BM <= P.M;
@@ -259,6 +239,9 @@ __global__ __launch_bounds__(256) void ts_gemm_kernel(const TsGemmParams P) {
         stage(std::integral_constant<int, 0>{}, base);
         stage(std::integral_constant<int, 1>{}, base + 1);
         if constexpr (PF > 2) stage(std::integral_constant<int, 2>{}, base + 2);
+        if constexpr (PF > 3) stage(std::integral_constant<int, 3>{}, base + 3);
+        if constexpr (PF > 4) stage(std::integral_constant<int, 4>{}, base + 4);
+        if constexpr (PF > 5) stage(std::integral_constant<int, 5>{}, base + 5);
     }
 }
 
@@ -287,7 +270,7 @@ template <bool BF16, int NW, bool ALIGNED>
 __global__ __launch_bounds__(64 * NW) void cheb_wgrad_kernel(const WgradParams P) {
     constexpr int NT_ = 64 * NW;                       // threads
     constexpr int RD = (WR * BN / 4 + NT_ - 1) / NT_;  // float4 of the dY tile per thread
-    constexpr int PF = 3;                              // prefetch ring depth (chunks in flight)
+    constexpr int PF = DSW_WGRAD_PF;                   // prefetch ring depth (chunks in flight)
     __shared__ __attribute__((aligned(16))) float Ts[NW][WR * 32];
     __shared__ __attribute__((aligned(16))) float Ds[WR * BN];
 
@@ -317,7 +300,7 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_kernel(const WgradParams P
     float4 rt[PF][4], rd[PF][RD];
     // ALIGNED: N % 32 == 0, so every chunk is complete and loads are unconditional (inactive waves
     // load tile 0's data and discard it) -> straight-line code, counted vmcnt, ring stays in flight.
-    auto fetch = [&](long n0, float4 (&drt)[4], float4 (&drd)[RD]) {
+    auto fetch = [&](long n0, float4 (&drt)[4], float4 (&drd)[RD]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long r = n0 + tr + 8 * i;
@@ -375,7 +358,7 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_kernel(const WgradParams P
             fetch(n_begin + (long)(u < n_chunks ? u : n_chunks - 1) * WR, rt[u], rd[u]);
     }
     const long n_pad = (n_chunks + PF - 1) / PF * PF;   // padded chunks re-read the last one, unused
-    auto stage = [&](auto U, const long ci) {
+    auto stage = [&](auto U, const long ci) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value;
         __syncthreads();
 #pragma unroll
@@ -414,7 +397,9 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_kernel(const WgradParams P
     for (long cb = 0; cb < n_pad; cb += PF) {
         stage(std::integral_constant<int, 0>{}, cb);
         stage(std::integral_constant<int, 1>{}, cb + 1);
-        stage(std::integral_constant<int, 2>{}, cb + 2);
+        if constexpr (PF > 2) stage(std::integral_constant<int, 2>{}, cb + 2);
+        if constexpr (PF > 3) stage(std::integral_constant<int, 3>{}, cb + 3);
+        if constexpr (PF > 4) stage(std::integral_constant<int, 4>{}, cb + 4);
     }
 
     float* out = P.partial + (size_t)blockIdx.x * (size_t)(Kd + 1) * P.Fout;
@@ -482,6 +467,10 @@ static int launch_ts_gemm_nt(const TsGemmParams& P, int col_tiles, hipStream_t s
     const size_t b_res = (size_t)P.n_planes_a * chunks * BK * BNT * 4;
     const bool resident = b_res <= 44 * 1024;   // A tile (18 KiB) + B panel stay under the 64 KiB default LDS limit
     const bool aligned = P.a_vec && (P.kd_per_plane % BK == 0);
+    if constexpr (!BF16) {
+        int rc = DSW_OK;
+        if (aligned && dsw_ts_gemm_x3_try_launch(P, NT, col_tiles, stream, &rc)) return rc;
+    }
     if (resident) {
         const size_t lds = a_bytes + b_res;
         int per_cu = 0;
@@ -528,6 +517,7 @@ int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* 
     P.Bsrc = W; P.b_sp = Fout; P.b_sq = 0; P.b_skd = K * Fout; P.b_sn = 1;
     P.C0 = Y; P.C1 = Y; P.c_plane_stride = 0; P.ldc = (int)Fout; P.n_planes_c = 1; P.n_per_plane = (int)Fout;
     P.bias = bias; P.M = N;
+    { static const char* d = getenv("DSW_DBG"); P.dbg = d ? atoi(d) : 0; }
     const uintptr_t am = (uintptr_t)(4 * es) - 1;
     P.a_vec = (Fin % 4 == 0) && (((uintptr_t)X & am) == 0) && (K == 1 || ((uintptr_t)T & am) == 0);
     if (dtype == DSW_F32) return launch_ts_gemm<false>(P, stream);
@@ -547,6 +537,7 @@ int dsw_mix_dgrad_launch(const void* dY, const void* W, void* G0, void* Grest, i
     P.C0 = G0; P.C1 = Grest; P.c_plane_stride = (size_t)N * Fin; P.ldc = (int)Fin; P.n_planes_c = (int)K;
     P.n_per_plane = (int)Fin;
     P.bias = nullptr; P.M = N;
+    { static const char* d = getenv("DSW_DBG"); P.dbg = d ? atoi(d) : 0; }
     const uintptr_t am = (uintptr_t)(4 * es) - 1;
     P.a_vec = (Fout % 4 == 0) && (((uintptr_t)dY & am) == 0);
     if (dtype == DSW_F32) return launch_ts_gemm<false>(P, stream);

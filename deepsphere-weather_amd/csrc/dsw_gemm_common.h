@@ -1,0 +1,69 @@
+// Shared definitions of the tall-skinny MFMA contractions (dsw_gemm.hip, dsw_gemm_x3.hip).
+#pragma once
+#include "dsw_common.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace dsw_gemm {
+
+#ifndef DSW_GEMM_PF
+#define DSW_GEMM_PF 3   // A-chunk prefetch ring depth of the resident-panel GEMM
+#endif
+#ifndef DSW_WGRAD_PF
+#define DSW_WGRAD_PF 3  // chunk prefetch ring depth of wgrad
+#endif
+
+constexpr int BM = 128;       // rows of the tall operand per workgroup (4 waves x 32)
+constexpr int BN = 64;        // output columns per workgroup (2 MFMA tiles per wave)
+constexpr int BK = 32;        // reduction chunk staged in LDS
+constexpr int LDA = BK + 4;   // +4 floats: conflict-free ds_read_b128 of 16 rows (stride 36 words)
+
+template <bool BF16>
+static __device__ __forceinline__ float ld1(const void* p, size_t i) {
+    if constexpr (BF16) return bf16_to_f32(static_cast<const uint16_t*>(p)[i]);
+    else return static_cast<const float*>(p)[i];
+}
+template <bool BF16>
+static __device__ __forceinline__ void st1(void* p, size_t i, float v) {
+    if constexpr (BF16) static_cast<uint16_t*>(p)[i] = f32_to_bf16(v);
+    else static_cast<float*>(p)[i] = v;
+}
+// 4 consecutive elements; `vec` promises 4-element alignment and in-bounds
+template <bool BF16>
+static __device__ __forceinline__ float4 ld4(const void* p, size_t i) {
+    if constexpr (BF16) {
+        const uint2 t = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(p) + i);
+        return make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u),
+                           __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u));
+    } else {
+        return *reinterpret_cast<const float4*>(static_cast<const float*>(p) + i);
+    }
+}
+
+struct TsGemmParams {
+    // tall operand A: n_planes_a planes of [M, lda]; plane 0 = A0, plane p>0 = A1 + (p-1)*a_plane_stride
+    const void* A0;
+    const void* A1;
+    size_t a_plane_stride;  // elements
+    int lda;
+    int n_planes_a;
+    int kd_per_plane;       // reduction extent inside one plane
+    // small operand: element (a-plane p, c-plane q, kd, n) at Bsrc[p*b_sp + q*b_sq + kd*b_skd + n*b_sn]
+    const void* Bsrc;
+    long b_sp, b_sq, b_skd, b_sn;
+    // output: n_planes_c planes of [M, ldc]; plane 0 = C0, plane q>0 = C1 + (q-1)*c_plane_stride.
+    // Output columns are addressed flattened: j = q * n_per_plane + n.
+    void* C0;
+    void* C1;
+    size_t c_plane_stride;
+    int ldc;
+    int n_planes_c;
+    int n_per_plane;        // valid columns per output plane
+    const void* bias;       // [n_per_plane] or null (same dtype as the data)
+    long M;
+    int a_vec;              // 1 if float4/bf16x4 loads of A are legal
+    int dbg;                // diagnostics (DSW_DBG env): 1 = skip the epilogue stores, 2 = skip the MFMAs
+};
+
+
+}  // namespace dsw_gemm

@@ -1,0 +1,235 @@
+// fp32 channel-mix GEMM evaluated on the bf16 matrix pipe by exact 3-way operand splitting.
+#include "dsw_gemm_common.h"
+
+using namespace dsw_gemm;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// fp32 contraction on the bf16 matrix pipe ("x3 split"): the fp32 MFMA runs at the VALU rate
+// (157 TFLOP/s, 64 cycles per 32x32x2), 16x slower than v_mfma_f32_32x32x16_bf16.  Each fp32
+// operand is split EXACTLY into three bf16 terms  x = x_h + x_m + x_l  (8+8+8 mantissa bits, by
+// truncation, residuals computed exactly in fp32) and the product is evaluated with the six
+// leading terms  a_h b_h + a_h b_m + a_m b_h + a_h b_l + a_m b_m + a_l b_h  in fp32 accumulators.
+// The dropped terms are O(2^-24 |a||b|), i.e. fp32-rounding class: the result is an fp32 GEMM
+// (measured max-rel error vs fp64 is within the same 2e-6 bound the tests apply to the exact-fp32
+// path) at 6/16 of the matrix-pipe time.  Same tiling / ring / wave-local staging as the resident
+// ts_gemm kernel; the B panel is pre-split once into three bf16 planes in LDS, stored [plane][col][k]
+// (k contiguous, rows padded by 16 B -> conflict-free ds_read_b128).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+static __device__ __forceinline__ bf16x8_t pack_bf16x8(const float (&f)[8]) {
+    // truncating fp32 -> bf16 of 8 values: v_perm_b32 picks the two high bytes of each pair
+    uint4 u;
+    u.x = __builtin_amdgcn_perm(__float_as_uint(f[1]), __float_as_uint(f[0]), 0x07060302u);
+    u.y = __builtin_amdgcn_perm(__float_as_uint(f[3]), __float_as_uint(f[2]), 0x07060302u);
+    u.z = __builtin_amdgcn_perm(__float_as_uint(f[5]), __float_as_uint(f[4]), 0x07060302u);
+    u.w = __builtin_amdgcn_perm(__float_as_uint(f[7]), __float_as_uint(f[6]), 0x07060302u);
+    return __builtin_bit_cast(bf16x8_t, u);
+}
+static __device__ __forceinline__ float trunc_bf16(float f) {
+    return __uint_as_float(__float_as_uint(f) & 0xffff0000u);
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void ts_gemm_x3_kernel(const TsGemmParams P) {
+    constexpr int BNT = 32 * NT;
+    constexpr int PF = 3;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                                  // [BM][LDA] fp32 staging
+    unsigned short* Bt = reinterpret_cast<unsigned short*>(smem + BM * LDA);  // [3][BNT][KS] bf16
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int n_total = P.n_planes_c * P.n_per_plane;
+    const int col0 = blockIdx.y * BNT;
+    const int chunks = P.kd_per_plane / BK;             // ALIGNED: kd_per_plane % 32 == 0
+    const int total = P.n_planes_a * chunks;
+    const int KS = total * BK + 8;                      // padded k-stride of a B row (bf16 elements)
+    const long row_tiles = (P.M + BM - 1) / BM;
+
+    // B panel: split once
+    for (int e = tid; e < total * BK * BNT; e += 256) {
+        const int r = e / BNT, jj = e - r * BNT;        // r = flattened reduction index, jj = tile column
+        const int pa = r / P.kd_per_plane, kd = r - pa * P.kd_per_plane;
+        const int j = col0 + jj;
+        float v = 0.f;
+        if (j < n_total) {
+            const int q = j / P.n_per_plane, n = j - q * P.n_per_plane;
+            v = static_cast<const float*>(P.Bsrc)[(long)pa * P.b_sp + (long)q * P.b_sq + (long)kd * P.b_skd + (long)n * P.b_sn];
+        }
+        const float h = trunc_bf16(v), r1 = v - h, m = trunc_bf16(r1), l = trunc_bf16(r1 - m);
+        Bt[(0 * BNT + jj) * KS + r] = (unsigned short)(__float_as_uint(h) >> 16);
+        Bt[(1 * BNT + jj) * KS + r] = (unsigned short)(__float_as_uint(m) >> 16);
+        Bt[(2 * BNT + jj) * KS + r] = (unsigned short)(__float_as_uint(l) >> 16);
+    }
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    bool col_ok[NT];
+    char* col_ptr[NT];
+    float col_bias[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int j = col0 + 32 * nt + l31;
+        col_ok[nt] = j < n_total;
+        const int q = col_ok[nt] ? j / P.n_per_plane : 0;
+        const int n = col_ok[nt] ? j - q * P.n_per_plane : 0;
+        char* base = static_cast<char*>((q == 0) ? P.C0 : P.C1);
+        const size_t cbase = (q == 0) ? 0 : (size_t)(q - 1) * P.c_plane_stride;
+        col_ptr[nt] = base + (cbase + (size_t)n) * 4;
+        col_bias[nt] = (P.bias != nullptr) ? static_cast<const float*>(P.bias)[n] : 0.f;
+    }
+
+    const int ar = wave * 32 + (lane >> 3);           // wave-local staging rows ar + 8*i
+    const int ac4 = (tid & 7) * 4;
+    f32x4 ra0[4], ra1[4], ra2[4];   // ring slots as separate arrays: guaranteed register-resident
+    const long my_tiles = (row_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const long n_iter = my_tiles * total;
+
+    auto fetch = [&](long it, f32x4 (&dra)[4]) __attribute__((always_inline)) {
+        const long ti = it / total;
+        const int c = (int)(it - ti * total);
+        const long row0 = ((long)blockIdx.x + ti * gridDim.x) * BM;
+        const int p = c / chunks;
+        const int k0 = (c - p * chunks) * BK;
+        const float* A = static_cast<const float*>((p == 0) ? P.A0 : P.A1);
+        const size_t abase = (p == 0) ? 0 : (size_t)(p - 1) * P.a_plane_stride;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long r = row0 + ar + 8 * i;
+            r = r < P.M ? r : P.M - 1;
+            dra[i] = *reinterpret_cast<const f32x4*>(A + abase + (size_t)r * P.lda + k0 + ac4);
+        }
+    };
+
+    __syncthreads();   // B panel complete (the only workgroup barrier)
+    if (n_iter <= 0) return;
+    fetch(0, ra0);
+    fetch(1 < n_iter ? 1 : n_iter - 1, ra1);
+    fetch(2 < n_iter ? 2 : n_iter - 1, ra2);
+    const long n_pad = (n_iter + PF - 1) / PF * PF;
+
+    auto stage = [&](auto U, const long it) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value;
+        f32x4 (&slot)[4] = *[&]() -> f32x4 (*)[4] {
+            if constexpr (u == 0) return &ra0;
+            else if constexpr (u == 1) return &ra1;
+            else return &ra2;
+        }();
+        const long ti = it / total;
+        const int c = (int)(it - ti * total);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<f32x4*>(&As[(ar + 8 * i) * LDA + ac4]) = slot[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            const long nx = it + PF;
+            fetch(nx < n_iter ? nx : n_iter - 1, slot);
+        }
+        const float* arow = &As[(wave * 32 + l31) * LDA + 8 * half];
+        const unsigned short* brow = Bt + (size_t)l31 * KS + c * BK + 8 * half;
+#pragma unroll
+        for (int s2 = 0; s2 < BK / 16; ++s2) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(arow + 16 * s2);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(arow + 16 * s2 + 4);
+            const float f[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            float r1[8], r2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                r1[j] = f[j] - trunc_bf16(f[j]);
+                r2[j] = r1[j] - trunc_bf16(r1[j]);
+            }
+            const bf16x8_t ah = pack_bf16x8(f), am = pack_bf16x8(r1), al = pack_bf16x8(r2);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const unsigned short* bp = brow + (size_t)(32 * nt) * KS + 16 * s2;
+                const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(bp);
+                const bf16x8_t bm = *reinterpret_cast<const bf16x8_t*>(bp + (size_t)BNT * KS);
+                const bf16x8_t bl = *reinterpret_cast<const bf16x8_t*>(bp + (size_t)2 * BNT * KS);
+                f32x16 a_ = acc[nt];
+                a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, a_, 0, 0, 0);
+                a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, a_, 0, 0, 0);
+                a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, a_, 0, 0, 0);
+                a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, a_, 0, 0, 0);
+                a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, a_, 0, 0, 0);
+                a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, a_, 0, 0, 0);
+                acc[nt] = a_;
+            }
+        }
+
+        if (c == total - 1 && it < n_iter) {
+            const long row0 = ((long)blockIdx.x + ti * gridDim.x) * BM;
+            const bool full_rows = row0 + BM <= P.M;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                char* C = col_ptr[nt];
+                const float bias = col_bias[nt];
+                const long rbase = row0 + wave * 32 + 4 * half;
+                if (full_rows) {
+                    if (col_ok[nt]) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            st1<false>(C, (size_t)(rbase + (i & 3) + 8 * (i >> 2)) * P.ldc, acc[nt][i] + bias);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const long r = rbase + (i & 3) + 8 * (i >> 2);
+                        if (col_ok[nt] && r < P.M) st1<false>(C, (size_t)r * P.ldc, acc[nt][i] + bias);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+            }
+        }
+    };
+    for (long base = 0; base < n_pad; base += PF) {
+        stage(std::integral_constant<int, 0>{}, base);
+        stage(std::integral_constant<int, 1>{}, base + 1);
+        stage(std::integral_constant<int, 2>{}, base + 2);
+    }
+}
+
+
+template <int NT>
+int launch_x3(const TsGemmParams& P, int col_tiles, size_t lds, hipStream_t stream) {
+    const long row_tiles = (P.M + BM - 1) / BM;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ts_gemm_x3_kernel<NT>, 256, lds) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+    long gx = 256L * per_cu / col_tiles;
+    if (gx < 1) gx = 1;
+    if (gx > row_tiles) gx = row_tiles;
+    dim3 grid((unsigned)gx, (unsigned)col_tiles);
+    hipLaunchKernelGGL((ts_gemm_x3_kernel<NT>), grid, dim3(256), lds, stream, P);
+    return dsw_check_launch();
+}
+
+}  // namespace
+
+// Takes the launch (returns 1, *rc = status) when the aligned fp32 problem's split B panel fits LDS.
+int dsw_ts_gemm_x3_try_launch(const TsGemmParams& P, int nt, int col_tiles, hipStream_t stream, int* rc) {
+    static const char* x3env = getenv("DSW_GEMM_X3");   // "0": exact fp32 MFMA path (diagnostics / A-B)
+    if (x3env && x3env[0] == '0') return 0;
+    const int chunks = P.kd_per_plane / BK;
+    const size_t ks = (size_t)P.n_planes_a * chunks * BK + 8;
+    const size_t lds = (size_t)BM * LDA * 4 + 3 * (size_t)(32 * nt) * ks * 2;
+    if (lds > 64 * 1024) return 0;
+    switch (nt) {
+        case 1: *rc = launch_x3<1>(P, col_tiles, lds, stream); return 1;
+        case 2: *rc = launch_x3<2>(P, col_tiles, lds, stream); return 1;
+        case 3: *rc = launch_x3<3>(P, col_tiles, lds, stream); return 1;
+        case 4: *rc = launch_x3<4>(P, col_tiles, lds, stream); return 1;
+    }
+    return 0;
+}

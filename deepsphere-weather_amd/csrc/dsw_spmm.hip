@@ -32,6 +32,17 @@ struct Vec<false, 4> {
     static __device__ __forceinline__ void store(void* base, size_t elem, const float (&v)[4]) {
         *reinterpret_cast<float4*>(static_cast<float*>(base) + elem) = make_float4(v[0], v[1], v[2], v[3]);
     }
+    // streaming (non-temporal) forms for data that this kernel touches exactly once (Z, Z2, Y): they
+    // should not evict the gathered X rows, which are re-read k+1 times, from L2
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ void load_nt(const void* base, size_t elem, float (&v)[4]) {
+        const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(static_cast<const float*>(base) + elem));
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    }
+    static __device__ __forceinline__ void store_nt(void* base, size_t elem, const float (&v)[4]) {
+        f4v t = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(static_cast<float*>(base) + elem));
+    }
 };
 template <>
 struct Vec<false, 1> {
@@ -41,6 +52,8 @@ struct Vec<false, 1> {
     static __device__ __forceinline__ void store(void* base, size_t elem, const float (&v)[1]) {
         static_cast<float*>(base)[elem] = v[0];
     }
+    static __device__ __forceinline__ void load_nt(const void* b, size_t e, float (&v)[1]) { load(b, e, v); }
+    static __device__ __forceinline__ void store_nt(void* b, size_t e, const float (&v)[1]) { store(b, e, v); }
 };
 template <>
 struct Vec<true, 8> {
@@ -60,6 +73,8 @@ struct Vec<true, 8> {
             w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
         *reinterpret_cast<uint4*>(static_cast<uint16_t*>(base) + elem) = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    static __device__ __forceinline__ void load_nt(const void* b, size_t e, float (&v)[8]) { load(b, e, v); }
+    static __device__ __forceinline__ void store_nt(void* b, size_t e, const float (&v)[8]) { store(b, e, v); }
 };
 template <>
 struct Vec<true, 1> {
@@ -69,6 +84,8 @@ struct Vec<true, 1> {
     static __device__ __forceinline__ void store(void* base, size_t elem, const float (&v)[1]) {
         static_cast<uint16_t*>(base)[elem] = f32_to_bf16(v[0]);
     }
+    static __device__ __forceinline__ void load_nt(const void* b, size_t e, float (&v)[1]) { load(b, e, v); }
+    static __device__ __forceinline__ void store_nt(void* b, size_t e, const float (&v)[1]) { store(b, e, v); }
 };
 
 // One thread = (row, VEC-wide channel chunk) x NB samples.
@@ -86,7 +103,7 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit(
     const long nwg = gridDim.x;
     const long orig = blockIdx.x;
     long wg = orig;
-    if (xcd_swizzle) {
+    if (xcd_swizzle & 1) {
         const long q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
@@ -148,17 +165,17 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit(
         for (int j = 0; j < VEC; ++j) o[j] = alpha * acc[i][j];
         if (Z != nullptr) {
             float z[VEC];
-            V::load(Z, off, z);
+            if (xcd_swizzle & 2) V::load_nt(Z, off, z); else V::load(Z, off, z);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) o[j] = fmaf(beta, z[j], o[j]);
         }
         if (Z2 != nullptr) {
             float z[VEC];
-            V::load(Z2, off, z);
+            if (xcd_swizzle & 2) V::load_nt(Z2, off, z); else V::load(Z2, off, z);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) o[j] = fmaf(gamma, z[j], o[j]);
         }
-        V::store(Y, off, o);
+        if (xcd_swizzle & 4) V::store_nt(Y, off, o); else V::store(Y, off, o);
     }
 }
 
@@ -266,13 +283,14 @@ int launch_tiled(const int* rowptr, const int* colind, const float* vals, const 
 template <bool BF16, int VEC, int NB>
 int launch_rowsplit(const int* rowptr, const int* colind, const float* vals, const void* X, void* Y,
                     const void* Z, const void* Z2, float alpha, float beta, float gamma, int v_out,
-                    int v_in, int C, int B, hipStream_t stream) {
+                    int v_in, int C, int B, hipStream_t stream, int hints = 0) {
     const int cpr = C / VEC;
     const long threads = (long)v_out * cpr;
     const long row_blocks = (threads + 255) / 256;
     const long bgroups = (B + NB - 1) / NB;
     static const char* sw = getenv("DSW_SPMM_XCD");  // "0" disables the XCD-aware block order (diagnostics)
-    const int swz = (sw && sw[0] == '0') ? 0 : 1;
+    // bit0: XCD block order, bit1: nt loads of Z/Z2, bit2: nt stores of Y (env overrides the caller's hints)
+    const int swz = sw ? atoi(sw) : (1 | (hints & 6));
     dim3 grid((unsigned)(row_blocks * bgroups));
     hipLaunchKernelGGL((spmm_csr_rowsplit<BF16, VEC, NB>), grid, dim3(256), 0, stream, rowptr, colind,
                        vals, X, Y, Z, Z2, alpha, beta, gamma, v_out, v_in, C, cpr, B, row_blocks, swz);
@@ -284,7 +302,7 @@ int launch_rowsplit(const int* rowptr, const int* colind, const float* vals, con
 // Internal C++ entry used by dsw_api.hip
 int dsw_spmm_launch(const int* rowptr, const int* colind, const float* vals, int64_t v_out, int64_t v_in,
                     const void* X, void* Y, int64_t B, int64_t C, float alpha, const void* Z, float beta,
-                    const void* Z2, float gamma, int dtype, hipStream_t stream) {
+                    const void* Z2, float gamma, int dtype, hipStream_t stream, int hints) {
     if (v_out <= 0 || v_in <= 0 || B <= 0 || C <= 0) return (v_out == 0 || B == 0) ? DSW_OK : DSW_ERR_BAD_ARG;
     if (v_out > INT32_MAX || v_in > INT32_MAX || C > INT32_MAX || B > 65535 * 4) return DSW_ERR_BAD_ARG;
     if (Z == nullptr) beta = 0.f;
@@ -317,22 +335,22 @@ int dsw_spmm_launch(const int* rowptr, const int* colind, const float* vals, int
     const int nbf = nbs ? atoi(nbs) : 0;
     if (dtype == DSW_F32) {
         if (al && c % 4 == 0) {
-            if (nbf == 1) return launch_rowsplit<false, 4, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream);
-            if (nbf == 2) return launch_rowsplit<false, 4, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream);
-            if (b >= 4) return launch_rowsplit<false, 4, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream);
-            if (b >= 2) return launch_rowsplit<false, 4, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream);
-            return launch_rowsplit<false, 4, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream);
+            if (nbf == 1) return launch_rowsplit<false, 4, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
+            if (nbf == 2) return launch_rowsplit<false, 4, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
+            if (b >= 4) return launch_rowsplit<false, 4, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
+            if (b >= 2) return launch_rowsplit<false, 4, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
+            return launch_rowsplit<false, 4, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
         }
-        if (b >= 4) return launch_rowsplit<false, 1, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream);
-        return launch_rowsplit<false, 1, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream);
+        if (b >= 4) return launch_rowsplit<false, 1, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
+        return launch_rowsplit<false, 1, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
     }
     if (dtype == DSW_BF16) {
         if (al && c % 8 == 0) {
-            if (b >= 2) return launch_rowsplit<true, 8, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream);
-            return launch_rowsplit<true, 8, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream);
+            if (b >= 2) return launch_rowsplit<true, 8, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
+            return launch_rowsplit<true, 8, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
         }
-        if (b >= 4) return launch_rowsplit<true, 1, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream);
-        return launch_rowsplit<true, 1, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream);
+        if (b >= 4) return launch_rowsplit<true, 1, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
+        return launch_rowsplit<true, 1, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
     }
     return DSW_ERR_BAD_DTYPE;
 }

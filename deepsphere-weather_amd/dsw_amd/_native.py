@@ -10,7 +10,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdsw_hip.so")
+LIB_PATH = os.environ.get("DSW_HIP_LIB") or os.path.join(_HERE, "libdsw_hip.so")  # env: A/B builds only
 
 DSW_F32 = 0
 DSW_BF16 = 1
@@ -31,6 +31,7 @@ SIGNATURES = {
         [_i32p, _i32p, _f32p, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _f32, _vp, _f32, _vp, _f32, _int, _vp],
     ),
     "dsw_cheb_basis_fwd": (_int, [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _int, _vp]),
+    "dsw_cheb_basis_adj": (_int, [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _int, _vp]),
     "dsw_cheb_mix_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp]),
     "dsw_cheb_fwd": (
         _int,

@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
-SOURCES = ["dsw_api.hip", "dsw_spmm.hip", "dsw_gemm.hip"]
+SOURCES = ["dsw_api.hip", "dsw_spmm.hip", "dsw_gemm.hip", "dsw_gemm_x3.hip"]
 OUT = os.path.join(HERE, "libdsw_hip.so")
 
 
@@ -26,10 +26,26 @@ def needs_build():
 
 
 def build(force=False, verbose=True):
+    """Compile every .hip translation unit for gfx950 (in parallel) and link libdsw_hip.so."""
     if not force and not needs_build():
         return OUT
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", OUT]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    from concurrent.futures import ThreadPoolExecutor
+
+    objdir = os.path.join(CSRC, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc_path(), *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print("[dsw build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs]
     if verbose:
         print("[dsw build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)

@@ -67,6 +67,14 @@ int dsw_cheb_basis_fwd(const int32_t* rowptr, const int32_t* colind, const float
                        int64_t V, int64_t nnz, const void* X, void* T,
                        int64_t B, int64_t C, int64_t K, int dtype, dsw_stream_t stream);
 
+/* Adjoint of the Chebyshev recurrence (what autograd derives for layers.py:163-169), in place on
+ * the K gradient planes G_0 (= the dX buffer, [B,V,C]) and G_1..G_{K-1} (Grest, [K-1,B,V,C]):
+ *     for j = K-1 .. 1:   G_{j-1} += (j > 1 ? 2 : 1) * L^T G_j - G_{j+1}        (G_K := 0)
+ * after which G_0 holds dX.  rowptr_t/colind_t/vals_t: CSR of L^T. */
+int dsw_cheb_basis_adj(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t,
+                       int64_t V, int64_t nnz, void* G0, void* Grest,
+                       int64_t B, int64_t C, int64_t K, int dtype, dsw_stream_t stream);
+
 /* Channel mix on the matrix cores:  Y[n,o] = bias[o] + sum_{k,f} T_k[n,f] * W[f,k,o]
  * (layers.py:171-178 and the bias add at :375).  X = T_0 [N,Fin]; T = T_1.. [K-1,N,Fin];
  * W: [Fin,K,Fout] (the reference's parameter layout); bias [Fout] or NULL; Y: [N,Fout]. */

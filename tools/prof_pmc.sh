@@ -1,0 +1,29 @@
+#!/bin/bash
+# usage: tools/prof_pmc.sh <tag> <bench args...>
+# PMC passes (each in its own rocprofv3 run, --kernel-trace only, as the MI355X guide prescribes):
+#   pass A: FETCH_SIZE (3 TCC slots)   pass B: WRITE_SIZE   pass C: MFMA busy / active cycles
+tag=$1; shift
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+for pass in "A FETCH_SIZE" "B WRITE_SIZE" "C SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "D TCC_HIT_sum TCC_MISS_sum"; do
+  set -- $pass; p=$1; shift
+  out=$root/gpurun_out/pmc_${tag}_$p
+  mkdir -p $out
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $@ --output-format csv -d $out -o pmc -- python $root/bench.py ${BENCH_ARGS:---steps 10 --warmup 3 --no-cpu-baseline} > $out/run.log 2>&1
+  echo "pass $p ($@): rc=$?"
+done
+cd $root
+python - "$tag" <<'PY'
+import csv, glob, sys, collections, os
+tag = sys.argv[1]
+root = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(f"{root}/gpurun_out/pmc_{tag}_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0][-60:]
+        agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in sorted(agg.items()):
+    if not any(s in k for s in ("spmm", "gemm", "wgrad", "cheb")):
+        continue
+    print(k, {c: (round(sum(v) / len(v), 1), len(v)) for c, v in d.items()})
+PY
