@@ -116,15 +116,18 @@ def roofline_leg(layer, x, steps, warmup):
     T = torch.empty((K - 1, B, V, C), dtype=x.dtype, device=x.device)
     G0 = torch.randn_like(x)
     Gr = torch.randn((K - 1, B, V, C), dtype=x.dtype, device=x.device)
+    spare = torch.empty((2, B, V, C), dtype=x.dtype, device=x.device)
+    pp, _k1 = F_._plan_ptr(op, x) if F_._FWD_FUSED else (None, None)
+    ppt, _k2 = F_._plan_ptr(opt, x)
 
     def fwd():   # K-1 launches: T_1 = L x, T_k = 2 L T_{k-1} - T_{k-2}
         rc = lib.dsw_cheb_basis_fwd(op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz,
-                                    x.data_ptr(), T.data_ptr(), B, C, K, dcode, st)
+                                    x.data_ptr(), T.data_ptr(), B, C, K, dcode, st, pp)
         assert rc == 0
 
     def adj():   # K-1 launches: G_{j-1} += (2|1) L^T G_j - G_{j+1}
         rc = lib.dsw_cheb_basis_adj(opt.rowptr.data_ptr(), opt.colind.data_ptr(), opt.values.data_ptr(), V, opt.nnz,
-                                    G0.data_ptr(), Gr.data_ptr(), B, C, K, dcode, st)
+                                    G0.data_ptr(), Gr.data_ptr(), B, C, K, dcode, st, ppt, spare.data_ptr())
         assert rc == 0
 
     def launches():
@@ -141,7 +144,9 @@ def roofline_leg(layer, x, steps, warmup):
         launches()
     t1.record(stream)
     torch.cuda.synchronize()
-    n_launch = 2 * (K - 1)
+    hops = 2 * (K - 1)                      # operator applications per step (forward + adjoint)
+    pairs = (K - 1 + 1) // 2                # launches of a pairwise-fused recurrence
+    n_launch = ((K - 1) if pp is None else pairs) + ((K - 1) if ppt is None else pairs)
     avg_s = t0.elapsed_time(t1) * 1e-3 / (steps * n_launch)
     fwd_b, bwd_b = spmm_algorithmic_bytes(E, Lb, K)
     bytes_per_launch = (fwd_b + bwd_b) / n_launch
@@ -161,7 +166,10 @@ def roofline_leg(layer, x, steps, warmup):
         except Exception:
             traffic = None
     return {
-        "bound": "hbm", "kernel": "spmm_csr (Chebyshev recurrence + adjoint, %d launches/step)" % n_launch,
+        "bound": "hbm",
+        "kernel": ("SpMM recurrence: forward %s + adjoint %s, %d launches/step" % (
+            "spmm2_fused" if pp is not None else "spmm_csr x%d" % (K - 1),
+            "spmm2_fused" if ppt is not None else "spmm_csr x%d" % (K - 1), n_launch)),
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 2),
@@ -175,7 +183,6 @@ def cpu_baseline_leg(wl, lap, layer):
     from oracle import cheb_oracle as orc
 
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     V = 12 * wl["nside"] ** 2
     B = wl["batch"]
     torch.manual_seed(1234)
@@ -184,19 +191,32 @@ def cpu_baseline_leg(wl, lap, layer):
     w = layer.weight.detach().float().cpu()
     b = layer.bias.detach().float().cpu()
     lap = lap.float().coalesce()
-    n_warm, n_iter = 2, 8
-    times = []
-    for i in range(n_warm + n_iter):
+
+    def one():
         t = time.perf_counter()
         orc.conv_cheb_fwd_bwd_torch(lap, x, w, b, gy)
-        dt = time.perf_counter() - t
-        if i >= n_warm:
-            times.append(dt)
-        if sum(times) > 30.0:
+        return time.perf_counter() - t
+
+    # ATen's sparse CPU kernels stop scaling (and then regress) well below the core count of a GPU
+    # host: pick the fastest of a few thread counts with one probe each, then time that setting.
+    best_thr, best_t = 1, float("inf")
+    for thr in sorted({min(cores, c) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(thr)
+        one()
+        t = one()
+        if t < best_t:
+            best_thr, best_t = thr, t
+        if t > 6.0:
             break
+    torch.set_num_threads(best_thr)
+    times = []
+    budget = time.perf_counter() + 20.0
+    while len(times) < 8 and (time.perf_counter() < budget or len(times) < 2):
+        times.append(one())
     med = float(np.median(times))
     return {
         "value": B * V * wl["fin"] / med, "unit": "nodes*channels/s", "cores": torch.get_num_threads(),
+        "host_cpus": cores,
         "kind": "port",
         "sample": "oracle conv_cheb torch restatement (sparse COO mm + matmul, fp32), full %s shape "
                   "[B=%d,V=%d,%d->%d,K=%d], median of %d fwd+bwd, %.1f ms" % (

@@ -1,6 +1,7 @@
 // extern "C" entry points of libdsw_hip.so (see include/dsw_hip.h for the contract).
 #include "dsw_common.h"
 #include "../../include/dsw_hip.h"
+#include <cstdlib>
 
 // internal launchers (dsw_spmm.hip / dsw_gemm.hip)
 int dsw_spmm_launch(const int* rowptr, const int* colind, const float* vals, int64_t v_out, int64_t v_in,
@@ -14,6 +15,9 @@ int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* 
 int dsw_mix_dgrad_launch(const void* dY, const void* W, void* G0, void* Grest, int64_t N, int64_t Fin,
                          int64_t Fout, int64_t K, int dtype, hipStream_t stream);
 int64_t dsw_wgrad_slabs(int64_t N, int64_t Fin, int64_t Fout, int64_t K);
+int dsw_spmm2_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const void* Z1, const void* Z1b,
+                     const void* Z2, void* Y1, void* Y2, int64_t B, int64_t C, float a1, float b1, float d1,
+                     float a2, float b2, float c2, int dtype, hipStream_t stream);
 int dsw_wgrad_launch(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
                      int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream);
 
@@ -47,9 +51,18 @@ int dsw_spmm_csr(const int32_t* rowptr, const int32_t* colind, const float* vals
                            (hipStream_t)stream);
 }
 
+int dsw_spmm2_fused(const dsw_hop2_plan* plan, int64_t V, const void* U, const void* Z1, const void* Z1b,
+                    const void* Z2, void* Y1, void* Y2, int64_t B, int64_t C, float a1, float b1, float d1,
+                    float a2, float b2, float c2, int dtype, dsw_stream_t stream) {
+    if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
+    if (V < 0 || B < 0 || C < 0) return DSW_ERR_BAD_ARG;
+    return dsw_spmm2_launch(plan, V, U, Z1, Z1b, Z2, Y1, Y2, B, C, a1, b1, d1, a2, b2, c2, dtype,
+                            (hipStream_t)stream);
+}
+
 int dsw_cheb_basis_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V,
                        int64_t nnz, const void* X, void* T, int64_t B, int64_t C, int64_t K, int dtype,
-                       dsw_stream_t stream) {
+                       dsw_stream_t stream, const dsw_hop2_plan* plan) {
     if (K <= 1) return K == 1 ? DSW_OK : DSW_ERR_BAD_ARG;
     if (V < 0 || B < 0 || C < 0 || nnz < 0) return DSW_ERR_BAD_ARG;
     if (V == 0 || B == 0 || C == 0) return DSW_OK;
@@ -57,20 +70,34 @@ int dsw_cheb_basis_fwd(const int32_t* rowptr, const int32_t* colind, const float
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     const int64_t plane = B * V * C * elem_size(dtype);
     char* t = static_cast<char*>(T);
-    int rc = dsw_spmm_launch(rowptr, colind, vals, V, V, X, t, B, C, 1.f, nullptr, 0.f, nullptr, 0.f, dtype,
-                             (hipStream_t)stream);
-    for (int64_t k = 2; k < K && rc == DSW_OK; ++k) {
-        const void* prev = t + (k - 2) * plane;                     // T_{k-1}
-        const void* prev2 = (k == 2) ? X : (t + (k - 3) * plane);    // T_{k-2}
-        rc = dsw_spmm_launch(rowptr, colind, vals, V, V, prev, t + (k - 1) * plane, B, C, 2.f, prev2, -1.f,
-                             nullptr, 0.f, dtype, (hipStream_t)stream);
+    hipStream_t s = (hipStream_t)stream;
+    auto Tk = [&](int64_t k) -> const void* { return k == 0 ? X : static_cast<const void*>(t + (k - 1) * plane); };
+    // Measured on MI355X (nside=64, 32 ch, fp32): one fused launch costs ~130 us whatever it replaces; the two
+    // forward hops it would replace move 5 E and take ~112 us, the two adjoint hops move 7 E and take ~225 us.
+    // So the forward recurrence keeps one launch per hop unless DSW_HOP2_FWD=1; the adjoint runs fused.
+    static const char* fwd_env = getenv("DSW_HOP2_FWD");
+    const bool fused = plan != nullptr && fwd_env != nullptr && fwd_env[0] == '1' && dsw_spmm2_supported(plan, C, dtype);
+    int rc = DSW_OK;
+    int64_t k = 1;   // next basis index to produce
+    while (k < K && rc == DSW_OK) {
+        if (fused && k + 1 < K) {
+            // T_k = c L T_{k-1} - [k>1] T_{k-2};  T_{k+1} = 2 L T_k - T_{k-1}   (c = 1 for k = 1, else 2)
+            rc = dsw_spmm2_launch(plan, V, Tk(k - 1), k > 1 ? Tk(k - 2) : nullptr, nullptr, nullptr,
+                                  t + (k - 1) * plane, t + k * plane, B, C, k == 1 ? 1.f : 2.f, -1.f, 0.f, 2.f,
+                                  -1.f, 0.f, dtype, s);
+            k += 2;
+        } else {
+            rc = dsw_spmm_launch(rowptr, colind, vals, V, V, Tk(k - 1), t + (k - 1) * plane, B, C,
+                                 k == 1 ? 1.f : 2.f, k > 1 ? Tk(k - 2) : nullptr, -1.f, nullptr, 0.f, dtype, s);
+            k += 1;
+        }
     }
     return rc;
 }
 
 int dsw_cheb_basis_adj(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t, int64_t V,
                        int64_t nnz, void* G0, void* Grest, int64_t B, int64_t C, int64_t K, int dtype,
-                       dsw_stream_t stream) {
+                       dsw_stream_t stream, const dsw_hop2_plan* plan_t, void* spare) {
     if (K <= 1) return K == 1 ? DSW_OK : DSW_ERR_BAD_ARG;
     if (V < 0 || B < 0 || C < 0 || nnz < 0) return DSW_ERR_BAD_ARG;
     if (V == 0 || B == 0 || C == 0) return DSW_OK;
@@ -78,14 +105,40 @@ int dsw_cheb_basis_adj(const int32_t* rowptr_t, const int32_t* colind_t, const f
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     const int64_t plane = B * V * C * elem_size(dtype);
     char* G = static_cast<char*>(Grest);
+    hipStream_t s = (hipStream_t)stream;
+    const bool fused = plan_t != nullptr && dsw_spmm2_supported(plan_t, C, dtype) && (K < 4 || spare != nullptr);
+    // G'_{j-1} = G_{j-1} + c_j L^T G'_j - G'_{j+1}   (c_j = 2 for j >= 2, 1 for j = 1; G'_K = 0)
+    // loc[j]: where G'_j currently lives (its own plane, or one of the two spare planes)
+    auto own = [&](int64_t j) -> char* { return j == 0 ? static_cast<char*>(G0) : G + (j - 1) * plane; };
+    char* loc_j = own(K - 1);        // G'_{K-1} = G_{K-1}
+    char* loc_jp1 = nullptr;         // G'_{K}   = 0
+    int spare_sel = 0;
     int rc = DSW_OK;
-    for (int64_t j = K - 1; j >= 1 && rc == DSW_OK; --j) {
-        void* gm1 = (j == 1) ? G0 : static_cast<void*>(G + (j - 2) * plane);   // G_{j-1}
-        const void* gj = G + (j - 1) * plane;                                 // G_j
-        const void* gp1 = (j + 1 <= K - 1) ? (G + j * plane) : nullptr;       // G_{j+1}
-        // G_{j-1} / G_{j+1} were written by the dgrad GEMM, not by the previous launch: cold operands
-        rc = dsw_spmm_launch(rowptr_t, colind_t, vals_t, V, V, gj, gm1, B, C, (j == 1) ? 1.f : 2.f, gm1, 1.f, gp1,
-                             -1.f, dtype, (hipStream_t)stream, DSW_SPMM_HINT_COLD_Z);
+    int64_t j = K - 1;
+    while (j >= 1 && rc == DSW_OK) {
+        if (fused && j >= 2) {
+            // pair (j, j-1):  Y1 = G'_{j-1} = 2 L^T G'_j + G_{j-1} - G'_{j+1}
+            //                 Y2 = G'_{j-2} = c L^T Y1 + G_{j-2} - G'_j        (c = 1 if j-1 == 1 else 2)
+            const bool last = (j - 2 == 0);
+            // Y1 is needed later only if another step follows (as its G'_{j+1}); it cannot be written over
+            // G_{j-1} in place (neighbouring tiles read that plane as Z1), so it goes to a spare plane.
+            char* y1 = last ? nullptr : static_cast<char*>(spare) + (size_t)spare_sel * plane;
+            char* y2 = own(j - 2);   // in place: Z2 = G_{j-2} is read on the writer's own rows only
+            rc = dsw_spmm2_launch(plan_t, V, loc_j, own(j - 1), loc_jp1, own(j - 2), y1, y2, B, C, 2.f, 1.f, -1.f,
+                                  (j - 1 == 1) ? 1.f : 2.f, -1.f, 1.f, dtype, s);
+            loc_jp1 = y1;
+            loc_j = y2;
+            spare_sel ^= 1;
+            j -= 2;
+        } else {
+            // single step: G'_{j-1} = c_j L^T G'_j + G_{j-1} - G'_{j+1}, in place on plane j-1
+            char* gm1 = own(j - 1);
+            rc = dsw_spmm_launch(rowptr_t, colind_t, vals_t, V, V, loc_j, gm1, B, C, (j == 1) ? 1.f : 2.f, gm1, 1.f,
+                                 loc_jp1, -1.f, dtype, s, DSW_SPMM_HINT_COLD_Z);
+            loc_jp1 = loc_j;
+            loc_j = gm1;
+            j -= 1;
+        }
     }
     return rc;
 }
@@ -100,11 +153,11 @@ int dsw_cheb_mix_fwd(const void* X, const void* T, const void* W, const void* bi
 
 int dsw_cheb_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V, int64_t nnz,
                  const void* X, const void* W, const void* bias, void* Y, void* T, int64_t B, int64_t Fin,
-                 int64_t Fout, int64_t K, int dtype, dsw_stream_t stream) {
+                 int64_t Fout, int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan) {
     if (K <= 0) return DSW_ERR_BAD_ARG;
     int rc = DSW_OK;
     if (K > 1) {
-        rc = dsw_cheb_basis_fwd(rowptr, colind, vals, V, nnz, X, T, B, Fin, K, dtype, stream);
+        rc = dsw_cheb_basis_fwd(rowptr, colind, vals, V, nnz, X, T, B, Fin, K, dtype, stream, plan);
         if (rc != DSW_OK) return rc;
     }
     return dsw_cheb_mix_fwd(X, T, W, bias, Y, B * V, Fin, Fout, K, dtype, stream);
@@ -113,7 +166,8 @@ int dsw_cheb_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals
 int64_t dsw_cheb_bwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t Fout, int64_t K, int dtype) {
     if (B < 0 || V < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
     const int64_t N = B * V;
-    const int64_t g = round_up((K - 1) * N * Fin * elem_size(dtype), 256);
+    // G_1..G_{K-1} planes, plus two spare planes for the pairwise fused adjoint when K >= 4
+    const int64_t g = round_up((K - 1 + (K >= 4 ? 2 : 0)) * N * Fin * elem_size(dtype), 256);
     const int64_t S = dsw_wgrad_slabs(N, Fin, Fout, K);
     const int64_t p = round_up((S > 0 ? S : 1) * (K * Fin + 1) * Fout * 4, 256);
     return g + p + 256;
@@ -122,7 +176,7 @@ int64_t dsw_cheb_bwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t 
 int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t, int64_t V,
                  int64_t nnz, const void* X, const void* T, const void* W, const void* dY, void* dX, void* dW,
                  void* db, void* workspace, int64_t workspace_bytes, int64_t B, int64_t Fin, int64_t Fout,
-                 int64_t K, int dtype, dsw_stream_t stream) {
+                 int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan_t) {
     if (B < 0 || V < 0 || Fin <= 0 || Fout <= 0 || K <= 0 || nnz < 0) return DSW_ERR_BAD_ARG;
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     const int64_t need = dsw_cheb_bwd_workspace_bytes(B, V, Fin, Fout, K, dtype);
@@ -134,13 +188,15 @@ int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* 
     char* ws = reinterpret_cast<char*>(round_up((int64_t)(uintptr_t)workspace, 256));
     const int64_t plane = N * Fin * elem_size(dtype);
     char* G = ws;                                                    // G_1 .. G_{K-1}
-    float* partial = reinterpret_cast<float*>(ws + round_up((K - 1) * plane, 256));
+    char* spare = G + (K - 1) * plane;
+    float* partial = reinterpret_cast<float*>(ws + round_up((K - 1 + (K >= 4 ? 2 : 0)) * plane, 256));
     int rc = DSW_OK;
     if (dX != nullptr && N > 0) {
         if (K > 1 && !rowptr_t) return DSW_ERR_BAD_ARG;
         rc = dsw_mix_dgrad_launch(dY, W, dX, G, N, Fin, Fout, K, dtype, s);
         if (rc == DSW_OK && K > 1)
-            rc = dsw_cheb_basis_adj(rowptr_t, colind_t, vals_t, V, nnz, dX, G, B, Fin, K, dtype, stream);
+            rc = dsw_cheb_basis_adj(rowptr_t, colind_t, vals_t, V, nnz, dX, G, B, Fin, K, dtype, stream, plan_t,
+                                    K >= 4 ? spare : nullptr);
         if (rc != DSW_OK) return rc;
     }
     if (dW != nullptr) {

@@ -30,18 +30,25 @@ SIGNATURES = {
         _int,
         [_i32p, _i32p, _f32p, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _f32, _vp, _f32, _vp, _f32, _int, _vp],
     ),
-    "dsw_cheb_basis_fwd": (_int, [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _int, _vp]),
-    "dsw_cheb_basis_adj": (_int, [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _int, _vp]),
+    "dsw_spmm2_fused": (
+        _int,
+        [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp],
+    ),
+    "dsw_spmm2_supported": (_int, [_vp, _i64, _int]),
+    "dsw_cheb_basis_fwd": (_int, [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _int, _vp, _vp]),
+    "dsw_cheb_basis_adj": (
+        _int, [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp]
+    ),
     "dsw_cheb_mix_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp]),
     "dsw_cheb_fwd": (
         _int,
-        [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp],
+        [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp],
     ),
     "dsw_cheb_bwd_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64, _i64, _int]),
     "dsw_cheb_bwd": (
         _int,
         [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
-         _i64, _int, _vp],
+         _i64, _int, _vp, _vp],
     ),
 }
 

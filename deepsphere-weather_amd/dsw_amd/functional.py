@@ -44,6 +44,7 @@ class CsrOperator:
         self.shape = (int(shape[0]), int(shape[1]))
         self.nnz = int(colind.numel())
         self._t = None
+        self._plans = {}
 
     @classmethod
     def from_sparse_coo(cls, mat: torch.Tensor) -> "CsrOperator":
@@ -66,6 +67,37 @@ class CsrOperator:
     @property
     def device(self):
         return self.values.device
+
+    def hop2_plan(self, row_bytes: int):
+        """Tile plan of the fused two-hop SpMM for rows of ``row_bytes`` bytes, or ``None`` when the
+        operator is not square / the tile neighbourhoods do not fit LDS (built once, cached)."""
+        if self.shape[0] != self.shape[1] or row_bytes % 16 != 0 or not self.values.is_cuda:
+            return None
+        if row_bytes not in self._plans:
+            from . import hop2
+
+            rp, ci, va = (t.cpu().numpy() for t in (self.rowptr, self.colind, self.values))
+            import os
+
+            plan = None
+            forced = os.environ.get("DSW_HOP2_ROWS")   # diagnostics: force a tile size
+            # largest tile whose workgroup still leaves room for >= 2 workgroups per CU (<= 80 KiB of
+            # the 160 KiB LDS); a single resident workgroup (<= 156 KiB) is the last resort
+            for budget in (80 * 1024, 156 * 1024):
+                for rows in ((int(forced),) if forced else (256, 128, 64)):
+                    if rows > self.shape[0]:
+                        continue
+                    try:
+                        cand = hop2.build_hop2_plan(rp, ci, va, rows)
+                    except ValueError:
+                        continue
+                    if cand.lds_bytes(row_bytes) <= budget:
+                        plan = cand
+                        break
+                if plan is not None:
+                    break
+            self._plans[row_bytes] = None if plan is None else plan.to(self.device)
+        return self._plans[row_bytes]
 
     def transpose(self) -> "CsrOperator":
         """CSR of the transposed operator (built once, on first backward)."""
@@ -122,6 +154,22 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+def _plan_ptr(op, x):
+    """Address of the dsw_hop2_plan struct for this operator / row size, or None."""
+    if _plan_ptr.disabled:
+        return None, None
+    plan = op.hop2_plan(x.shape[-1] * x.element_size())
+    if plan is None:
+        return None, None
+    import ctypes
+
+    return ctypes.addressof(plan._struct), plan   # the plan object must outlive the call
+
+
+_plan_ptr.disabled = False
+_FWD_FUSED = __import__("os").environ.get("DSW_HOP2_FWD") == "1"   # forward hops: fused only on request (see dsw_api.hip)
+
+
 class _HipBackend:
     """Thin tensor-level wrapper over the C ABI (include/dsw_hip.h)."""
 
@@ -146,10 +194,11 @@ class _HipBackend:
         B, V, C = x.shape
         T = torch.empty((max(K - 1, 0), B, V, C), dtype=x.dtype, device=x.device)
         if K > 1:
+            pp, _keep = _plan_ptr(op, x) if (K > 2 and _FWD_FUSED) else (None, None)
             with torch.cuda.device(x.device):
                 rc = lib.dsw_cheb_basis_fwd(
                     op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz,
-                    x.data_ptr(), T.data_ptr(), B, C, K, _DTYPES[x.dtype], _stream(x),
+                    x.data_ptr(), T.data_ptr(), B, C, K, _DTYPES[x.dtype], _stream(x), pp,
                 )
             _native.check(rc, "dsw_cheb_basis_fwd")
         return T
@@ -160,11 +209,12 @@ class _HipBackend:
         _, K, Fout = w.shape
         y = torch.empty((B, V, Fout), dtype=x.dtype, device=x.device)
         T = torch.empty((K - 1, B, V, Fin), dtype=x.dtype, device=x.device) if K > 1 else None
+        pp, _keep = _plan_ptr(op, x) if (K > 2 and _FWD_FUSED) else (None, None)
         with torch.cuda.device(x.device):
             rc = lib.dsw_cheb_fwd(
                 op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz,
                 x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(T), B, Fin, Fout, K,
-                _DTYPES[x.dtype], _stream(x),
+                _DTYPES[x.dtype], _stream(x), pp,
             )
         _native.check(rc, "dsw_cheb_fwd")
         return y, T
@@ -183,11 +233,12 @@ class _HipBackend:
             _native.check(nbytes, "dsw_cheb_bwd_workspace_bytes")
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
         opt = op.transpose() if (need_dx and K > 1) else op
+        pp, _keep = _plan_ptr(opt, x) if (need_dx and K > 2) else (None, None)
         with torch.cuda.device(x.device):
             rc = lib.dsw_cheb_bwd(
                 opt.rowptr.data_ptr(), opt.colind.data_ptr(), opt.values.data_ptr(), V, opt.nnz,
                 x.data_ptr(), _ptr(T), w.data_ptr(), dy.data_ptr(), _ptr(dx), _ptr(dw), _ptr(db),
-                ws.data_ptr(), nbytes, B, Fin, Fout, K, dt, _stream(x),
+                ws.data_ptr(), nbytes, B, Fin, Fout, K, dt, _stream(x), pp,
             )
         _native.check(rc, "dsw_cheb_bwd")
         return dx, (dw if need_dw else None), (db if need_db else None)

@@ -1,0 +1,175 @@
+"""Tile plans for the fused two-hop SpMM kernel (``csrc/dsw_spmm2.hip``).
+
+Two consecutive applications of the same sparse operator (``T_1 = L x`` then ``T_2 = 2 L T_1 - x``,
+or two steps of the adjoint recurrence) are fused into one launch so that the intermediate never
+makes a round trip through HBM.  A workgroup owns a tile of ``R`` consecutive rows of one sample
+and needs
+
+* the first-hop result on ``S1`` = tile rows + every column they reference (the 1-ring), and hence
+* the input on ``S2`` = ``S1`` + every column the rows of ``S1`` reference (the 2-ring).
+
+This module computes, once per operator (host side, numpy), for every tile: the gather list of
+``S2`` (global row ids, ``S1`` first, tile rows first of all) and the CSR of the ``S1`` rows with
+column indices rewritten as *positions in that list* (uint16).  Rows ``[0, R_t)`` of that local CSR
+are the tile rows, and all their columns lie in ``S1``, so the same local CSR drives both hops.
+
+In HEALPix nested order a 128-row tile is an 8x16 pixel patch: |S1| ~ 180, |S2| ~ 240 for the
+8-neighbour stencil.  Nothing here is specific to HEALPix: any square CSR operator works, the
+halo sizes just grow with worse locality (the builder reports them and the caller falls back to
+two single-hop launches when they do not fit LDS).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+
+class Hop2PlanStruct(ctypes.Structure):
+    """Mirror of ``dsw_hop2_plan`` in ``include/dsw_hip.h`` (device pointers + sizes)."""
+
+    _fields_ = [
+        ("n_tiles", ctypes.c_int32),
+        ("tile_rows", ctypes.c_int32),
+        ("max_n1", ctypes.c_int32),
+        ("max_n2", ctypes.c_int32),
+        ("max_nnz", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("tile_meta", ctypes.c_void_p),   # int32 [n_tiles][6]: s2_off, n1, n2, nnz_off, rp_off, 0
+        ("s2_rows", ctypes.c_void_p),     # int32, concatenated gather lists
+        ("lrowptr", ctypes.c_void_p),     # int32, concatenated, (n1 + 1) per tile, tile-relative
+        ("lcol", ctypes.c_void_p),        # uint16, concatenated
+        ("lval", ctypes.c_void_p),        # float32, concatenated
+    ]
+
+
+class Hop2Plan:
+    def __init__(self, tile_rows, tile_meta, s2_rows, lrowptr, lcol, lval, max_n1, max_n2, max_nnz, n_rows):
+        self.tile_rows = int(tile_rows)
+        self.tile_meta = tile_meta
+        self.s2_rows = s2_rows
+        self.lrowptr = lrowptr
+        self.lcol = lcol
+        self.lval = lval
+        self.max_n1, self.max_n2, self.max_nnz = int(max_n1), int(max_n2), int(max_nnz)
+        self.n_tiles = int(tile_meta.shape[0])
+        self.n_rows = int(n_rows)
+        self._struct = None
+        self._dev = None
+
+    def lds_bytes(self, row_bytes: int) -> int:
+        """LDS the kernel carves (must match hop2_lds_bytes in csrc/dsw_spmm2.hip): the input rows on
+        S2, the first-hop rows on S1, {col, val} pairs, local row pointers, the gather list."""
+        s = (self.max_n1 + 2 * self.max_n2) * row_bytes   # input rows are double-buffered
+        s += ((self.max_nnz + 1) & ~1) * 8
+        s += ((self.max_n1 + 1 + 3) & ~3) * 4
+        s += self.max_n2 * 4
+        return (s + 15) & ~15
+
+    def to(self, device):
+        """Device-resident copy (cached) + the ctypes struct handed to the C ABI."""
+        if self._dev is not None and self._dev[0] == device:
+            return self
+        arrs = {}
+        for name in ("tile_meta", "s2_rows", "lrowptr", "lcol", "lval"):
+            a = getattr(self, name)
+            t = torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a)
+            arrs[name] = t.to(device)
+        st = Hop2PlanStruct(
+            self.n_tiles, self.tile_rows, self.max_n1, self.max_n2, self.max_nnz, 0,
+            arrs["tile_meta"].data_ptr(), arrs["s2_rows"].data_ptr(), arrs["lrowptr"].data_ptr(),
+            arrs["lcol"].data_ptr(), arrs["lval"].data_ptr(),
+        )
+        self._dev = (device, arrs)   # keeps the device tensors alive
+        self._struct = st
+        return self
+
+    @property
+    def struct_ptr(self):
+        return ctypes.byref(self._struct)
+
+
+def build_hop2_plan(rowptr: np.ndarray, colind: np.ndarray, values: np.ndarray, tile_rows: int) -> Hop2Plan:
+    """Plan for a square CSR operator (int32 rowptr/colind, fp32 values) and a tile size."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    colind = np.asarray(colind, dtype=np.int64)
+    values = np.asarray(values, dtype=np.float32)
+    n = rowptr.shape[0] - 1
+    n_tiles = (n + tile_rows - 1) // tile_rows
+    meta = np.zeros((n_tiles, 6), dtype=np.int32)
+    s2_chunks, rp_chunks, col_chunks, val_chunks = [], [], [], []
+    s2_off = nnz_off = rp_off = 0
+    max_n1 = max_n2 = max_nnz = 0
+    pos = np.full(n, -1, dtype=np.int64)   # scratch: global row -> position in the current gather list
+    for t in range(n_tiles):
+        r0, r1 = t * tile_rows, min(n, (t + 1) * tile_rows)
+        tile = np.arange(r0, r1)
+        c1 = np.unique(colind[rowptr[r0]:rowptr[r1]])
+        halo1 = c1[(c1 < r0) | (c1 >= r1)]
+        s1 = np.concatenate([tile, halo1])
+        # columns referenced by the S1 rows
+        starts, ends = rowptr[s1], rowptr[s1 + 1]
+        lens = ends - starts
+        idx = np.repeat(starts - np.cumsum(np.concatenate([[0], lens[:-1]])), lens) + np.arange(lens.sum())
+        cols = colind[idx]
+        pos[s1] = np.arange(s1.size)
+        new = np.unique(cols[pos[cols] < 0])
+        s2 = np.concatenate([s1, new])
+        pos[new] = s1.size + np.arange(new.size)
+        if s2.size > 65535:
+            raise ValueError("tile neighbourhood exceeds 65535 rows; operator too dense for the fused path")
+        lcol = pos[cols].astype(np.uint16)
+        lrp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        pos[s2] = -1
+        meta[t] = (s2_off, s1.size, s2.size, nnz_off, rp_off, 0)
+        s2_chunks.append(s2.astype(np.int32))
+        rp_chunks.append(lrp)
+        col_chunks.append(lcol)
+        val_chunks.append(values[idx])
+        s2_off += s2.size
+        rp_off += s1.size + 1
+        nnz_off += int(lens.sum())
+        max_n1, max_n2, max_nnz = max(max_n1, s1.size), max(max_n2, s2.size), max(max_nnz, int(lens.sum()))
+    return Hop2Plan(
+        tile_rows, meta, np.concatenate(s2_chunks), np.concatenate(rp_chunks), np.concatenate(col_chunks),
+        np.concatenate(val_chunks), max_n1, max_n2, max_nnz, n,
+    )
+
+
+def emulate_hop2(plan: Hop2Plan, U, Z1, Z1b, Z2, a1, b1, d1, a2, b2, c2):
+    """numpy restatement of what one fused launch computes (used by the CPU tests of the plan):
+
+        Y1 = a1 * L U + b1 * Z1 + d1 * Z1b      (on S1 of every tile; returned on tile rows)
+        Y2 = a2 * L Y1 + b2 * U + c2 * Z2       (on tile rows)
+
+    ``U``/``Z*``: ``[V, C]`` float64 arrays or None.  Returns ``(Y1, Y2)`` as ``[V, C]``.
+    """
+    V, C = U.shape
+    y1 = np.zeros((V, C))
+    y2 = np.zeros((V, C))
+    for t in range(plan.n_tiles):
+        s2_off, n1, n2, nnz_off, rp_off, _ = (int(v) for v in plan.tile_meta[t])
+        rows = plan.s2_rows[s2_off:s2_off + n2].astype(np.int64)
+        lrp = plan.lrowptr[rp_off:rp_off + n1 + 1].astype(np.int64)
+        lcol = plan.lcol[nnz_off:nnz_off + lrp[-1]].astype(np.int64)
+        lval = plan.lval[nnz_off:nnz_off + lrp[-1]].astype(np.float64)
+        bufx = U[rows]
+        buft = np.zeros((n1, C))
+        for i in range(n1):
+            sl = slice(lrp[i], lrp[i + 1])
+            buft[i] = a1 * (lval[sl, None] * bufx[lcol[sl]]).sum(0)
+        if Z1 is not None:
+            buft += b1 * Z1[rows[:n1]]
+        if Z1b is not None:
+            buft += d1 * Z1b[rows[:n1]]
+        r0 = t * plan.tile_rows
+        rt = min(plan.tile_rows, V - r0)
+        for i in range(rt):
+            sl = slice(lrp[i], lrp[i + 1])
+            acc = a2 * (lval[sl, None] * buft[lcol[sl]]).sum(0) + b2 * bufx[i]
+            if Z2 is not None:
+                acc = acc + c2 * Z2[r0 + i]
+            y2[r0 + i] = acc
+        y1[r0:r0 + rt] = buft[:rt]
+    return y1, y2

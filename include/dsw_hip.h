@@ -42,6 +42,19 @@ extern "C" {
 
 typedef void* dsw_stream_t; /* hipStream_t */
 
+/* Tile plan of the fused two-hop SpMM (built once per operator on the host, see
+ * deepsphere-weather_amd/dsw_amd/hop2.py): for every tile of `tile_rows` consecutive rows, the list
+ * of rows it gathers (tile rows, then its 1-ring, then its 2-ring) and the CSR of tile + 1-ring rows
+ * with columns rewritten as positions in that list.  All pointers are device pointers. */
+typedef struct dsw_hop2_plan {
+    int32_t n_tiles, tile_rows, max_n1, max_n2, max_nnz, reserved;
+    const int32_t* tile_meta;  /* [n_tiles][6]: s2_off, n1, n2, nnz_off, rp_off, 0 */
+    const int32_t* s2_rows;    /* concatenated gather lists (global row ids) */
+    const int32_t* lrowptr;    /* concatenated local row pointers, n1 + 1 per tile, tile-relative */
+    const uint16_t* lcol;      /* concatenated local column positions */
+    const float* lval;         /* concatenated values */
+} dsw_hop2_plan;
+
 /* Library version (major*10000 + minor*100 + patch). */
 int dsw_version(void);
 
@@ -60,20 +73,38 @@ int dsw_spmm_csr(const int32_t* rowptr, const int32_t* colind, const float* vals
                  float alpha, const void* Z, float beta, const void* Z2, float gamma,
                  int dtype, dsw_stream_t stream);
 
+/* Two applications of one square operator A (V x V) in a single launch, per sample:
+ *     Y1 = a1 * (A U)  + b1 * Z1 + d1 * Z1b
+ *     Y2 = a2 * (A Y1) + b2 * U  + c2 * Z2
+ * U, Z*, Y*: [B, V, C]; Z1 / Z1b / Z2 / Y1 may be NULL (Y1 then stays on chip).  Y2 may alias Z2;
+ * Y1 must not alias Z1 / Z1b / U.  Returns DSW_ERR_BAD_ARG if dsw_spmm2_supported() is 0. */
+int dsw_spmm2_fused(const dsw_hop2_plan* plan, int64_t V, const void* U, const void* Z1,
+                    const void* Z1b, const void* Z2, void* Y1, void* Y2, int64_t B, int64_t C,
+                    float a1, float b1, float d1, float a2, float b2, float c2,
+                    int dtype, dsw_stream_t stream);
+
+/* 1 if the fused two-hop kernel can take this plan and row size (LDS capacity, 16-byte lanes). */
+int dsw_spmm2_supported(const dsw_hop2_plan* plan, int64_t C, int dtype);
+
 /* Chebyshev basis T_1 .. T_{K-1} of X (T_0 = X is not copied):
  *     T_1 = L X,  T_k = 2 L T_{k-1} - T_{k-2}        (layers.py:163-169)
- * T: [K-1, B, V, C].  K <= 1 is a no-op. */
+ * T: [K-1, B, V, C].  K <= 1 is a no-op.  With a (supported) plan of L, hops run pairwise fused. */
 int dsw_cheb_basis_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals,
                        int64_t V, int64_t nnz, const void* X, void* T,
-                       int64_t B, int64_t C, int64_t K, int dtype, dsw_stream_t stream);
+                       int64_t B, int64_t C, int64_t K, int dtype, dsw_stream_t stream,
+                       const dsw_hop2_plan* plan);
 
 /* Adjoint of the Chebyshev recurrence (what autograd derives for layers.py:163-169), in place on
  * the K gradient planes G_0 (= the dX buffer, [B,V,C]) and G_1..G_{K-1} (Grest, [K-1,B,V,C]):
  *     for j = K-1 .. 1:   G_{j-1} += (j > 1 ? 2 : 1) * L^T G_j - G_{j+1}        (G_K := 0)
- * after which G_0 holds dX.  rowptr_t/colind_t/vals_t: CSR of L^T. */
+ * after which G_0 holds dX.  rowptr_t/colind_t/vals_t: CSR of L^T.
+ * With a (supported) plan of L^T the steps run pairwise fused; `spare` ([2,B,V,C], required when a
+ * plan is given and K >= 4, else may be NULL) receives the intermediates that cannot be updated in
+ * place. */
 int dsw_cheb_basis_adj(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t,
                        int64_t V, int64_t nnz, void* G0, void* Grest,
-                       int64_t B, int64_t C, int64_t K, int dtype, dsw_stream_t stream);
+                       int64_t B, int64_t C, int64_t K, int dtype, dsw_stream_t stream,
+                       const dsw_hop2_plan* plan_t, void* spare);
 
 /* Channel mix on the matrix cores:  Y[n,o] = bias[o] + sum_{k,f} T_k[n,f] * W[f,k,o]
  * (layers.py:171-178 and the bias add at :375).  X = T_0 [N,Fin]; T = T_1.. [K-1,N,Fin];
@@ -87,7 +118,7 @@ int dsw_cheb_mix_fwd(const void* X, const void* T, const void* W, const void* bi
 int dsw_cheb_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals,
                  int64_t V, int64_t nnz, const void* X, const void* W, const void* bias,
                  void* Y, void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K,
-                 int dtype, dsw_stream_t stream);
+                 int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan);
 
 /* Scratch bytes dsw_cheb_bwd needs for this problem size. */
 int64_t dsw_cheb_bwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t Fout, int64_t K,
@@ -97,12 +128,13 @@ int64_t dsw_cheb_bwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t 
  *     dW[f,k,o] = sum_n T_k[n,f] dY[n,o];  db[o] = sum_n dY[n,o];
  *     G_k = dY W[:,k,:]^T;  for j=K-1..1: G_{j-1} += (j>1 ? 2 : 1) L^T G_j - G_{j+1};  dX = G_0
  * rowptr_t/colind_t/vals_t describe the CSR of L^T (for a symmetric L pass L itself).
- * dX / dW / db may be NULL to skip them (db is only produced together with dW). */
+ * dX / dW / db may be NULL to skip them (db is only produced together with dW).
+ * plan_t: optional two-hop plan of L^T (NULL = one launch per adjoint step). */
 int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t,
                  int64_t V, int64_t nnz, const void* X, const void* T, const void* W,
                  const void* dY, void* dX, void* dW, void* db, void* workspace,
                  int64_t workspace_bytes, int64_t B, int64_t Fin, int64_t Fout, int64_t K,
-                 int dtype, dsw_stream_t stream);
+                 int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan_t);
 
 #ifdef __cplusplus
 }

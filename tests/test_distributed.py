@@ -1,0 +1,85 @@
+"""N>1 path on CPU: 2 ranks over gloo, batch shards, one flat-bucket gradient all-reduce.
+
+The kernels cannot run here, so the oracle backend stands in for them (test-only hook); what is
+being tested is the host logic: sharding, flat bucket, averaging, and that ranks end up with
+identical, correct gradients.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO, load_golden
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    for p in (os.path.join(REPO, "deepsphere-weather_amd"), REPO, os.path.join(REPO, "tests"), os.path.join(REPO, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from dsw_amd import functional
+    from dsw_amd.parallel import FlatGradAllReduce, init_from_env, shard_batch
+    from _oracle_backend import OracleBackend
+    from modules.layers import ConvCheb
+    from oracle import cheb_oracle as orc
+
+    functional.set_test_backend(OracleBackend())
+    r, w, _ = init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    g = load_golden("G2_conv_K_sweep")
+    p = "sym_K3_"
+    B, V, Fin, Fout, K = [int(v) for v in g[p + "meta"][:5]]
+    lap = orc.coo_from_csr_arrays(g[p + "rowptr"], g[p + "colind"], g[p + "values"], (V, V))
+    layer = ConvCheb(Fin, Fout, K, laplacian=lap)
+    layer.set_parameters(torch.from_numpy(g[p + "w"]), torch.from_numpy(g[p + "b"]))
+    x, gy = torch.from_numpy(g[p + "x"]), torch.from_numpy(g[p + "gy"])
+    lo, hi = shard_batch(B, rank, world)       # B = 3 over 2 ranks: ragged shards (2, 1)
+    sync = FlatGradAllReduce(layer.parameters())
+    layer(x[lo:hi]).backward(gy[lo:hi])
+    sync()
+    out[rank] = (lo, hi, layer.weight.grad.clone(), layer.bias.grad.clone())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_allreduce():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    g = load_golden("G2_conv_K_sweep")
+    p = "sym_K3_"
+    assert sorted((out[r][0], out[r][1]) for r in range(world)) == [(0, 2), (2, 3)]
+    # the all-reduce averages over ranks: sum over the full batch / world
+    ref_w, ref_b = g[p + "dw"] / world, g[p + "db"] / world
+    for r in range(world):
+        np.testing.assert_allclose(out[r][2].numpy(), ref_w, rtol=0, atol=1e-5 * np.abs(ref_w).max())
+        np.testing.assert_allclose(out[r][3].numpy(), ref_b, rtol=0, atol=1e-5 * np.abs(ref_b).max())
+    assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][3], out[1][3])
+
+
+def test_shard_batch_covers_everything():
+    from dsw_amd.parallel import shard_batch
+
+    for B in (1, 7, 16, 128):
+        for world in (1, 2, 3, 8):
+            spans = [shard_batch(B, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -4,6 +4,8 @@ Tolerances (errors normalised by max|ref|):
   fp32: <= 1e-5 vs the reference's fp32 output (golden) and <= 2e-6 vs the fp64 closed form;
   bf16 storage (fp32 operator + accumulation): <= 3e-2 vs fp64.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -314,3 +316,95 @@ def test_full_size_sample_vs_oracle(ns_layer):
     y64 = orc.cheb_forward_f64(rp, ci, va, x[11:12].cpu().numpy(), ns_layer.weight.detach().cpu().numpy(),
                                ns_layer.bias.detach().cpu().numpy())
     assert orc.max_rel_err(y[11:12], y64) <= TOL_F64
+
+
+# ---------------------------------------------------------------------------------------------
+# fused two-hop SpMM (dsw_spmm2_fused) against the plain formula, and basis/adjoint with plans
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("opname,C,B,dt", [("nest", 32, 3, torch.float32), ("ring", 8, 2, torch.float32),
+                                            ("irregular", 12, 2, torch.float32), ("nest", 64, 2, torch.bfloat16)])
+def test_spmm2_fused_vs_formula(opname, C, B, dt):
+    import ctypes
+    from dsw_amd import functional as F_, _native, sphere
+    from scipy import sparse
+
+    if opname == "irregular":
+        rp, ci, va = recipes.irregular_operator(700, seed=8, min_deg=0, max_deg=30)
+    else:
+        m = sphere.SphereHealpix(8, nest=(opname == "nest"), k=8).L
+        rp, ci, va = m.indptr, m.indices, m.data.astype(np.float32)
+    V = len(rp) - 1
+    op = F_.CsrOperator.from_sparse_coo(orc.coo_from_csr_arrays(rp, ci, va, (V, V)).to(DEV))
+    plan = op.hop2_plan(C * (2 if dt == torch.bfloat16 else 4))
+    assert plan is not None
+    lib = _native.load()
+    assert lib.dsw_spmm2_supported(ctypes.addressof(plan._struct), C, 1 if dt == torch.bfloat16 else 0) == 1
+    mk = lambda s: torch.from_numpy(recipes.rand(s, (B, V, C))).to(dt).to(DEV)
+    U, Z1, Z1b, Z2 = mk(1), mk(2), mk(3), mk(4)
+    Y1, Y2 = torch.empty_like(U), torch.empty_like(U)
+    a1, b1, d1, a2, b2, c2 = 2.0, 1.0, -1.0, 1.5, -1.0, 0.5
+    rc = lib.dsw_spmm2_fused(ctypes.addressof(plan._struct), V, U.data_ptr(), Z1.data_ptr(), Z1b.data_ptr(),
+                             Z2.data_ptr(), Y1.data_ptr(), Y2.data_ptr(), B, C, a1, b1, d1, a2, b2, c2,
+                             1 if dt == torch.bfloat16 else 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    f = lambda t: t.float().cpu().numpy().astype(np.float64)
+    r1 = a1 * orc.remap_f64(rp, ci, va, (V, V), f(U)) + b1 * f(Z1) + d1 * f(Z1b)
+    if dt == torch.bfloat16:
+        r1_used = torch.from_numpy(r1).to(torch.bfloat16).float().numpy().astype(np.float64)  # Y1 is stored in bf16
+    else:
+        r1_used = r1
+    r2 = a2 * orc.remap_f64(rp, ci, va, (V, V), r1_used) + b2 * f(U) + c2 * f(Z2)
+    tol = TOL_BF16 if dt == torch.bfloat16 else TOL_F64
+    assert orc.max_rel_err(Y1.float(), r1) <= tol
+    assert orc.max_rel_err(Y2.float(), r2) <= tol
+    # NULL optionals + in-place Y2 == Z2
+    Z2c = Z2.clone()
+    rc = lib.dsw_spmm2_fused(ctypes.addressof(plan._struct), V, U.data_ptr(), None, None, Z2c.data_ptr(), None,
+                             Z2c.data_ptr(), B, C, 1.0, 0.0, 0.0, 2.0, -1.0, 1.0,
+                             1 if dt == torch.bfloat16 else 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    t1 = orc.remap_f64(rp, ci, va, (V, V), f(U))
+    if dt == torch.bfloat16:
+        t1 = torch.from_numpy(t1).to(torch.bfloat16).float().numpy().astype(np.float64)
+    ref = 2.0 * orc.remap_f64(rp, ci, va, (V, V), t1) - f(U) + f(Z2)
+    assert orc.max_rel_err(Z2c.float(), ref) <= tol
+
+
+@pytest.mark.parametrize("K", [3, 4, 5, 6])
+def test_fused_recurrences_equal_unfused(K):
+    """Forward basis and adjoint recurrence: pairwise-fused launches vs one launch per hop."""
+    from dsw_amd import functional as F_, _native, sphere
+
+    assert os.environ.get("DSW_HOP2_FWD") == "1", "conftest sets DSW_HOP2_FWD=1 so the fused forward path is tested"
+    m = sphere.SphereHealpix(8, nest=True, k=8).L
+    rp, ci, va = m.indptr, m.indices, (m.data * 0.7).astype(np.float32)
+    # non-symmetric on purpose: scale rows
+    va = (va * np.repeat(0.5 + np.random.default_rng(1).random(768), np.diff(rp))).astype(np.float32)
+    op = F_.CsrOperator.from_sparse_coo(orc.coo_from_csr_arrays(rp, ci, va, (768, 768)).to(DEV))
+    opt = op.transpose()
+    B, V, C = 3, 768, 32
+    lib = _native.load()
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.from_numpy(recipes.rand(5, (B, V, C))).to(DEV)
+    res = {}
+    for fused in (False, True):
+        pp = F_._plan_ptr(op, x)[0] if fused else None
+        ppt = F_._plan_ptr(opt, x)[0] if fused else None
+        assert (pp is not None) == fused
+        T = torch.empty(K - 1, B, V, C, device=DEV)
+        assert lib.dsw_cheb_basis_fwd(op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz,
+                                      x.data_ptr(), T.data_ptr(), B, C, K, 0, st, pp) == 0
+        G0 = torch.from_numpy(recipes.rand(6, (B, V, C))).to(DEV)
+        Gr = torch.from_numpy(recipes.rand(7, (K - 1, B, V, C))).to(DEV)
+        spare = torch.empty(2, B, V, C, device=DEV)
+        assert lib.dsw_cheb_basis_adj(opt.rowptr.data_ptr(), opt.colind.data_ptr(), opt.values.data_ptr(), V, opt.nnz,
+                                      G0.data_ptr(), Gr.data_ptr(), B, C, K, 0, st, ppt, spare.data_ptr()) == 0
+        torch.cuda.synchronize()
+        res[fused] = (T.clone(), G0.clone())
+    assert orc.max_rel_err(res[True][0], res[False][0].double()) <= TOL_F64
+    assert orc.max_rel_err(res[True][1], res[False][1].double()) <= TOL_F64
+    # and the unfused forward basis against the fp64 oracle
+    L = orc._csr64(rp, ci, va, (V, V))
+    Tref = np.stack(orc.cheb_basis_f64(L, x.cpu().numpy(), K)[1:])
+    assert orc.max_rel_err(res[True][0], Tref) <= TOL_F64

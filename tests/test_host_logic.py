@@ -260,3 +260,30 @@ def test_config_driven_construction():
     assert len([k for k in model.state_dict() if k.endswith("laplacian")]) == 11
     assert len([k for k in model.state_dict() if k.endswith("remap_matrix")]) == 4
     assert model.pool1.remap_matrix.shape == (48, 192)
+
+
+def test_hop2_plan_matches_two_plain_hops():
+    """The tile plan of the fused two-hop kernel, emulated in numpy, equals two plain operator
+    applications (HEALPix nested / ring order and an irregular non-symmetric operator)."""
+    from dsw_amd import hop2, sphere
+
+    cases = {
+        "nest_k8": sphere.SphereHealpix(4, nest=True, k=8).L,
+        "ring_k20": sphere.SphereHealpix(4, nest=False, k=20).L,
+    }
+    ops = {k: (m.indptr, m.indices, m.data.astype(np.float32)) for k, m in cases.items()}
+    ops["irregular"] = recipes.irregular_operator(300, seed=4, min_deg=0, max_deg=40)
+    rng = np.random.default_rng(0)
+    for name, (rp, ci, va) in ops.items():
+        n = len(rp) - 1
+        L = sparse.csr_matrix((np.asarray(va, dtype=np.float64), ci, rp), shape=(n, n))
+        for rows in (64, 100):
+            plan = hop2.build_hop2_plan(rp, ci, va, rows)
+            assert plan.n_tiles == -(-n // rows) and plan.lds_bytes(128) > 0
+            assert (plan.tile_meta[:, 1] <= plan.max_n1).all() and (plan.tile_meta[:, 2] <= plan.max_n2).all()
+            U, Z1, Z1b, Z2 = (rng.standard_normal((n, 3)) for _ in range(4))
+            y1, y2 = hop2.emulate_hop2(plan, U, Z1, Z1b, Z2, 2.0, 1.0, -1.0, 1.5, -1.0, 0.5)
+            r1 = 2.0 * (L @ U) + Z1 - Z1b
+            r2 = 1.5 * (L @ r1) - U + 0.5 * Z2
+            np.testing.assert_allclose(y1, r1, atol=1e-12)
+            np.testing.assert_allclose(y2, r2, atol=1e-12)

@@ -5,7 +5,7 @@
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-for pass in "A FETCH_SIZE" "B WRITE_SIZE" "C SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "D TCC_HIT_sum TCC_MISS_sum"; do
+for pass in "A FETCH_SIZE" "B WRITE_SIZE" "C SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "D TCC_HIT_sum TCC_MISS_sum" "E SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_WAIT_INST_LDS"; do
   set -- $pass; p=$1; shift
   out=$root/gpurun_out/pmc_${tag}_$p
   mkdir -p $out
@@ -20,10 +20,14 @@ root = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{root}/gpurun_out/pmc_{tag}_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"].split("(")[0][-60:]
+        import re
+        m = re.search(r"(ts_gemm_x3_kernel<[^>]*>|ts_gemm_kernel<[^>]*>|cheb_wgrad_kernel<[^>]*>|spmm_csr_rowsplit<[^>]*>|spmm2_fused_kernel<[^>]*>|cheb_wgrad_reduce)", r["Kernel_Name"])
+        if not m:
+            continue
+        name = m.group(1)
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in sorted(agg.items()):
-    if not any(s in k for s in ("spmm", "gemm", "wgrad", "cheb")):
-        continue
-    print(k, {c: (round(sum(v) / len(v), 1), len(v)) for c, v in d.items()})
+    print(k)
+    for c, v in sorted(d.items()):
+        print("    %-28s n=%3d avg=%.4g min=%.4g max=%.4g" % (c, len(v), sum(v) / len(v), min(v), max(v)))
 PY
