@@ -72,11 +72,9 @@ int dsw_cheb_basis_fwd(const int32_t* rowptr, const int32_t* colind, const float
     char* t = static_cast<char*>(T);
     hipStream_t s = (hipStream_t)stream;
     auto Tk = [&](int64_t k) -> const void* { return k == 0 ? X : static_cast<const void*>(t + (k - 1) * plane); };
-    // Measured on MI355X (nside=64, 32 ch, fp32): one fused launch costs ~130 us whatever it replaces; the two
-    // forward hops it would replace move 5 E and take ~112 us, the two adjoint hops move 7 E and take ~225 us.
-    // So the forward recurrence keeps one launch per hop unless DSW_HOP2_FWD=1; the adjoint runs fused.
+    // hop pairs run fused whenever a supported plan is given (DSW_HOP2_FWD=0 forces one launch per hop)
     static const char* fwd_env = getenv("DSW_HOP2_FWD");
-    const bool fused = plan != nullptr && fwd_env != nullptr && fwd_env[0] == '1' && dsw_spmm2_supported(plan, C, dtype);
+    const bool fused = plan != nullptr && !(fwd_env != nullptr && fwd_env[0] == '0') && dsw_spmm2_supported(plan, C, dtype);
     int rc = DSW_OK;
     int64_t k = 1;   // next basis index to produce
     while (k < K && rc == DSW_OK) {

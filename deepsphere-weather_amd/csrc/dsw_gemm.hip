@@ -18,7 +18,7 @@
 using namespace dsw_gemm;
 
 // x3-split fp32 GEMM on the bf16 matrix pipe (dsw_gemm_x3.hip); returns 1 if it took the launch
-int dsw_ts_gemm_x3_try_launch(const TsGemmParams& P, int nt, int col_tiles, hipStream_t stream, int* rc);
+int dsw_ts_gemm_x3_try_launch(const TsGemmParams& P, int nt, int col_tiles, int bf16, hipStream_t stream, int* rc);
 
 namespace {
 
@@ -467,9 +467,9 @@ static int launch_ts_gemm_nt(const TsGemmParams& P, int col_tiles, hipStream_t s
     const size_t b_res = (size_t)P.n_planes_a * chunks * BK * BNT * 4;
     const bool resident = b_res <= 44 * 1024;   // A tile (18 KiB) + B panel stay under the 64 KiB default LDS limit
     const bool aligned = P.a_vec && (P.kd_per_plane % BK == 0);
-    if constexpr (!BF16) {
+    {
         int rc = DSW_OK;
-        if (aligned && dsw_ts_gemm_x3_try_launch(P, NT, col_tiles, stream, &rc)) return rc;
+        if (aligned && dsw_ts_gemm_x3_try_launch(P, NT, col_tiles, BF16 ? 1 : 0, stream, &rc)) return rc;
     }
     if (resident) {
         const size_t lds = a_bytes + b_res;
@@ -496,6 +496,21 @@ static int launch_ts_gemm_nt(const TsGemmParams& P, int col_tiles, hipStream_t s
 template <bool BF16>
 static int launch_ts_gemm(const TsGemmParams& P, hipStream_t stream) {
     const int n_total = P.n_planes_c * P.n_per_plane;
+    // bf16-pipe path with narrower column tiles when the (split) W panel of the natural tile does not fit LDS:
+    // re-reading A once per extra column tile is cheaper than running on the 16x slower fp32 MFMA
+    if (P.a_vec && (P.kd_per_plane % BK == 0) && n_total > 32) {
+        const int nat = n_total <= 128 ? (n_total + 31) / 32 : 4;
+        for (int nt = nat - 1; nt >= 1; --nt) {
+            int rc = DSW_OK;
+            // only when the natural width fails: probe it first through the normal path below
+            const int chunks = P.kd_per_plane / BK;
+            const size_t ks = (size_t)P.n_planes_a * chunks * BK + 8;
+            const size_t lds_nat = (size_t)BM * LDA * 4 + (size_t)(BF16 ? 1 : 3) * (size_t)(32 * nat) * ks * 2;
+            if (lds_nat <= 160 * 1024) break;
+            const int tiles = (n_total + 32 * nt - 1) / (32 * nt);
+            if (dsw_ts_gemm_x3_try_launch(P, nt, tiles, BF16 ? 1 : 0, stream, &rc)) return rc;
+        }
+    }
     if (n_total <= 32) return launch_ts_gemm_nt<BF16, 1>(P, 1, stream);
     if (n_total <= 64) return launch_ts_gemm_nt<BF16, 2>(P, 1, stream);
     if (n_total <= 96) return launch_ts_gemm_nt<BF16, 3>(P, 1, stream);

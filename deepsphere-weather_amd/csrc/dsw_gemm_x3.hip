@@ -31,13 +31,15 @@ static __device__ __forceinline__ float trunc_bf16(float f) {
     return __uint_as_float(__float_as_uint(f) & 0xffff0000u);
 }
 
-template <int NT>
+// NSPLIT = 3: fp32 storage, exact 3-way split (6 MFMA terms).  NSPLIT = 1: bf16 storage - the operands
+// ARE bf16, one MFMA term is exact (fp32 accumulate), i.e. the plain bf16 tensor-core GEMM of the path.
+template <int NT, int NSPLIT, bool BF16IO>
 __global__ __launch_bounds__(256) void ts_gemm_x3_kernel(const TsGemmParams P) {
     constexpr int BNT = 32 * NT;
     constexpr int PF = 3;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                                                  // [BM][LDA] fp32 staging
-    unsigned short* Bt = reinterpret_cast<unsigned short*>(smem + BM * LDA);  // [3][BNT][KS] bf16
+    unsigned short* Bt = reinterpret_cast<unsigned short*>(smem + BM * LDA);  // [NSPLIT][BNT][KS] bf16
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -57,12 +59,14 @@ __global__ __launch_bounds__(256) void ts_gemm_x3_kernel(const TsGemmParams P) {
         float v = 0.f;
         if (j < n_total) {
             const int q = j / P.n_per_plane, n = j - q * P.n_per_plane;
-            v = static_cast<const float*>(P.Bsrc)[(long)pa * P.b_sp + (long)q * P.b_sq + (long)kd * P.b_skd + (long)n * P.b_sn];
+            v = ld1<BF16IO>(P.Bsrc, (size_t)((long)pa * P.b_sp + (long)q * P.b_sq + (long)kd * P.b_skd + (long)n * P.b_sn));
         }
         const float h = trunc_bf16(v), r1 = v - h, m = trunc_bf16(r1), l = trunc_bf16(r1 - m);
         Bt[(0 * BNT + jj) * KS + r] = (unsigned short)(__float_as_uint(h) >> 16);
-        Bt[(1 * BNT + jj) * KS + r] = (unsigned short)(__float_as_uint(m) >> 16);
-        Bt[(2 * BNT + jj) * KS + r] = (unsigned short)(__float_as_uint(l) >> 16);
+        if constexpr (NSPLIT == 3) {
+            Bt[(1 * BNT + jj) * KS + r] = (unsigned short)(__float_as_uint(m) >> 16);
+            Bt[(2 * BNT + jj) * KS + r] = (unsigned short)(__float_as_uint(l) >> 16);
+        }
     }
 
     f32x16 acc[NT];
@@ -82,8 +86,8 @@ __global__ __launch_bounds__(256) void ts_gemm_x3_kernel(const TsGemmParams P) {
         const int n = col_ok[nt] ? j - q * P.n_per_plane : 0;
         char* base = static_cast<char*>((q == 0) ? P.C0 : P.C1);
         const size_t cbase = (q == 0) ? 0 : (size_t)(q - 1) * P.c_plane_stride;
-        col_ptr[nt] = base + (cbase + (size_t)n) * 4;
-        col_bias[nt] = (P.bias != nullptr) ? static_cast<const float*>(P.bias)[n] : 0.f;
+        col_ptr[nt] = base + (cbase + (size_t)n) * (BF16IO ? 2 : 4);
+        col_bias[nt] = (P.bias != nullptr) ? ld1<BF16IO>(P.bias, n) : 0.f;
     }
 
     const int ar = wave * 32 + (lane >> 3);           // wave-local staging rows ar + 8*i
@@ -98,13 +102,23 @@ __global__ __launch_bounds__(256) void ts_gemm_x3_kernel(const TsGemmParams P) {
         const long row0 = ((long)blockIdx.x + ti * gridDim.x) * BM;
         const int p = c / chunks;
         const int k0 = (c - p * chunks) * BK;
-        const float* A = static_cast<const float*>((p == 0) ? P.A0 : P.A1);
+        const void* A = (p == 0) ? P.A0 : P.A1;
         const size_t abase = (p == 0) ? 0 : (size_t)(p - 1) * P.a_plane_stride;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             long r = row0 + ar + 8 * i;
             r = r < P.M ? r : P.M - 1;
-            dra[i] = *reinterpret_cast<const f32x4*>(A + abase + (size_t)r * P.lda + k0 + ac4);
+            const size_t off = abase + (size_t)r * P.lda + k0 + ac4;
+            if constexpr (BF16IO) {
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 t = *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(A) + off);
+                f32x4 v;
+                v[0] = __uint_as_float(t[0] << 16); v[1] = __uint_as_float(t[0] & 0xffff0000u);
+                v[2] = __uint_as_float(t[1] << 16); v[3] = __uint_as_float(t[1] & 0xffff0000u);
+                dra[i] = v;
+            } else {
+                dra[i] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(A) + off);
+            }
         }
     };
 
@@ -149,19 +163,23 @@ __global__ __launch_bounds__(256) void ts_gemm_x3_kernel(const TsGemmParams P) {
                 r1[j] = f[j] - trunc_bf16(f[j]);
                 r2[j] = r1[j] - trunc_bf16(r1[j]);
             }
-            const bf16x8_t ah = pack_bf16x8(f), am = pack_bf16x8(r1), al = pack_bf16x8(r2);
+            const bf16x8_t ah = pack_bf16x8(f);
+            bf16x8_t am = ah, al = ah;
+            if constexpr (NSPLIT == 3) { am = pack_bf16x8(r1); al = pack_bf16x8(r2); }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const unsigned short* bp = brow + (size_t)(32 * nt) * KS + 16 * s2;
                 const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(bp);
-                const bf16x8_t bm = *reinterpret_cast<const bf16x8_t*>(bp + (size_t)BNT * KS);
-                const bf16x8_t bl = *reinterpret_cast<const bf16x8_t*>(bp + (size_t)2 * BNT * KS);
                 f32x16 a_ = acc[nt];
-                a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, a_, 0, 0, 0);
-                a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, a_, 0, 0, 0);
-                a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, a_, 0, 0, 0);
-                a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, a_, 0, 0, 0);
-                a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, a_, 0, 0, 0);
+                if constexpr (NSPLIT == 3) {
+                    const bf16x8_t bm = *reinterpret_cast<const bf16x8_t*>(bp + (size_t)BNT * KS);
+                    const bf16x8_t bl = *reinterpret_cast<const bf16x8_t*>(bp + (size_t)2 * BNT * KS);
+                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, a_, 0, 0, 0);
+                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, a_, 0, 0, 0);
+                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, a_, 0, 0, 0);
+                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, a_, 0, 0, 0);
+                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, a_, 0, 0, 0);
+                }
                 a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, a_, 0, 0, 0);
                 acc[nt] = a_;
             }
@@ -179,13 +197,13 @@ __global__ __launch_bounds__(256) void ts_gemm_x3_kernel(const TsGemmParams P) {
                     if (col_ok[nt]) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i)
-                            st1<false>(C, (size_t)(rbase + (i & 3) + 8 * (i >> 2)) * P.ldc, acc[nt][i] + bias);
+                            st1<BF16IO>(C, (size_t)(rbase + (i & 3) + 8 * (i >> 2)) * P.ldc, acc[nt][i] + bias);
                     }
                 } else {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const long r = rbase + (i & 3) + 8 * (i >> 2);
-                        if (col_ok[nt] && r < P.M) st1<false>(C, (size_t)r * P.ldc, acc[nt][i] + bias);
+                        if (col_ok[nt] && r < P.M) st1<BF16IO>(C, (size_t)r * P.ldc, acc[nt][i] + bias);
                     }
                 }
 #pragma unroll
@@ -201,35 +219,43 @@ __global__ __launch_bounds__(256) void ts_gemm_x3_kernel(const TsGemmParams P) {
 }
 
 
-template <int NT>
+template <int NT, int NSPLIT, bool BF16IO>
 int launch_x3(const TsGemmParams& P, int col_tiles, size_t lds, hipStream_t stream) {
     const long row_tiles = (P.M + BM - 1) / BM;
+    const void* kfn = (const void*)ts_gemm_x3_kernel<NT, NSPLIT, BF16IO>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DSW_ERR_LAUNCH;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ts_gemm_x3_kernel<NT>, 256, lds) != hipSuccess || per_cu < 1)
-        per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     long gx = 256L * per_cu / col_tiles;
     if (gx < 1) gx = 1;
     if (gx > row_tiles) gx = row_tiles;
     dim3 grid((unsigned)gx, (unsigned)col_tiles);
-    hipLaunchKernelGGL((ts_gemm_x3_kernel<NT>), grid, dim3(256), lds, stream, P);
+    hipLaunchKernelGGL((ts_gemm_x3_kernel<NT, NSPLIT, BF16IO>), grid, dim3(256), lds, stream, P);
     return dsw_check_launch();
 }
 
 }  // namespace
 
-// Takes the launch (returns 1, *rc = status) when the aligned fp32 problem's split B panel fits LDS.
-int dsw_ts_gemm_x3_try_launch(const TsGemmParams& P, int nt, int col_tiles, hipStream_t stream, int* rc) {
+// Takes the launch (returns 1, *rc = status) when the aligned problem's (split) W panel fits LDS.
+// fp32 storage -> 3-way split; bf16 storage -> plain bf16 MFMA.
+int dsw_ts_gemm_x3_try_launch(const TsGemmParams& P, int nt, int col_tiles, int bf16, hipStream_t stream, int* rc) {
     static const char* x3env = getenv("DSW_GEMM_X3");   // "0": exact fp32 MFMA path (diagnostics / A-B)
     if (x3env && x3env[0] == '0') return 0;
     const int chunks = P.kd_per_plane / BK;
     const size_t ks = (size_t)P.n_planes_a * chunks * BK + 8;
-    const size_t lds = (size_t)BM * LDA * 4 + 3 * (size_t)(32 * nt) * ks * 2;
-    if (lds > 64 * 1024) return 0;
+    const int nsplit = bf16 ? 1 : 3;
+    const size_t lds = (size_t)BM * LDA * 4 + (size_t)nsplit * (size_t)(32 * nt) * ks * 2;
+    if (lds > 160 * 1024) return 0;
+#define DSW_X3_CASE(NT_)                                                                   \
+    case NT_:                                                                              \
+        *rc = bf16 ? launch_x3<NT_, 1, true>(P, col_tiles, lds, stream)                    \
+                   : launch_x3<NT_, 3, false>(P, col_tiles, lds, stream);                  \
+        return 1;
     switch (nt) {
-        case 1: *rc = launch_x3<1>(P, col_tiles, lds, stream); return 1;
-        case 2: *rc = launch_x3<2>(P, col_tiles, lds, stream); return 1;
-        case 3: *rc = launch_x3<3>(P, col_tiles, lds, stream); return 1;
-        case 4: *rc = launch_x3<4>(P, col_tiles, lds, stream); return 1;
+        DSW_X3_CASE(1) DSW_X3_CASE(2) DSW_X3_CASE(3) DSW_X3_CASE(4)
     }
+#undef DSW_X3_CASE
     return 0;
 }

@@ -286,13 +286,15 @@ int launch_rowsplit(const int* rowptr, const int* colind, const float* vals, con
                     int v_in, int C, int B, hipStream_t stream, int hints = 0) {
     const int cpr = C / VEC;
     const long threads = (long)v_out * cpr;
-    const long row_blocks = (threads + 255) / 256;
+    static const char* bs_env = getenv("DSW_SPMM_BLOCK");   // diagnostics: threads per block (64..1024)
+    const int bs = bs_env ? (atoi(bs_env) > 256 ? 256 : atoi(bs_env)) : 256;
+    const long row_blocks = (threads + bs - 1) / bs;
     const long bgroups = (B + NB - 1) / NB;
     static const char* sw = getenv("DSW_SPMM_XCD");  // "0" disables the XCD-aware block order (diagnostics)
     // bit0: XCD block order, bit1: nt loads of Z/Z2, bit2: nt stores of Y (env overrides the caller's hints)
     const int swz = sw ? atoi(sw) : (1 | (hints & 6));
     dim3 grid((unsigned)(row_blocks * bgroups));
-    hipLaunchKernelGGL((spmm_csr_rowsplit<BF16, VEC, NB>), grid, dim3(256), 0, stream, rowptr, colind,
+    hipLaunchKernelGGL((spmm_csr_rowsplit<BF16, VEC, NB>), grid, dim3(bs), 0, stream, rowptr, colind,
                        vals, X, Y, Z, Z2, alpha, beta, gamma, v_out, v_in, C, cpr, B, row_blocks, swz);
     return dsw_check_launch();
 }

@@ -75,53 +75,78 @@ struct Hop2Args {
     int B;
     int n_chunks;               // batch chunks per tile (grid = n_tiles * n_chunks)
     int spc;                    // samples per chunk
+    int ell_w;                  // ELL width in LDS: max row length of the plan rounded up to 4
 };
 
 
-// acc += sum_p val[p] * buf[col[p]] over the local CSR row [p, e): 4 independent {entry, row} LDS reads
-// in flight per batch (the loop is latency-bound: entry -> address -> data -> fma)
+// acc += sum_j val[j] * buf[col[j]] over one ELL row (W entries, W % 4 == 0, padded with {own row, 0}).
+// The chain entry -> address -> data -> fma is a sequence of dependent LDS round trips, so entries are
+// read two per ds_read_b128 and 8 (then 4) data rows are requested back to back: two LDS latencies per
+// batch instead of two per non-zero.
 template <bool BF16>
-static __device__ __forceinline__ void gather_row(const uint2* __restrict__ ent, int p, const int e,
+static __device__ __forceinline__ void gather_ell(const uint2* __restrict__ row_ent, const int W,
                                                   const unsigned char* __restrict__ buf, const int row_bytes,
                                                   const int cb, float (&acc)[Row16<BF16>::N]) {
     using R = Row16<BF16>;
     constexpr int N = R::N;
-    for (; p + 4 <= e; p += 4) {
-        const uint2 e0 = ent[p], e1 = ent[p + 1], e2 = ent[p + 2], e3 = ent[p + 3];
-        const uint4 d0 = *reinterpret_cast<const uint4*>(buf + (size_t)e0.x * row_bytes + cb);
-        const uint4 d1 = *reinterpret_cast<const uint4*>(buf + (size_t)e1.x * row_bytes + cb);
-        const uint4 d2 = *reinterpret_cast<const uint4*>(buf + (size_t)e2.x * row_bytes + cb);
-        const uint4 d3 = *reinterpret_cast<const uint4*>(buf + (size_t)e3.x * row_bytes + cb);
-        float x0[N], x1[N], x2[N], x3[N];
-        R::unpack(d0, x0); R::unpack(d1, x1); R::unpack(d2, x2); R::unpack(d3, x3);
-        const float v0 = __uint_as_float(e0.y), v1 = __uint_as_float(e1.y);
-        const float v2 = __uint_as_float(e2.y), v3 = __uint_as_float(e3.y);
+    const uint4* e4 = reinterpret_cast<const uint4*>(row_ent);   // {col0, val0, col1, val1}
+    int j = 0;
+    for (; j + 8 <= W; j += 8) {
+        uint4 e[4];
+        uint4 d[8];
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-            acc[j] = fmaf(v0, x0[j], acc[j]);
-            acc[j] = fmaf(v1, x1[j], acc[j]);
-            acc[j] = fmaf(v2, x2[j], acc[j]);
-            acc[j] = fmaf(v3, x3[j], acc[j]);
+        for (int t = 0; t < 4; ++t) e[t] = e4[(j >> 1) + t];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            d[2 * t] = *reinterpret_cast<const uint4*>(buf + (size_t)e[t].x * row_bytes + cb);
+            d[2 * t + 1] = *reinterpret_cast<const uint4*>(buf + (size_t)e[t].z * row_bytes + cb);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float x0[N], x1[N];
+            R::unpack(d[2 * t], x0);
+            R::unpack(d[2 * t + 1], x1);
+            const float v0 = __uint_as_float(e[t].y), v1 = __uint_as_float(e[t].w);
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                acc[c] = fmaf(v0, x0[c], acc[c]);
+                acc[c] = fmaf(v1, x1[c], acc[c]);
+            }
         }
     }
-    for (; p < e; ++p) {
-        const uint2 e0 = ent[p];
-        float x0[N];
-        R::unpack(*reinterpret_cast<const uint4*>(buf + (size_t)e0.x * row_bytes + cb), x0);
-        const float v0 = __uint_as_float(e0.y);
+    for (; j < W; j += 4) {
+        const uint4 ea = e4[j >> 1], eb = e4[(j >> 1) + 1];
+        const uint4 d0 = *reinterpret_cast<const uint4*>(buf + (size_t)ea.x * row_bytes + cb);
+        const uint4 d1 = *reinterpret_cast<const uint4*>(buf + (size_t)ea.z * row_bytes + cb);
+        const uint4 d2 = *reinterpret_cast<const uint4*>(buf + (size_t)eb.x * row_bytes + cb);
+        const uint4 d3 = *reinterpret_cast<const uint4*>(buf + (size_t)eb.z * row_bytes + cb);
+        float x0[N], x1[N], x2[N], x3[N];
+        R::unpack(d0, x0); R::unpack(d1, x1); R::unpack(d2, x2); R::unpack(d3, x3);
+        const float v0 = __uint_as_float(ea.y), v1 = __uint_as_float(ea.w);
+        const float v2 = __uint_as_float(eb.y), v3 = __uint_as_float(eb.w);
 #pragma unroll
-        for (int j = 0; j < N; ++j) acc[j] = fmaf(v0, x0[j], acc[j]);
+        for (int c = 0; c < N; ++c) {
+            acc[c] = fmaf(v0, x0[c], acc[c]);
+            acc[c] = fmaf(v1, x1[c], acc[c]);
+            acc[c] = fmaf(v2, x2[c], acc[c]);
+            acc[c] = fmaf(v3, x3[c], acc[c]);
+        }
     }
 }
 
-// Rows of U staged per thread and sample (register double buffer): ceil(max_n2 * lpr / NTHREADS) <= MAXST
+// NST = ceil(max_n2 / rows-per-pass): register-stage slots per thread.  Slot k of a lane group is list
+// position i = grp + k*rpp: its U row (every slot) and - S1 and the tile rows being prefixes of the
+// gather list - also its Z1/Z1b row (i < n1) and its Z2 row (i < rt).
 constexpr int MAXST = 8;
 
-// One workgroup = (tile, chunk of the batch): the tile's plan slice is staged once and reused for every
-// sample of the chunk; the next sample's U rows are loaded into registers while the current sample is
-// processed out of LDS (bufX is double-buffered).
-template <bool BF16>
-__global__ __launch_bounds__(NTHREADS) void spmm2_fused_kernel(const Hop2Args P) {
+// One workgroup = (tile, chunk of the batch).  The tile's plan slice is expanded to ELL in LDS once and
+// reused for every sample of the chunk.  Per sample: the epilogue operands Z* of THIS sample and then the
+// U rows of the NEXT sample are requested in one unconditional, index-clamped burst right after the
+// barrier; vmcnt completes in order, so waiting for Z* (first use: end of the first phase-1 task) leaves
+// the U burst in flight under phases 1 and 2, and it lands in the other half of the double-buffered bufX
+// at the top of the next iteration.
+template <bool BF16, int NST, bool HZA, bool HZ2, int NS1 = NST, int NS2 = NST>
+__global__ __launch_bounds__(NTHREADS, (HZA ? 2 : 4)) void spmm2_fused_kernel(const Hop2Args P) {
     using R = Row16<BF16>;
     constexpr int N = R::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -129,9 +154,8 @@ __global__ __launch_bounds__(NTHREADS) void spmm2_fused_kernel(const Hop2Args P)
     unsigned char* bufX0 = lds;                                            // [max_n2][row_bytes], sample s
     unsigned char* bufX1 = bufX0 + (size_t)P.max_n2 * P.row_bytes;         // [max_n2][row_bytes], sample s+1
     unsigned char* bufT = bufX1 + (size_t)P.max_n2 * P.row_bytes;          // [max_n1][row_bytes]
-    uint2* ent = reinterpret_cast<uint2*>(bufT + (size_t)P.max_n1 * P.row_bytes);   // [max_nnz] {col, val}
-    int* lrp = reinterpret_cast<int*>(ent + ((P.max_nnz + 1) & ~1));       // [max_n1 + 1]
-    int* rows = lrp + ((P.max_n1 + 1 + 3) & ~3);                           // [max_n2] global row ids
+    uint2* ell = reinterpret_cast<uint2*>(bufT + (size_t)P.max_n1 * P.row_bytes);   // [max_n1][W] {col, val}
+    int* rows = reinterpret_cast<int*>(ell + (size_t)P.max_n1 * P.ell_w);  // [max_n2] global row ids
 
     // XCD-aware order: each XCD (hardware block id % 8) walks one contiguous range of (tile, batch chunk)
     const long nwg = gridDim.x, orig = blockIdx.x;
@@ -146,71 +170,94 @@ __global__ __launch_bounds__(NTHREADS) void spmm2_fused_kernel(const Hop2Args P)
     const int r0 = tile * P.tile_rows;
     const int rt = min(P.tile_rows, P.V - r0);
     const int tid = threadIdx.x;
+    const int W = P.ell_w;
     const size_t sample_bytes = (size_t)P.V * P.row_bytes;
 
-    // ---- the tile's plan slice -> LDS, once for all samples of this workgroup
-    for (int i = tid; i <= n1; i += NTHREADS) lrp[i] = P.lrowptr[rp_off + i];
+    // ---- the tile's plan slice -> LDS (CSR expanded to ELL), once for all samples of this workgroup
     for (int i = tid; i < n2; i += NTHREADS) rows[i] = P.s2_rows[s2_off + i];
+    for (int t = tid; t < n1 * W; t += NTHREADS) {
+        const int i = t / W, j = t - i * W;
+        const int p0 = P.lrowptr[rp_off + i], p1 = P.lrowptr[rp_off + i + 1];
+        const int p = p0 + j;
+        ell[t] = (p < p1) ? make_uint2((unsigned)P.lcol[nnz_off + p], __float_as_uint(P.lval[nnz_off + p]))
+                          : make_uint2((unsigned)i, 0u);     // padding: own row, weight 0
+    }
     __syncthreads();
-    const int nnz = lrp[n1];
-    for (int i = tid; i < nnz; i += NTHREADS)
-        ent[i] = make_uint2((unsigned)P.lcol[nnz_off + i], __float_as_uint(P.lval[nnz_off + i]));
 
     const int lpr = P.lpr;
     const int rpp = NTHREADS / lpr;                 // rows per pass
-    const int grp = tid / lpr;                      // row slot of this lane group
-    const int cb = (tid - grp * lpr) * 16;          // byte offset of this lane inside the row
-    const bool lane_ok = grp < rpp;
+    const int grp0 = tid / lpr;
+    const bool lane_ok = grp0 < rpp;
+    const int grp = lane_ok ? grp0 : rpp - 1;       // leftover lanes shadow the last group (never store)
+    const int cb = ((tid - grp0 * lpr) * 16) % P.row_bytes;   // byte offset of this lane inside the row
 
-    // register staging of the U rows of S2 (next sample's loads fly under this sample's compute)
-    u32x4 stg[MAXST];
-    auto stage_load = [&](int b) __attribute__((always_inline)) {
-        const char* src = P.U + (size_t)b * sample_bytes + cb;
+    // per-slot byte offsets (sample-relative), clamped so that every load is legal and unconditional
+    unsigned offU[NST], offZ1[NST], offZ2[NST];   // < 2^32: one sample of one tensor
 #pragma unroll
-        for (int k = 0; k < MAXST; ++k) {
-            const int i = grp + k * rpp;
-            if (lane_ok && i < n2) stg[k] = *reinterpret_cast<const u32x4*>(src + (size_t)rows[i] * P.row_bytes);
-        }
-    };
-    auto stage_store = [&](unsigned char* dst) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < MAXST; ++k) {
-            const int i = grp + k * rpp;
-            if (lane_ok && i < n2) *reinterpret_cast<u32x4*>(dst + (size_t)i * P.row_bytes + cb) = stg[k];
-        }
-    };
+    for (int k = 0; k < NST; ++k) {
+        const int i = grp + k * rpp;
+        offU[k] = (unsigned)rows[min(i, n2 - 1)] * (unsigned)P.row_bytes + cb;
+        offZ1[k] = (unsigned)rows[min(i, n1 - 1)] * (unsigned)P.row_bytes + cb;
+        offZ2[k] = (unsigned)(r0 + min(i, rt - 1)) * (unsigned)P.row_bytes + cb;
+    }
 
-    if (b_begin < b_end) stage_load(b_begin);
+    u32x4 su[NST];
+    if (b_begin < b_end) {
+        const size_t sb = (size_t)b_begin * sample_bytes;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) su[k] = *reinterpret_cast<const u32x4*>(P.U + sb + offU[k]);
+    }
     for (int b = b_begin; b < b_end; ++b) {
         unsigned char* bufX = ((b - b_begin) & 1) ? bufX1 : bufX0;
-        stage_store(bufX);
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int i = grp + k * rpp;
+            if (lane_ok && i < n2) *reinterpret_cast<u32x4*>(bufX + (size_t)i * P.row_bytes + cb) = su[k];
+        }
         __syncthreads();   // bufX(b) complete; every wave is past phase 2 of sample b-1 (bufT reusable)
-        if (b + 1 < b_end) stage_load(b + 1);
         const size_t sample = (size_t)b * sample_bytes;
+        // burst: this sample's epilogue operands first, then the next sample's U rows
+        // NS1 / NS2: slots that can hold an S1 row / a tile row (ceil(max_n1 / rpp), ceil(tile_rows / rpp))
+        u32x4 cz1[HZA ? NS1 : 1], cz1b[HZA ? NS1 : 1], cz2[HZ2 ? NS2 : 1];
+        if constexpr (HZA) {
+#pragma unroll
+            for (int k = 0; k < NS1; ++k) cz1[k] = *reinterpret_cast<const u32x4*>(P.Z1 + sample + offZ1[k]);
+        }
+        if (HZA && P.Z1b != P.Z1) {   // uniform; Z1b aliases Z1 (weight 0) when the caller has only one
+#pragma unroll
+            for (int k = 0; k < NS1; ++k) cz1b[k] = *reinterpret_cast<const u32x4*>(P.Z1b + sample + offZ1[k]);
+        }
+        if constexpr (HZ2) {
+#pragma unroll
+            for (int k = 0; k < NS2; ++k) cz2[k] = *reinterpret_cast<const u32x4*>(P.Z2 + sample + offZ2[k]);
+        }
+        {
+            const size_t sb = (size_t)(b + 1 < b_end ? b + 1 : b) * sample_bytes;   // tail: harmless re-read
+#pragma unroll
+            for (int k = 0; k < NST; ++k) su[k] = *reinterpret_cast<const u32x4*>(P.U + sb + offU[k]);
+        }
 
         // ---- phase 1: Y1 on S1
-        if (lane_ok) {
-            for (int i = grp; i < n1; i += rpp) {
-                const size_t goff = sample + (size_t)rows[i] * P.row_bytes + cb;
-                uint4 z1 = make_uint4(0, 0, 0, 0), z1b = make_uint4(0, 0, 0, 0);
-                if (P.Z1) z1 = *reinterpret_cast<const uint4*>(P.Z1 + goff);      // issued before the gathers
-                if (P.Z1b) z1b = *reinterpret_cast<const uint4*>(P.Z1b + goff);
+#pragma unroll
+        for (int k = 0; k < NS1; ++k) {
+            const int i = grp + k * rpp;
+            if (lane_ok && i < n1) {
                 float acc[N];
 #pragma unroll
                 for (int j = 0; j < N; ++j) acc[j] = 0.f;
-                gather_row<BF16>(ent, lrp[i], lrp[i + 1], bufX, P.row_bytes, cb, acc);
+                gather_ell<BF16>(ell + (size_t)i * W, W, bufX, P.row_bytes, cb, acc);
                 float o[N];
 #pragma unroll
                 for (int j = 0; j < N; ++j) o[j] = P.a1 * acc[j];
-                if (P.Z1) {
+                if constexpr (HZA) {
                     float z[N];
-                    R::unpack(z1, z);
+                    R::unpack(__builtin_bit_cast(uint4, cz1[k]), z);
 #pragma unroll
                     for (int j = 0; j < N; ++j) o[j] = fmaf(P.b1, z[j], o[j]);
                 }
-                if (P.Z1b) {
+                if (HZA && P.Z1b != P.Z1) {
                     float z[N];
-                    R::unpack(z1b, z);
+                    R::unpack(__builtin_bit_cast(uint4, cz1b[k]), z);
 #pragma unroll
                     for (int j = 0; j < N; ++j) o[j] = fmaf(P.d1, z[j], o[j]);
                 }
@@ -223,26 +270,25 @@ __global__ __launch_bounds__(NTHREADS) void spmm2_fused_kernel(const Hop2Args P)
         __syncthreads();
 
         // ---- phase 2: Y2 on the tile rows
-        if (lane_ok) {
-            for (int i = grp; i < rt; i += rpp) {
-                const size_t goff = sample + (size_t)(r0 + i) * P.row_bytes + cb;
-                uint4 z2 = make_uint4(0, 0, 0, 0);
-                if (P.Z2) z2 = *reinterpret_cast<const uint4*>(P.Z2 + goff);
+#pragma unroll
+        for (int k = 0; k < NS2; ++k) {
+            const int i = grp + k * rpp;
+            if (lane_ok && i < rt) {
                 float acc[N];
 #pragma unroll
                 for (int j = 0; j < N; ++j) acc[j] = 0.f;
-                gather_row<BF16>(ent, lrp[i], lrp[i + 1], bufT, P.row_bytes, cb, acc);
+                gather_ell<BF16>(ell + (size_t)i * W, W, bufT, P.row_bytes, cb, acc);
                 float u[N], o[N];
                 R::unpack(*reinterpret_cast<const uint4*>(bufX + (size_t)i * P.row_bytes + cb), u);
 #pragma unroll
                 for (int j = 0; j < N; ++j) o[j] = fmaf(P.a2, acc[j], P.b2 * u[j]);
-                if (P.Z2) {
+                if constexpr (HZ2) {
                     float z[N];
-                    R::unpack(z2, z);
+                    R::unpack(__builtin_bit_cast(uint4, cz2[k]), z);
 #pragma unroll
                     for (int j = 0; j < N; ++j) o[j] = fmaf(P.c2, z[j], o[j]);
                 }
-                *reinterpret_cast<uint4*>(P.Y2 + goff) = R::pack(o);
+                *reinterpret_cast<uint4*>(P.Y2 + sample + (size_t)(r0 + i) * P.row_bytes + cb) = R::pack(o);
             }
         }
         // no barrier here: the next iteration writes the OTHER bufX, and its barrier orders bufT reuse
@@ -252,17 +298,20 @@ __global__ __launch_bounds__(NTHREADS) void spmm2_fused_kernel(const Hop2Args P)
 }  // namespace
 
 // LDS bytes the kernel needs for this plan and row size (must match the carve-up above)
+// ELL width: the longest local row is not in the plan struct; bound it by max_nnz / rows is useless, so the
+// plan carries it in `reserved` (hop2.py); 0 = unknown -> not supported.
+static int hop2_ell_w(const dsw_hop2_plan* plan) { return (plan->reserved + 3) & ~3; }
+
 static size_t hop2_lds_bytes(const dsw_hop2_plan* plan, int row_bytes) {
-    size_t s = (size_t)(plan->max_n1 + 2 * (size_t)plan->max_n2) * row_bytes;   // bufX double-buffered
-    s += (size_t)((plan->max_nnz + 1) & ~1) * 8;
-    s += (size_t)((plan->max_n1 + 1 + 3) & ~3) * 4;
+    size_t s = (size_t)(plan->max_n1 + 2 * (size_t)plan->max_n2) * row_bytes;   // bufT + double-buffered bufX
+    s += (size_t)plan->max_n1 * hop2_ell_w(plan) * 8;
     s += (size_t)plan->max_n2 * 4;
     return (s + 15) & ~(size_t)15;
 }
 
 // 1 if the fused kernel can run this plan / shape (LDS fits, rows are whole 16-byte lanes)
 int dsw_spmm2_supported(const dsw_hop2_plan* plan, int64_t C, int dtype) {
-    if (!plan || plan->n_tiles <= 0) return 0;
+    if (!plan || plan->n_tiles <= 0 || plan->reserved <= 0) return 0;
     const int es = dtype == DSW_BF16 ? 2 : 4;
     const int64_t row_bytes = C * es;
     if (row_bytes % 16 != 0 || row_bytes / 16 > NTHREADS) return 0;
@@ -270,6 +319,31 @@ int dsw_spmm2_supported(const dsw_hop2_plan* plan, int64_t C, int dtype) {
     if ((plan->max_n2 + rpp - 1) / rpp > MAXST) return 0;   // register staging capacity
     return hop2_lds_bytes(plan, (int)row_bytes) <= 160 * 1024 ? 1 : 0;
 }
+
+namespace {
+template <bool BF16, int NST, int NS1, int NS2>
+int launch_h2(const Hop2Args& A, long nwg, size_t lds, hipStream_t stream) {
+    const int sel = ((A.Z1 || A.Z1b) ? 1 : 0) | (A.Z2 ? 2 : 0);
+#define DSW_H2_SEL(S, ZA_, Z2_)                                                                                  \
+    case S: {                                                                                                    \
+        if (lds > 64 * 1024 &&                                                                                   \
+            hipFuncSetAttribute((const void*)spmm2_fused_kernel<BF16, NST, ZA_, Z2_, NS1, NS2>,                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
+            return DSW_ERR_LAUNCH;                                                                               \
+        hipLaunchKernelGGL((spmm2_fused_kernel<BF16, NST, ZA_, Z2_, NS1, NS2>), dim3((unsigned)nwg),             \
+                           dim3(NTHREADS), lds, stream, A);                                                      \
+        break;                                                                                                   \
+    }
+    switch (sel) {
+        DSW_H2_SEL(0, false, false)
+        DSW_H2_SEL(1, true, false)
+        DSW_H2_SEL(2, false, true)
+        DSW_H2_SEL(3, true, true)
+    }
+#undef DSW_H2_SEL
+    return dsw_check_launch();
+}
+}  // namespace
 
 int dsw_spmm2_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const void* Z1, const void* Z1b,
                      const void* Z2, void* Y1, void* Y2, int64_t B, int64_t C, float a1, float b1, float d1,
@@ -285,9 +359,12 @@ int dsw_spmm2_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const 
     A.Z1b = static_cast<const char*>(Z1b); A.Z2 = static_cast<const char*>(Z2);
     A.Y1 = static_cast<char*>(Y1); A.Y2 = static_cast<char*>(Y2);
     A.a1 = a1; A.b1 = Z1 ? b1 : 0.f; A.d1 = Z1b ? d1 : 0.f; A.a2 = a2; A.b2 = b2; A.c2 = Z2 ? c2 : 0.f;
+    if (!A.Z1 && A.Z1b) { A.Z1 = A.Z1b; A.b1 = A.d1; A.Z1b = nullptr; A.d1 = 0.f; }
+    if (A.Z1 && !A.Z1b) A.Z1b = A.Z1;   // the kernel skips the second operand when both alias
     A.V = (int)V; A.n_tiles = plan->n_tiles; A.tile_rows = plan->tile_rows;
     A.max_n1 = plan->max_n1; A.max_n2 = plan->max_n2; A.max_nnz = plan->max_nnz;
     A.row_bytes = (int)(C * es); A.lpr = A.row_bytes / 16; A.B = (int)B;
+    A.ell_w = hop2_ell_w(plan);
     const size_t lds = hop2_lds_bytes(plan, A.row_bytes);
     // batch chunks: enough workgroups for ~4 rounds over the resident slots, >= 2 samples per workgroup
     // so that the plan staging and the first U load are amortised and the register double buffer pays
@@ -299,16 +376,22 @@ int dsw_spmm2_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const 
     A.n_chunks = (int)((B + A.spc - 1) / A.spc);
     const long nwg = (long)plan->n_tiles * A.n_chunks;
     if (nwg > 2147483647L) return DSW_ERR_BAD_ARG;
-    if (dtype == DSW_BF16) {
-        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)spmm2_fused_kernel<true>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return DSW_ERR_LAUNCH;
-        hipLaunchKernelGGL(spmm2_fused_kernel<true>, dim3((unsigned)nwg), dim3(NTHREADS), lds, stream, A);
-    } else {
-        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)spmm2_fused_kernel<false>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return DSW_ERR_LAUNCH;
-        hipLaunchKernelGGL(spmm2_fused_kernel<false>, dim3((unsigned)nwg), dim3(NTHREADS), lds, stream, A);
+    const int rpp = NTHREADS / A.lpr;
+    const int nst = (plan->max_n2 + rpp - 1) / rpp;
+    const int ns1 = (plan->max_n1 + rpp - 1) / rpp;
+    const int ns2 = (plan->tile_rows + rpp - 1) / rpp;
+    // the common shape (64-row tiles, 8 lanes per row: 146 / 100 / 64 rows in 64-row passes) gets exact slot
+    // counts - 16 fewer live registers in the adjoint variants; everything else sizes all three by NST
+    if (nst == 3 && ns1 <= 2 && ns2 <= 1)
+        return dtype == DSW_BF16 ? launch_h2<true, 3, 2, 1>(A, nwg, lds, stream) : launch_h2<false, 3, 2, 1>(A, nwg, lds, stream);
+#define DSW_H2_NST(N_)                                                                                     \
+    case N_:                                                                                               \
+        return dtype == DSW_BF16 ? launch_h2<true, N_, N_, N_>(A, nwg, lds, stream)                        \
+                                 : launch_h2<false, N_, N_, N_>(A, nwg, lds, stream);
+    switch (nst) {
+        DSW_H2_NST(1) DSW_H2_NST(2) DSW_H2_NST(3) DSW_H2_NST(4)
+        DSW_H2_NST(5) DSW_H2_NST(6) DSW_H2_NST(7) DSW_H2_NST(8)
     }
-    return dsw_check_launch();
+#undef DSW_H2_NST
+    return DSW_ERR_BAD_ARG;
 }

@@ -167,7 +167,7 @@ def _plan_ptr(op, x):
 
 
 _plan_ptr.disabled = False
-_FWD_FUSED = __import__("os").environ.get("DSW_HOP2_FWD") == "1"   # forward hops: fused only on request (see dsw_api.hip)
+_FWD_FUSED = __import__("os").environ.get("DSW_HOP2_FWD") != "0"   # forward hop pairs fused unless disabled
 
 
 class _HipBackend:

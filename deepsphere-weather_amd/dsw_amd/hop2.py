@@ -35,7 +35,7 @@ class Hop2PlanStruct(ctypes.Structure):
         ("max_n1", ctypes.c_int32),
         ("max_n2", ctypes.c_int32),
         ("max_nnz", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),      # longest local CSR row (ELL width before rounding to 4)
         ("tile_meta", ctypes.c_void_p),   # int32 [n_tiles][6]: s2_off, n1, n2, nnz_off, rp_off, 0
         ("s2_rows", ctypes.c_void_p),     # int32, concatenated gather lists
         ("lrowptr", ctypes.c_void_p),     # int32, concatenated, (n1 + 1) per tile, tile-relative
@@ -45,7 +45,9 @@ class Hop2PlanStruct(ctypes.Structure):
 
 
 class Hop2Plan:
-    def __init__(self, tile_rows, tile_meta, s2_rows, lrowptr, lcol, lval, max_n1, max_n2, max_nnz, n_rows):
+    def __init__(self, tile_rows, tile_meta, s2_rows, lrowptr, lcol, lval, max_n1, max_n2, max_nnz, n_rows,
+                 max_row_len=0):
+        self.max_row_len = int(max_row_len)
         self.tile_rows = int(tile_rows)
         self.tile_meta = tile_meta
         self.s2_rows = s2_rows
@@ -61,10 +63,10 @@ class Hop2Plan:
     def lds_bytes(self, row_bytes: int) -> int:
         """LDS the kernel carves (must match hop2_lds_bytes in csrc/dsw_spmm2.hip): the input rows on
         S2, the first-hop rows on S1, {col, val} pairs, local row pointers, the gather list."""
-        s = (self.max_n1 + 2 * self.max_n2) * row_bytes   # input rows are double-buffered
-        s += ((self.max_nnz + 1) & ~1) * 8
-        s += ((self.max_n1 + 1 + 3) & ~3) * 4
-        s += self.max_n2 * 4
+        ell_w = (self.max_row_len + 3) & ~3
+        s = (self.max_n1 + 2 * self.max_n2) * row_bytes   # bufT + double-buffered input rows
+        s += self.max_n1 * ell_w * 8                      # ELL {col, val}
+        s += self.max_n2 * 4                              # gather list
         return (s + 15) & ~15
 
     def to(self, device):
@@ -77,7 +79,7 @@ class Hop2Plan:
             t = torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a)
             arrs[name] = t.to(device)
         st = Hop2PlanStruct(
-            self.n_tiles, self.tile_rows, self.max_n1, self.max_n2, self.max_nnz, 0,
+            self.n_tiles, self.tile_rows, self.max_n1, self.max_n2, self.max_nnz, self.max_row_len,
             arrs["tile_meta"].data_ptr(), arrs["s2_rows"].data_ptr(), arrs["lrowptr"].data_ptr(),
             arrs["lcol"].data_ptr(), arrs["lval"].data_ptr(),
         )
@@ -100,7 +102,7 @@ def build_hop2_plan(rowptr: np.ndarray, colind: np.ndarray, values: np.ndarray, 
     meta = np.zeros((n_tiles, 6), dtype=np.int32)
     s2_chunks, rp_chunks, col_chunks, val_chunks = [], [], [], []
     s2_off = nnz_off = rp_off = 0
-    max_n1 = max_n2 = max_nnz = 0
+    max_n1 = max_n2 = max_nnz = max_len = 0
     pos = np.full(n, -1, dtype=np.int64)   # scratch: global row -> position in the current gather list
     for t in range(n_tiles):
         r0, r1 = t * tile_rows, min(n, (t + 1) * tile_rows)
@@ -131,9 +133,10 @@ def build_hop2_plan(rowptr: np.ndarray, colind: np.ndarray, values: np.ndarray, 
         rp_off += s1.size + 1
         nnz_off += int(lens.sum())
         max_n1, max_n2, max_nnz = max(max_n1, s1.size), max(max_n2, s2.size), max(max_nnz, int(lens.sum()))
+        max_len = max(max_len, int(lens.max()) if lens.size else 0)
     return Hop2Plan(
         tile_rows, meta, np.concatenate(s2_chunks), np.concatenate(rp_chunks), np.concatenate(col_chunks),
-        np.concatenate(val_chunks), max_n1, max_n2, max_nnz, n,
+        np.concatenate(val_chunks), max_n1, max_n2, max_nnz, n, max_len,
     )
 
 

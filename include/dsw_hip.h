@@ -47,7 +47,8 @@ typedef void* dsw_stream_t; /* hipStream_t */
  * of rows it gathers (tile rows, then its 1-ring, then its 2-ring) and the CSR of tile + 1-ring rows
  * with columns rewritten as positions in that list.  All pointers are device pointers. */
 typedef struct dsw_hop2_plan {
-    int32_t n_tiles, tile_rows, max_n1, max_n2, max_nnz, reserved;
+    int32_t n_tiles, tile_rows, max_n1, max_n2, max_nnz;
+    int32_t reserved;          /* longest local CSR row (the kernel's ELL width before rounding up to 4) */
     const int32_t* tile_meta;  /* [n_tiles][6]: s2_off, n1, n2, nnz_off, rp_off, 0 */
     const int32_t* s2_rows;    /* concatenated gather lists (global row ids) */
     const int32_t* lrowptr;    /* concatenated local row pointers, n1 + 1 per tile, tile-relative */

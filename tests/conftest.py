@@ -10,8 +10,7 @@ for p in (PKG, REPO, os.path.join(REPO, "tests", "golden"), os.path.join(REPO, "
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
-# the forward recurrence only uses the fused two-hop kernel on request; the tests cover both paths
-os.environ.setdefault("DSW_HOP2_FWD", "1")
+
 
 
 def pytest_configure(config):

@@ -329,7 +329,7 @@ def test_spmm2_fused_vs_formula(opname, C, B, dt):
     from scipy import sparse
 
     if opname == "irregular":
-        rp, ci, va = recipes.irregular_operator(700, seed=8, min_deg=0, max_deg=30)
+        rp, ci, va = recipes.irregular_operator(300, seed=8, min_deg=0, max_deg=30)  # no locality: S1 = S2 = everything
     else:
         m = sphere.SphereHealpix(8, nest=(opname == "nest"), k=8).L
         rp, ci, va = m.indptr, m.indices, m.data.astype(np.float32)
@@ -376,7 +376,6 @@ def test_fused_recurrences_equal_unfused(K):
     """Forward basis and adjoint recurrence: pairwise-fused launches vs one launch per hop."""
     from dsw_amd import functional as F_, _native, sphere
 
-    assert os.environ.get("DSW_HOP2_FWD") == "1", "conftest sets DSW_HOP2_FWD=1 so the fused forward path is tested"
     m = sphere.SphereHealpix(8, nest=True, k=8).L
     rp, ci, va = m.indptr, m.indices, (m.data * 0.7).astype(np.float32)
     # non-symmetric on purpose: scale rows
