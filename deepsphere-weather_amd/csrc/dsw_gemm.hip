@@ -20,6 +20,10 @@ using namespace dsw_gemm;
 // x3-split fp32 GEMM on the bf16 matrix pipe (dsw_gemm_x3.hip); returns 1 if it took the launch
 int dsw_ts_gemm_x3_try_launch(const TsGemmParams& P, int nt, int col_tiles, int bf16, hipStream_t stream, int* rc);
 
+// wgrad on the bf16 matrix pipe (dsw_wgrad_x3.hip); returns 1 if it took the launch
+int dsw_wgrad_x3_try_launch(WgradParams& P, int nw, int groups, int otiles, int bf16, int64_t max_slabs, int64_t* S_out,
+                            hipStream_t stream, int* rc);
+
 namespace {
 
 // C (M x n_total) = sum_p A[p] (M x kd) * B[p] (kd x n_total) (+ bias),  n_total = n_planes_c * n_per_plane.
@@ -248,21 +252,6 @@ __global__ __launch_bounds__(256) void ts_gemm_kernel(const TsGemmParams P) {
 // ---------------------------------------------------------------------------------------------
 // wgrad: partial[s][(k*Fin + f)][o] = sum_{n in slab s} T_k[n, f] * dY[n, o]; row Kd = column sums
 // ---------------------------------------------------------------------------------------------
-constexpr int WR = 32;  // node rows per staged chunk
-
-struct WgradParams {
-    const void* X;          // T_0
-    const void* T;          // T_1.. planes
-    size_t plane_stride;    // elements
-    const void* dY;
-    float* partial;         // [S][Kd + 1][Fout]
-    long N;
-    int Fin, Fout, K;
-    long rows_per_slab;
-    int tiles_per_plane;    // ceil(Fin / 32)
-    int t_vec, dy_vec;
-};
-
 // NW waves per workgroup = number of 32-row (k, f) tiles it covers (1..4): no idle waves when
 // K * ceil(Fin/32) is not a multiple of 4 (north-star: 3 tiles -> 3-wave workgroups).
 // ALIGNED: Fin % 32 == 0, Fout-tile full and 16-byte aligned rows (no column bounds checks).
@@ -607,6 +596,16 @@ int dsw_wgrad_launch(const void* X, const void* T, const void* dY, void* dW, voi
         const int nw = (ntiles + groups - 1) / groups;
         const bool aligned = P.t_vec && P.dy_vec && (Fin % 32 == 0) && (Fout % BN == 0) && (N % WR == 0);
         const int64_t otiles = (Fout + BN - 1) / BN;
+        {   // bf16 matrix pipe (3-way split for fp32 storage) when the problem is aligned
+            int rc3 = DSW_OK;
+            int64_t S3 = 0;
+            if (aligned && dsw_wgrad_x3_try_launch(P, nw, groups, (int)otiles, dtype == DSW_BF16 ? 1 : 0,
+                                                   wgrad_max_slabs(Fin, Fout, K), &S3, stream, &rc3)) {
+                if (rc3 != DSW_OK) return rc3;
+                S = S3;
+                goto reduce;
+            }
+        }
         // slabs = resident workgroups (occupancy query), so the launch is a single full wave of work
 #define DSW_WGRAD_LAUNCH(BF, NW_)                                                                          \
     do {                                                                                                   \
@@ -639,6 +638,7 @@ int dsw_wgrad_launch(const void* X, const void* T, const void* dY, void* dW, voi
         int rc = dsw_check_launch();
         if (rc != DSW_OK) return rc;
     }
+reduce:
     const long total = (long)(K * Fin + 1) * Fout;
     dim3 rgrid((unsigned)((total + 31) / 32));
     if (dtype == DSW_F32)

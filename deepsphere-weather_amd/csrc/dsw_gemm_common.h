@@ -66,4 +66,20 @@ struct TsGemmParams {
 };
 
 
+constexpr int WR = 32;  // node rows per staged chunk
+
+struct WgradParams {
+    const void* X;          // T_0
+    const void* T;          // T_1.. planes
+    size_t plane_stride;    // elements
+    const void* dY;
+    float* partial;         // [S][Kd + 1][Fout]
+    long N;
+    int Fin, Fout, K;
+    long rows_per_slab;
+    int tiles_per_plane;    // ceil(Fin / 32)
+    int t_vec, dy_vec;
+};
+
+
 }  // namespace dsw_gemm
