@@ -118,105 +118,91 @@ class ResBlock(torch.nn.Module):
         return y
 
 
+# (attribute, input width, output widths, level) of the six residual blocks; "in" / "out" stand for the model's
+# merged time-feature widths, `level` selects the U-Net level whose Laplacian the block convolves with
+_UNET_BLOCKS = (
+    ("conv1", "in", (64, 128), 0),
+    ("conv2", 128, (192, 256), 1),
+    ("conv3", 256, (512, 256), 2),
+    ("uconv2", 512, (256, 128), 1),      # input = unpooled level 3 stacked with the level-2 skip
+    ("uconv1", 256, (128, 64), 0),       # input = unpooled level 2 stacked with the level-1 skip
+    ("uconv1_final", 64, "out", 0),
+)
+
+
 class UNetSpherical(UNet, torch.nn.Module):
-    """Three-level spherical U-Net with residual blocks (see the reference docstring for the
-    meaning of every option; the keys are those of ``configs/UNetSpherical/*/*.json``)."""
+    """Three-level spherical U-Net of residual ConvCheb blocks.
+
+    The options (and their defaults) are the keys of ``configs/UNetSpherical/*/*.json`` in the
+    reference; see its docstring for their meaning.  ``tensor_info`` carries the dimension order and
+    the feature / time / node counts of inputs and outputs.
+    """
 
     def __init__(
-        self,
-        tensor_info: Dict,
-        sampling: str,
-        sampling_kwargs: Dict,
-        # Convolutions options
-        kernel_size_conv: int = 3,
-        conv_type: str = "graph",
-        graph_type: str = "knn",
-        knn: int = 20,
-        # Options for classical image convolution on equiangular sampling
+        self, tensor_info: Dict, sampling: str, sampling_kwargs: Dict,
+        kernel_size_conv: int = 3, conv_type: str = "graph", graph_type: str = "knn", knn: int = 20,
         periodic_padding: bool = True,
-        # ConvBlock Options
-        bias: bool = True,
-        batch_norm: bool = False,
-        batch_norm_before_activation: bool = False,
-        activation: bool = True,
-        activation_fun: str = "relu",
-        # Pooling options
-        pool_method: str = "max",
-        kernel_size_pooling: int = 4,
-        # Architecture options
-        skip_connection: str = "stack",
-        increment_learning: bool = False,
+        bias: bool = True, batch_norm: bool = False, batch_norm_before_activation: bool = False,
+        activation: bool = True, activation_fun: str = "relu",
+        pool_method: str = "max", kernel_size_pooling: int = 4,
+        skip_connection: str = "stack", increment_learning: bool = False,
     ):
         super().__init__()
         self.dim_names = tensor_info["dim_order"]["dynamic"]
-        self.input_n_feature = tensor_info["input_n_feature"]
-        self.output_n_feature = tensor_info["output_n_feature"]
-        self.input_n_time = tensor_info["input_n_time"]
-        self.output_n_time = tensor_info["output_n_time"]
-        self.input_n_node = tensor_info["input_shape_info"]["dynamic"]["node"]
-        self.output_n_node = tensor_info["output_shape_info"]["dynamic"]["node"]
+        for side in ("input", "output"):
+            setattr(self, side + "_n_feature", tensor_info[side + "_n_feature"])
+            setattr(self, side + "_n_time", tensor_info[side + "_n_time"])
+            setattr(self, side + "_n_node", tensor_info[side + "_shape_info"]["dynamic"]["node"])
         # ConvCheb mixes the merged (time, feature) axis
-        self.input_channels = self.input_n_feature * self.input_n_time
-        self.output_channels = self.output_n_feature * self.output_n_time
+        self.input_channels = self.input_n_time * self.input_n_feature
+        self.output_channels = self.output_n_time * self.output_n_feature
         self.increment_learning = increment_learning
 
         sampling = check_sampling(sampling)
         conv_type = check_conv_type(conv_type, sampling)
         pool_method = check_pool_method(pool_method)
-        skip_connection = check_skip_connection(skip_connection)
-        lonlat_ratio = sampling_kwargs["nlon"] / sampling_kwargs["nlat"] if sampling == "equiangular" else None
-        block_opts = {
-            "kernel_size": kernel_size_conv,
-            "conv_type": conv_type,
-            "bias": bias,
-            "batch_norm": batch_norm,
-            "batch_norm_before_activation": batch_norm_before_activation,
-            "activation": activation,
-            "activation_fun": activation_fun,
-            "periodic_padding": periodic_padding,
-            "lonlat_ratio": lonlat_ratio,
-        }
-
-        # one graph per U-Net level, each `coarsening` times coarser than the previous
-        depth = 3
-        coarsening = int(np.sqrt(kernel_size_pooling))
-        sampling_kwargs["k"] = knn
-        level_kwargs = [sampling_kwargs]
-        for _ in range(1, depth):
-            level_kwargs.append(pygsp_graph_coarsening(sampling, level_kwargs[-1], coarsening))
-        self.init_graph_and_laplacians(
-            sampling_list=[sampling] * depth,
-            sampling_kwargs_list=level_kwargs,
-            graph_type=graph_type,
-            conv_type=conv_type,
+        check_skip_connection(skip_connection)
+        lonlat_ratio = None
+        if sampling == "equiangular":
+            lonlat_ratio = sampling_kwargs["nlon"] / sampling_kwargs["nlat"]
+        block_opts = dict(
+            kernel_size=kernel_size_conv, conv_type=conv_type, bias=bias, batch_norm=batch_norm,
+            batch_norm_before_activation=batch_norm_before_activation, activation=activation,
+            activation_fun=activation_fun, periodic_padding=periodic_padding, lonlat_ratio=lonlat_ratio,
         )
+
+        # one graph per level, each `step` times coarser (linear) than the one above
+        n_levels, step = 3, int(np.sqrt(kernel_size_pooling))
+        sampling_kwargs["k"] = knn
+        per_level = [sampling_kwargs]
+        while len(per_level) < n_levels:
+            per_level.append(pygsp_graph_coarsening(sampling, per_level[-1], step))
+        self.init_graph_and_laplacians(sampling_list=[sampling] * n_levels, sampling_kwargs_list=per_level,
+                                       graph_type=graph_type, conv_type=conv_type)
 
         if pool_method in ("interp", "maxval", "maxarea", "learn"):
             assert conv_type == "graph"
-            self.pool1, self.unpool1 = PoolUnpoolBlock.getGeneralPoolUnpoolLayer(
-                src_graph=self.graphs[0], dst_graph=self.graphs[1], pool_method=pool_method
-            )
-            self.pool2, self.unpool2 = PoolUnpoolBlock.getGeneralPoolUnpoolLayer(
-                src_graph=self.graphs[1], dst_graph=self.graphs[2], pool_method=pool_method
-            )
+            for lvl in (1, 2):
+                pool, unpool = PoolUnpoolBlock.getGeneralPoolUnpoolLayer(
+                    src_graph=self.graphs[lvl - 1], dst_graph=self.graphs[lvl], pool_method=pool_method)
+                setattr(self, f"pool{lvl}", pool)
+                setattr(self, f"unpool{lvl}", unpool)
         elif pool_method in ("max", "avg"):
             assert sampling in ["healpix", "equiangular"]
-            opts = dict(sampling=sampling, pool_method=pool_method, kernel_size=kernel_size_pooling,
-                        lonlat_ratio=lonlat_ratio)
-            self.pool1, self.unpool1 = PoolUnpoolBlock.getPoolUnpoolLayer(**opts)
-            self.pool2, self.unpool2 = PoolUnpoolBlock.getPoolUnpoolLayer(**opts)
+            for lvl in (1, 2):
+                pool, unpool = PoolUnpoolBlock.getPoolUnpoolLayer(
+                    sampling=sampling, pool_method=pool_method, kernel_size=kernel_size_pooling,
+                    lonlat_ratio=lonlat_ratio)
+                setattr(self, f"pool{lvl}", pool)
+                setattr(self, f"unpool{lvl}", unpool)
         elif pool_method is not None:
             raise ValueError("Not valid pooling method provided.")
 
-        lap0, lap1, lap2 = self.laplacians
-        # encoder
-        self.conv1 = ResBlock(self.input_channels, (64, 128), laplacian=lap0, convblock_kwargs=block_opts)
-        self.conv2 = ResBlock(128, (192, 256), laplacian=lap1, convblock_kwargs=block_opts)
-        self.conv3 = ResBlock(256, (512, 256), laplacian=lap2, convblock_kwargs=block_opts)
-        # decoder (inputs are the stacked skip connections)
-        self.uconv2 = ResBlock(512, (256, 128), laplacian=lap1, convblock_kwargs=block_opts)
-        self.uconv1 = ResBlock(256, (128, 64), laplacian=lap0, convblock_kwargs=block_opts)
-        self.uconv1_final = ResBlock(64, self.output_channels, laplacian=lap0, convblock_kwargs=block_opts)
+        widths = {"in": self.input_channels, "out": self.output_channels}
+        for name, w_in, w_out, level in _UNET_BLOCKS:
+            block = ResBlock(widths.get(w_in, w_in), widths.get(w_out, w_out) if isinstance(w_out, str) else w_out,
+                             laplacian=self.laplacians[level], convblock_kwargs=block_opts)
+            setattr(self, name, block)
         if self.increment_learning:
             self.res_increment = torch.nn.Parameter(torch.zeros(1), requires_grad=True)
 

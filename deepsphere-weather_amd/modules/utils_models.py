@@ -1,66 +1,68 @@
-"""Sampling-name helpers (counterpart of ``/root/reference/modules/utils_models.py``).
+"""Sampling-name helpers of the spherical models.
 
-pygsp's ``sphere-graphs`` branch is used when importable; otherwise the self-contained builders of
-``dsw_amd.sphere`` stand in for the samplings they cover (healpix, equiangular).
+API-compatible counterpart of the reference's ``modules/utils_models.py`` (same function names,
+arguments, return values and exception types); the implementation is table driven.  Graph classes
+come from pygsp's ``sphere-graphs`` branch when it is importable, otherwise from the self-contained
+builders in ``dsw_amd.sphere`` (healpix and equiangular only).
 """
-try:  # pragma: no cover - pygsp is not installable in the build image
-    import pygsp as _pygsp
+from dsw_amd import sphere as _sphere
 
-    _GRAPHS = {
-        "healpix": _pygsp.graphs.SphereHealpix,
-        "equiangular": _pygsp.graphs.SphereEquiangular,
-        "icosahedral": _pygsp.graphs.SphereIcosahedral,
-        "cubed": _pygsp.graphs.SphereCubed,
-        "gauss": _pygsp.graphs.SphereGaussLegendre,
-    }
-except Exception:
-    from dsw_amd import sphere as _sphere
+_SAMPLINGS = ("healpix", "equiangular", "icosahedral", "cubed", "gauss")
+_PYGSP_CLASS = dict(zip(_SAMPLINGS, ("SphereHealpix", "SphereEquiangular", "SphereIcosahedral",
+                                     "SphereCubed", "SphereGaussLegendre")))
+_BUILTIN = {"healpix": _sphere.SphereHealpix, "equiangular": _sphere.SphereEquiangular}
+# which sampling kwargs shrink (integer division) when going one U-Net level down
+_COARSEN_KEYS = {"equiangular": ("nlat", "nlon"), "healpix": ("subdivisions",), "icosahedral": ("subdivisions",),
+                 "cubed": ("subdivisions",), "gauss": ("nlat",)}
+_SKIP_MODES = ("none", "stack", "sum", "avg")
 
-    def _missing(name):
-        def ctor(*args, **kwargs):
-            raise ImportError(f"sampling '{name}' needs pygsp (sphere-graphs branch), which is not installed")
 
-        return ctor
+def _unavailable(name):
+    def ctor(*_args, **_kwargs):
+        raise ImportError("sampling '%s' needs pygsp (sphere-graphs branch), which is not installed" % name)
 
-    _GRAPHS = {
-        "healpix": _sphere.SphereHealpix,
-        "equiangular": _sphere.SphereEquiangular,
-        "icosahedral": _missing("icosahedral"),
-        "cubed": _missing("cubed"),
-        "gauss": _missing("gauss"),
-    }
+    return ctor
 
-_SKIP_CONNECTIONS = ("none", "stack", "sum", "avg")
+
+def _graph_table():
+    try:  # pragma: no cover - pygsp cannot be installed in the build image
+        import pygsp
+
+        return {name: getattr(pygsp.graphs, cls) for name, cls in _PYGSP_CLASS.items()}
+    except Exception:
+        return {name: _BUILTIN.get(name, _unavailable(name)) for name in _SAMPLINGS}
+
+
+def _require_str(value, label):
+    if not isinstance(value, str):
+        raise TypeError("'%s' must be a string." % label)
+    return value.lower()
 
 
 def get_pygsp_graph_dict():
-    return dict(_GRAPHS)
+    """sampling name -> graph class."""
+    return _graph_table()
 
 
 def get_valid_pygsp_graph():
-    return list(_GRAPHS)
+    return list(_SAMPLINGS)
 
 
 def check_sampling(sampling):
-    if not isinstance(sampling, str):
-        raise TypeError("'sampling' must be a string.")
-    sampling = sampling.lower()
-    if sampling not in _GRAPHS:
-        raise ValueError("'sampling' must be one of {}.".format(get_valid_pygsp_graph()))
-    return sampling
+    name = _require_str(sampling, "sampling")
+    if name not in _SAMPLINGS:
+        raise ValueError("'sampling' must be one of {}.".format(list(_SAMPLINGS)))
+    return name
 
 
 def check_conv_type(conv_type, sampling):
-    if not isinstance(conv_type, str):
-        raise TypeError("'conv_type' must be a string.")
-    if not isinstance(sampling, str):
-        raise TypeError("'sampling' must be a string.")
-    conv_type = conv_type.lower()
-    if conv_type not in ("graph", "image"):
+    kind = _require_str(conv_type, "conv_type")
+    grid = _require_str(sampling, "sampling")
+    if kind not in ("graph", "image"):
         raise ValueError("'conv_type' must be either 'graph' or 'image'.")
-    if conv_type == "image" and sampling.lower() != "equiangular":
+    if kind == "image" and grid != "equiangular":
         raise ValueError("conv_type='image' is available only if sampling='equiangular'.")
-    return conv_type
+    return kind
 
 
 def check_pool_method(pool_method):
@@ -68,17 +70,16 @@ def check_pool_method(pool_method):
 
 
 def check_skip_connection(skip_connection):
-    if skip_connection is None:
-        return "none"
-    if not isinstance(skip_connection, str):
+    mode = "none" if skip_connection is None else skip_connection
+    if not isinstance(mode, str):
         raise TypeError("'skip_connection' must be a string.")
-    if skip_connection not in _SKIP_CONNECTIONS:
-        raise ValueError("'skip_connection' must be one of {}".format(_SKIP_CONNECTIONS))
-    return skip_connection
+    if mode not in _SKIP_MODES:
+        raise ValueError("'skip_connection' must be one of {}".format(_SKIP_MODES))
+    return mode
 
 
 def get_pygsp_graph_fun(sampling):
-    return _GRAPHS[check_sampling(sampling)]
+    return _graph_table()[check_sampling(sampling)]
 
 
 def get_pygsp_graph(sampling, sampling_kwargs, knn=20):
@@ -87,13 +88,8 @@ def get_pygsp_graph(sampling, sampling_kwargs, knn=20):
 
 
 def pygsp_graph_coarsening(sampling, sampling_kwargs, coarsening):
-    """Sampling kwargs of the next-coarser U-Net level."""
-    coarse = dict(sampling_kwargs)
-    if sampling == "equiangular":
-        coarse["nlat"] //= coarsening
-        coarse["nlon"] //= coarsening
-    elif sampling in ("icosahedral", "cubed", "healpix"):
-        coarse["subdivisions"] //= coarsening
-    elif sampling == "gauss":
-        coarse["nlat"] //= coarsening
-    return coarse
+    """kwargs of the sampling one U-Net level down (``coarsening`` = linear factor)."""
+    out = dict(sampling_kwargs)
+    for key in _COARSEN_KEYS.get(sampling, ()):
+        out[key] = out[key] // coarsening
+    return out
