@@ -70,6 +70,14 @@ def _check_fixture(g, prefix=""):
     assert orc.max_rel_err(dw, dw64) <= TOL_F64
     if has_bias:
         assert orc.max_rel_err(db, db64) <= TOL_F64
+    # and against the plain-C restatement (third independent statement of the arithmetic)
+    from oracle import c_oracle
+
+    yc, basis_c = c_oracle.cheb_forward(rp, ci, va, g[prefix + "x"], g[prefix + "w"], b)
+    dxc, dwc, _ = c_oracle.cheb_backward(rp, ci, va, basis_c, g[prefix + "w"], g[prefix + "gy"], bool(has_bias))
+    assert orc.max_rel_err(y, yc) <= TOL_F64
+    assert orc.max_rel_err(dx, dxc) <= TOL_F64
+    assert orc.max_rel_err(dw, dwc) <= TOL_F64
 
 
 @pytest.mark.parametrize("name", ["G1_conv_c1_k8", "G1_conv_c1_k20", "G6_conv_irregular"])

@@ -95,3 +95,32 @@ def test_error_fixture():
     lap = orc.coo_from_csr_arrays(np.array([0, 1, 2]), np.array([0, 1]), np.array([1.0, 1.0], dtype=np.float32), (2, 2))
     with pytest.raises(ValueError, match="does not match the expected shape"):
         orc.conv_cheb_torch(lap, torch.zeros(1, 2, 3), torch.zeros(4, 3, 2))
+
+
+# ---------------------------------------------------------------------------------------------
+# plain-C restatement (oracle/cheb_oracle.c) against the same fixtures
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,prefix", [("G1_conv_c1_k20", ""), ("G6_conv_irregular", ""),
+                                         ("G2_conv_K_sweep", "ns_K5_"), ("G2_conv_K_sweep", "sym_K1_"),
+                                         ("G2_conv_K_sweep", "ns_K2_")])
+def test_c_oracle_conv(name, prefix):
+    from oracle import c_oracle
+
+    g = load_golden(name)
+    (B, V, Fin, Fout, K, has_bias), (rp, ci, va), (x, w, b, gy) = _conv_case(g, prefix)
+    y, basis = c_oracle.cheb_forward(rp, ci, va, x, w, b)
+    dx, dw, db = c_oracle.cheb_backward(rp, ci, va, basis, w, gy, bool(has_bias))
+    assert orc.max_rel_err(g[prefix + "y"], y) <= TOL64
+    assert orc.max_rel_err(g[prefix + "dx"], dx) <= TOL64
+    assert orc.max_rel_err(g[prefix + "dw"], dw) <= TOL64
+    if has_bias:
+        assert orc.max_rel_err(g[prefix + "db"], db) <= TOL64
+
+
+def test_c_oracle_remap():
+    from oracle import c_oracle
+
+    g = load_golden("G3_remap")
+    rp, ci, va = (g[f"interp_pool_{k}"] for k in ("rowptr", "colind", "values"))
+    y = c_oracle.remap(rp, ci, va, (192, 768), g["interp_x"])
+    assert orc.max_rel_err(g["interp_yp"], y) <= TOL64
