@@ -18,6 +18,7 @@
 // HBM-bound by construction: every U row is fetched ~|S2|/R times, but only the first fetch
 // misses L2 (blocks of one XCD walk contiguous tiles), and the gathers - k+1 per row and hop,
 // the limiter of the one-hop kernel on the L1/TA path - run on the LDS pipe at 4x the rate.
+#include <type_traits>
 #include "dsw_common.h"
 #include "../../include/dsw_hip.h"
 
@@ -26,33 +27,41 @@ namespace {
 constexpr int NTHREADS = 512;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in VGPRs
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));       // v_pk_fma_f32 / v_pk_mul_f32 operands
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));      // v_cvt_pk_bf16_f32 result
+
+static __device__ __forceinline__ f32x2 fmav(const f32x2 a, const f32x2 b, const f32x2 c) {
+    return __builtin_elementwise_fma(a, b, c);
+}
+static __device__ __forceinline__ float fmav(const float a, const float b, const float c) { return fmaf(a, b, c); }
+
+// 16 bytes of a row widened to fp32: bf16 -> 4 register PAIRS (packed fp32 math halves the VALU work of the
+// 8-channel lane), fp32 -> 4 scalars (pairs would only cost registers there)
 template <bool BF16>
-struct Row16 {  // 16 bytes of a row: 4 fp32 or 8 bf16, widened to fp32 registers
-    static constexpr int N = BF16 ? 8 : 4;
-    static __device__ __forceinline__ void unpack(const uint4 t, float (&v)[N]) {
-        if constexpr (BF16) {
-            const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+struct Row16 {
+    static constexpr int N = 4;
+    using V = typename std::conditional<BF16, f32x2, float>::type;
+    static __device__ __forceinline__ V splat(const float a) {
+        if constexpr (BF16) return f32x2{a, a};
+        else return a;
+    }
+    static __device__ __forceinline__ void unpack(const uint4 t, V (&v)[N]) {
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[2 * i] = __uint_as_float(w[i] << 16);
-                v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
-            }
-        } else {
-            v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y);
-            v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (BF16) v[i] = f32x2{__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)};
+            else v[i] = __uint_as_float(w[i]);
         }
     }
-    static __device__ __forceinline__ uint4 pack(const float (&v)[N]) {
-        if constexpr (BF16) {
-            uint32_t w[4];
+    static __device__ __forceinline__ uint4 pack(const V (&v)[N]) {
+        uint32_t w[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
-            return make_uint4(w[0], w[1], w[2], w[3]);
-        } else {
-            return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
-                              __float_as_uint(v[3]));
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (BF16)   // round-to-nearest-even, one v_cvt_pk_bf16_f32 per pair
+                w[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v[i], bf16x2));
+            else w[i] = __float_as_uint(v[i]);
         }
+        return make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
 
@@ -79,15 +88,16 @@ struct Hop2Args {
 };
 
 
-// acc += sum_j val[j] * buf[col[j]] over one ELL row (W entries, W % 4 == 0, padded with {own row, 0}).
+// acc += sum_j val[j] * buf[col[j]] over the first W entries of one ELL row (W even, padded with {own row, 0}).
 // The chain entry -> address -> data -> fma is a sequence of dependent LDS round trips, so entries are
 // read two per ds_read_b128 and 8 (then 4) data rows are requested back to back: two LDS latencies per
 // batch instead of two per non-zero.
 template <bool BF16>
 static __device__ __forceinline__ void gather_ell(const uint2* __restrict__ row_ent, const int W,
                                                   const unsigned char* __restrict__ buf, const int row_bytes,
-                                                  const int cb, float (&acc)[Row16<BF16>::N]) {
+                                                  const int cb, typename Row16<BF16>::V (&acc)[Row16<BF16>::N]) {
     using R = Row16<BF16>;
+    using VT = typename R::V;
     constexpr int N = R::N;
     const uint4* e4 = reinterpret_cast<const uint4*>(row_ent);   // {col0, val0, col1, val1}
     int j = 0;
@@ -103,33 +113,47 @@ static __device__ __forceinline__ void gather_ell(const uint2* __restrict__ row_
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            float x0[N], x1[N];
+            VT x0[N], x1[N];
             R::unpack(d[2 * t], x0);
             R::unpack(d[2 * t + 1], x1);
-            const float v0 = __uint_as_float(e[t].y), v1 = __uint_as_float(e[t].w);
+            const VT v0 = R::splat(__uint_as_float(e[t].y)), v1 = R::splat(__uint_as_float(e[t].w));
 #pragma unroll
             for (int c = 0; c < N; ++c) {
-                acc[c] = fmaf(v0, x0[c], acc[c]);
-                acc[c] = fmaf(v1, x1[c], acc[c]);
+                acc[c] = fmav(v0, x0[c], acc[c]);
+                acc[c] = fmav(v1, x1[c], acc[c]);
             }
         }
     }
-    for (; j < W; j += 4) {
+    if (j + 4 <= W) {
         const uint4 ea = e4[j >> 1], eb = e4[(j >> 1) + 1];
         const uint4 d0 = *reinterpret_cast<const uint4*>(buf + (size_t)ea.x * row_bytes + cb);
         const uint4 d1 = *reinterpret_cast<const uint4*>(buf + (size_t)ea.z * row_bytes + cb);
         const uint4 d2 = *reinterpret_cast<const uint4*>(buf + (size_t)eb.x * row_bytes + cb);
         const uint4 d3 = *reinterpret_cast<const uint4*>(buf + (size_t)eb.z * row_bytes + cb);
-        float x0[N], x1[N], x2[N], x3[N];
+        VT x0[N], x1[N], x2[N], x3[N];
         R::unpack(d0, x0); R::unpack(d1, x1); R::unpack(d2, x2); R::unpack(d3, x3);
-        const float v0 = __uint_as_float(ea.y), v1 = __uint_as_float(ea.w);
-        const float v2 = __uint_as_float(eb.y), v3 = __uint_as_float(eb.w);
+        const VT v0 = R::splat(__uint_as_float(ea.y)), v1 = R::splat(__uint_as_float(ea.w));
+        const VT v2 = R::splat(__uint_as_float(eb.y)), v3 = R::splat(__uint_as_float(eb.w));
 #pragma unroll
         for (int c = 0; c < N; ++c) {
-            acc[c] = fmaf(v0, x0[c], acc[c]);
-            acc[c] = fmaf(v1, x1[c], acc[c]);
-            acc[c] = fmaf(v2, x2[c], acc[c]);
-            acc[c] = fmaf(v3, x3[c], acc[c]);
+            acc[c] = fmav(v0, x0[c], acc[c]);
+            acc[c] = fmav(v1, x1[c], acc[c]);
+            acc[c] = fmav(v2, x2[c], acc[c]);
+            acc[c] = fmav(v3, x3[c], acc[c]);
+        }
+        j += 4;
+    }
+    if (j < W) {   // W is even: one last pair
+        const uint4 ea = e4[j >> 1];
+        const uint4 d0 = *reinterpret_cast<const uint4*>(buf + (size_t)ea.x * row_bytes + cb);
+        const uint4 d1 = *reinterpret_cast<const uint4*>(buf + (size_t)ea.z * row_bytes + cb);
+        VT x0[N], x1[N];
+        R::unpack(d0, x0); R::unpack(d1, x1);
+        const VT v0 = R::splat(__uint_as_float(ea.y)), v1 = R::splat(__uint_as_float(ea.w));
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            acc[c] = fmav(v0, x0[c], acc[c]);
+            acc[c] = fmav(v1, x1[c], acc[c]);
         }
     }
 }
@@ -146,8 +170,9 @@ constexpr int MAXST = 8;
 // the U burst in flight under phases 1 and 2, and it lands in the other half of the double-buffered bufX
 // at the top of the next iteration.
 template <bool BF16, int NST, bool HZA, bool HZ2, int NS1 = NST, int NS2 = NST>
-__global__ __launch_bounds__(NTHREADS, (HZA ? 2 : 4)) void spmm2_fused_kernel(const Hop2Args P) {
+__global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fused_kernel(const Hop2Args P) {
     using R = Row16<BF16>;
+    using VT = typename R::V;
     constexpr int N = R::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     // LDS carve-up (all offsets multiples of 16)
@@ -156,6 +181,7 @@ __global__ __launch_bounds__(NTHREADS, (HZA ? 2 : 4)) void spmm2_fused_kernel(co
     unsigned char* bufT = bufX1 + (size_t)P.max_n2 * P.row_bytes;          // [max_n1][row_bytes]
     uint2* ell = reinterpret_cast<uint2*>(bufT + (size_t)P.max_n1 * P.row_bytes);   // [max_n1][W] {col, val}
     int* rows = reinterpret_cast<int*>(ell + (size_t)P.max_n1 * P.ell_w);  // [max_n2] global row ids
+    int* tile_w = rows + ((P.max_n2 + 3) & ~3);                            // longest local row of THIS tile
 
     // XCD-aware order: each XCD (hardware block id % 8) walks one contiguous range of (tile, batch chunk)
     const long nwg = gridDim.x, orig = blockIdx.x;
@@ -174,16 +200,20 @@ __global__ __launch_bounds__(NTHREADS, (HZA ? 2 : 4)) void spmm2_fused_kernel(co
     const size_t sample_bytes = (size_t)P.V * P.row_bytes;
 
     // ---- the tile's plan slice -> LDS (CSR expanded to ELL), once for all samples of this workgroup
+    if (tid == 0) *tile_w = 2;
     for (int i = tid; i < n2; i += NTHREADS) rows[i] = P.s2_rows[s2_off + i];
+    __syncthreads();
     for (int t = tid; t < n1 * W; t += NTHREADS) {
         const int i = t / W, j = t - i * W;
         const int p0 = P.lrowptr[rp_off + i], p1 = P.lrowptr[rp_off + i + 1];
         const int p = p0 + j;
+        if (j == 0 && p1 - p0 > 2) atomicMax(tile_w, p1 - p0);
         ell[t] = (p < p1) ? make_uint2((unsigned)P.lcol[nnz_off + p], __float_as_uint(P.lval[nnz_off + p]))
                           : make_uint2((unsigned)i, 0u);     // padding: own row, weight 0
     }
     __syncthreads();
 
+    const int Wt = (*tile_w + 1) & ~1;              // gather loop length of this tile (<= W, even)
     const int lpr = P.lpr;
     const int rpp = NTHREADS / lpr;                 // rows per pass
     const int grp0 = tid / lpr;
@@ -242,24 +272,24 @@ __global__ __launch_bounds__(NTHREADS, (HZA ? 2 : 4)) void spmm2_fused_kernel(co
         for (int k = 0; k < NS1; ++k) {
             const int i = grp + k * rpp;
             if (lane_ok && i < n1) {
-                float acc[N];
+                VT acc[N];
 #pragma unroll
-                for (int j = 0; j < N; ++j) acc[j] = 0.f;
-                gather_ell<BF16>(ell + (size_t)i * W, W, bufX, P.row_bytes, cb, acc);
-                float o[N];
+                for (int j = 0; j < N; ++j) acc[j] = R::splat(0.f);
+                gather_ell<BF16>(ell + (size_t)i * W, Wt, bufX, P.row_bytes, cb, acc);
+                VT o[N];
 #pragma unroll
-                for (int j = 0; j < N; ++j) o[j] = P.a1 * acc[j];
+                for (int j = 0; j < N; ++j) o[j] = R::splat(P.a1) * acc[j];
                 if constexpr (HZA) {
-                    float z[N];
+                    VT z[N];
                     R::unpack(__builtin_bit_cast(uint4, cz1[k]), z);
 #pragma unroll
-                    for (int j = 0; j < N; ++j) o[j] = fmaf(P.b1, z[j], o[j]);
+                    for (int j = 0; j < N; ++j) o[j] = fmav(R::splat(P.b1), z[j], o[j]);
                 }
                 if (HZA && P.Z1b != P.Z1) {
-                    float z[N];
+                    VT z[N];
                     R::unpack(__builtin_bit_cast(uint4, cz1b[k]), z);
 #pragma unroll
-                    for (int j = 0; j < N; ++j) o[j] = fmaf(P.d1, z[j], o[j]);
+                    for (int j = 0; j < N; ++j) o[j] = fmav(R::splat(P.d1), z[j], o[j]);
                 }
                 const uint4 packed = R::pack(o);
                 *reinterpret_cast<uint4*>(bufT + (size_t)i * P.row_bytes + cb) = packed;
@@ -274,19 +304,19 @@ __global__ __launch_bounds__(NTHREADS, (HZA ? 2 : 4)) void spmm2_fused_kernel(co
         for (int k = 0; k < NS2; ++k) {
             const int i = grp + k * rpp;
             if (lane_ok && i < rt) {
-                float acc[N];
+                VT acc[N];
 #pragma unroll
-                for (int j = 0; j < N; ++j) acc[j] = 0.f;
-                gather_ell<BF16>(ell + (size_t)i * W, W, bufT, P.row_bytes, cb, acc);
-                float u[N], o[N];
+                for (int j = 0; j < N; ++j) acc[j] = R::splat(0.f);
+                gather_ell<BF16>(ell + (size_t)i * W, Wt, bufT, P.row_bytes, cb, acc);
+                VT u[N], o[N];
                 R::unpack(*reinterpret_cast<const uint4*>(bufX + (size_t)i * P.row_bytes + cb), u);
 #pragma unroll
-                for (int j = 0; j < N; ++j) o[j] = fmaf(P.a2, acc[j], P.b2 * u[j]);
+                for (int j = 0; j < N; ++j) o[j] = fmav(R::splat(P.a2), acc[j], R::splat(P.b2) * u[j]);
                 if constexpr (HZ2) {
-                    float z[N];
+                    VT z[N];
                     R::unpack(__builtin_bit_cast(uint4, cz2[k]), z);
 #pragma unroll
-                    for (int j = 0; j < N; ++j) o[j] = fmaf(P.c2, z[j], o[j]);
+                    for (int j = 0; j < N; ++j) o[j] = fmav(R::splat(P.c2), z[j], o[j]);
                 }
                 *reinterpret_cast<uint4*>(P.Y2 + sample + (size_t)(r0 + i) * P.row_bytes + cb) = R::pack(o);
             }
@@ -305,7 +335,7 @@ static int hop2_ell_w(const dsw_hop2_plan* plan) { return (plan->reserved + 3) &
 static size_t hop2_lds_bytes(const dsw_hop2_plan* plan, int row_bytes) {
     size_t s = (size_t)(plan->max_n1 + 2 * (size_t)plan->max_n2) * row_bytes;   // bufT + double-buffered bufX
     s += (size_t)plan->max_n1 * hop2_ell_w(plan) * 8;
-    s += (size_t)plan->max_n2 * 4;
+    s += (size_t)((plan->max_n2 + 3) & ~3) * 4 + 16;   // row ids + the tile's loop length
     return (s + 15) & ~(size_t)15;
 }
 

@@ -66,7 +66,7 @@ class Hop2Plan:
         ell_w = (self.max_row_len + 3) & ~3
         s = (self.max_n1 + 2 * self.max_n2) * row_bytes   # bufT + double-buffered input rows
         s += self.max_n1 * ell_w * 8                      # ELL {col, val}
-        s += self.max_n2 * 4                              # gather list
+        s += ((self.max_n2 + 3) & ~3) * 4 + 16            # gather list + the tile's loop length
         return (s + 15) & ~15
 
     def to(self, device):
