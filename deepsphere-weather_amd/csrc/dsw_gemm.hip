@@ -470,6 +470,7 @@ static int launch_ts_gemm_nt(const TsGemmParams& P, int col_tiles, hipStream_t s
         long gx = 256L * per_cu / col_tiles;
         if (gx < 1) gx = 1;
         if (gx > row_tiles) gx = row_tiles;
+        if (col_tiles > 1 && gx >= 8) gx &= ~7L;   // column tiles of one row tile on one XCD: A re-reads hit its L2
         dim3 grid((unsigned)gx, (unsigned)col_tiles);
         if (aligned) hipLaunchKernelGGL((ts_gemm_kernel<BF16, NT, true, true>), grid, dim3(256), lds, stream, P);
         else hipLaunchKernelGGL((ts_gemm_kernel<BF16, NT, true, false>), grid, dim3(256), lds, stream, P);
