@@ -584,7 +584,7 @@ int dsw_wgrad_launch(const void* X, const void* T, const void* dY, void* dW, voi
     int64_t rps = 0;
     int64_t S = N > 0 ? 1 : 0;
     if (S > 0) {
-        WgradParams P;
+        WgradParams P{};
         P.X = X; P.T = T; P.plane_stride = (size_t)N * Fin; P.dY = dY; P.partial = partial;
         P.N = N; P.Fin = (int)Fin; P.Fout = (int)Fout; P.K = (int)K; P.rows_per_slab = rps;
         P.tiles_per_plane = (int)((Fin + 31) / 32);

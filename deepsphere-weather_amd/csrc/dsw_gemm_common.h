@@ -79,6 +79,7 @@ struct WgradParams {
     long rows_per_slab;
     int tiles_per_plane;    // ceil(Fin / 32)
     int t_vec, dy_vec;
+    int dbg;                // diagnostics (DSW_DBG env): 2 = skip MFMAs, 3 = skip LDS staging, 4 = skip refetch
 };
 
 

@@ -131,13 +131,14 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_x3_kernel(const WgradParam
         __syncthreads();   // previous chunk's fragments fully consumed
         const bool live = ci < n_chunks;
         // transpose + split into LDS
+        if (P.dbg != 3)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             split_store<NSPLIT>(TsT + (size_t)wave * NSPLIT * TPLANE, TPLANE, tc4, tr + 8 * i, srt[i]);
 #pragma unroll
         for (int i = 0; i < RD; ++i) {
             const int e = tid + NT_ * i;
-            if (e < WR * BN / 4) {
+            if (e < WR * BN / 4 && P.dbg != 3) {
                 split_store<NSPLIT>(DsT, DPLANE, (e & 15) * 4, e >> 4, srd[i]);
                 if (live && blockIdx.y == 0) {
 #pragma unroll
@@ -146,11 +147,11 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_x3_kernel(const WgradParam
             }
         }
         __syncthreads();
-        {
+        if (P.dbg != 4) {
             const long nx = ci + PF;
             fetch(n_begin + (nx < n_chunks ? nx : n_chunks - 1) * WR, srt, srd);
         }
-        if (live && active) {
+        if (live && active && P.dbg != 2) {
             const unsigned short* ta = TsT + (size_t)wave * NSPLIT * TPLANE + (size_t)l31 * KSN + 8 * half;
             const unsigned short* db = DsT + (size_t)l31 * KSN + 8 * half;
 #pragma unroll
@@ -232,6 +233,7 @@ int launch_wx3(WgradParams& P, int groups, int otiles, int64_t max_slabs, int64_
     if (rps < 4 * WR) rps = 4 * WR;
     const int64_t S = (P.N + rps - 1) / rps;
     P.rows_per_slab = rps;
+    { static const char* d = getenv("DSW_DBG"); P.dbg = d ? atoi(d) : 0; }
     *S_out = S;
     dim3 grid((unsigned)S, (unsigned)groups, (unsigned)otiles);
     hipLaunchKernelGGL((cheb_wgrad_x3_kernel<BF16IO, NSPLIT, NW>), grid, dim3(NT_), lds, stream, P);

@@ -210,9 +210,11 @@ class _HipBackend:
         y = torch.empty((B, V, Fout), dtype=x.dtype, device=x.device)
         T = torch.empty((K - 1, B, V, Fin), dtype=x.dtype, device=x.device) if K > 1 else None
         pp, _keep = _plan_ptr(op, x) if (K > 2 and _FWD_FUSED) else (None, None)
+        csr = (None, None, None, V, 0) if op is None else (
+            op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz)
         with torch.cuda.device(x.device):
             rc = lib.dsw_cheb_fwd(
-                op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz,
+                *csr,
                 x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(T), B, Fin, Fout, K,
                 _DTYPES[x.dtype], _stream(x), pp,
             )
@@ -234,9 +236,11 @@ class _HipBackend:
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
         opt = op.transpose() if (need_dx and K > 1) else op
         pp, _keep = _plan_ptr(opt, x) if (need_dx and K > 2) else (None, None)
+        csr = (None, None, None, V, 0) if opt is None else (
+            opt.rowptr.data_ptr(), opt.colind.data_ptr(), opt.values.data_ptr(), V, opt.nnz)
         with torch.cuda.device(x.device):
             rc = lib.dsw_cheb_bwd(
-                opt.rowptr.data_ptr(), opt.colind.data_ptr(), opt.values.data_ptr(), V, opt.nnz,
+                *csr,
                 x.data_ptr(), _ptr(T), w.data_ptr(), dy.data_ptr(), _ptr(dx), _ptr(dw), _ptr(db),
                 ws.data_ptr(), nbytes, B, Fin, Fout, K, dt, _stream(x), pp,
             )
@@ -331,6 +335,18 @@ def cheb_conv(op: CsrOperator, x: torch.Tensor, weight: torch.Tensor, bias=None)
         )
     _check_dtype(x, weight, bias)
     return _ChebConvFn.apply(x, weight, bias, op)
+
+
+def dense_mix(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
+    """``y = x @ weight (+ bias)`` over the last axis, ``weight [Fin, Fout]``: the K = 1 channel mix (no operator),
+    i.e. the per-node linear map of the residual branch (my_models_graph.py:177-180) on the same MFMA GEMM
+    kernels as ConvCheb - forward, dgrad and wgrad."""
+    if weight.dim() != 2 or x.shape[-1] != weight.shape[0]:
+        raise ValueError("expected x [..., Fin] and weight [Fin, Fout]")
+    _check_dtype(x, weight, bias)
+    lead = x.shape[:-1]
+    y = _ChebConvFn.apply(x.reshape(1, -1, x.shape[-1]), weight.unsqueeze(1), bias, None)
+    return y.reshape(*lead, weight.shape[1])
 
 
 def sparse_remap(op: CsrOperator, x: torch.Tensor) -> torch.Tensor:

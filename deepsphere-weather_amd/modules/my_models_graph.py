@@ -13,6 +13,7 @@ import torch
 from torch.nn import BatchNorm1d, Identity, Linear
 from torch.nn import functional as F
 
+from dsw_amd import functional as dsw_functional
 from modules.layers import GeneralConvBlock, PoolUnpoolBlock
 from modules.models import UNet
 from modules.utils_models import (
@@ -80,6 +81,16 @@ class ConvBlock(GeneralConvBlock):
         return x
 
 
+class _NodeLinear(Linear):
+    """``torch.nn.Linear`` (same parameters / state_dict entries) whose per-node map runs on the path's own
+    MFMA GEMM kernels (the K = 1 channel mix) instead of a rocBLAS call."""
+
+    def forward(self, x):
+        if not x.is_cuda:
+            return super().forward(x)
+        return dsw_functional.dense_mix(x, self.weight.t(), self.bias)
+
+
 class ResBlock(torch.nn.Module):
     """Stack of ConvBlocks (``convblock1..n``, no activation on the last) with a ReZero-scaled
     residual branch: ``out = rezero_weight * convs(x) + res_connection(x)``."""
@@ -100,7 +111,7 @@ class ResBlock(torch.nn.Module):
             setattr(self, name, ConvBlock(width_in, width_out, laplacian=laplacian, **opts))
             self.conv_names_list.append(name)
             width_in = width_out
-        self.res_connection = Identity() if in_channels == widths[-1] else Linear(in_channels, widths[-1])
+        self.res_connection = Identity() if in_channels == widths[-1] else _NodeLinear(in_channels, widths[-1])
         if self.rezero:
             self.rezero_weight = torch.nn.Parameter(torch.zeros(1), requires_grad=True)
         if convblock_kwargs["batch_norm"]:  # start each block as an identity mapping

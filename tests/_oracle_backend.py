@@ -5,7 +5,9 @@ import torch
 from oracle import cheb_oracle as orc
 
 
-def _csr_np(op):
+def _csr_np(op, V=None):
+    if op is None:   # K = 1 (dense_mix): the operator is never applied
+        return np.zeros(V + 1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32)
     return op.rowptr.cpu().numpy(), op.colind.cpu().numpy(), op.values.cpu().numpy()
 
 
@@ -30,7 +32,7 @@ class OracleBackend:
         return torch.from_numpy(np.stack(T[1:])).to(x.dtype)
 
     def cheb_fwd(self, op, x, w, bias):
-        rp, ci, va = _csr_np(op)
+        rp, ci, va = _csr_np(op, x.shape[1])
         y = orc.cheb_forward_f64(
             rp, ci, va, x.detach().float().numpy(), w.detach().float().numpy(),
             None if bias is None else bias.detach().float().numpy(),
@@ -40,7 +42,7 @@ class OracleBackend:
         return torch.from_numpy(y).to(x.dtype), T
 
     def cheb_bwd(self, op, x, T, w, dy, need_dx, need_dw, need_db):
-        rp, ci, va = _csr_np(op)
+        rp, ci, va = _csr_np(op, x.shape[1])
         dx, dw, db = orc.cheb_backward_f64(
             rp, ci, va, x.detach().float().numpy(), w.detach().float().numpy(),
             dy.detach().float().numpy(), has_bias=True,

@@ -415,3 +415,23 @@ def test_fused_recurrences_equal_unfused(K):
     L = orc._csr64(rp, ci, va, (V, V))
     Tref = np.stack(orc.cheb_basis_f64(L, x.cpu().numpy(), K)[1:])
     assert orc.max_rel_err(res[True][0], Tref) <= TOL_F64
+
+
+@pytest.mark.parametrize("N,Fin,Fout", [(768 * 3, 256, 128), (1000, 48, 20), (64, 512, 256)])
+def test_dense_mix_vs_f64(N, Fin, Fout):
+    """K = 1 channel mix (residual branch of ResBlock) against an fp64 matmul: forward, dX, dW, db."""
+    from dsw_amd import functional as F_
+
+    torch.manual_seed(3)
+    x = torch.randn(3, N // 3 if N % 3 == 0 else N, Fin, device=DEV)[: (3 if N % 3 == 0 else 1)].contiguous().requires_grad_(True)
+    w = (torch.randn(Fout, Fin, device=DEV) / Fin ** 0.5).requires_grad_(True)   # nn.Linear layout
+    b = torch.randn(Fout, device=DEV).requires_grad_(True)
+    gy = torch.randn(*x.shape[:-1], Fout, device=DEV)
+    y = F_.dense_mix(x, w.t(), b)
+    y.backward(gy)
+    x64, w64, b64, g64 = (t.detach().double().cpu() for t in (x, w, b, gy))
+    y64 = x64 @ w64.t() + b64
+    assert orc.max_rel_err(y, y64.numpy()) <= TOL_F64
+    assert orc.max_rel_err(x.grad, (g64 @ w64).numpy()) <= TOL_F64
+    assert orc.max_rel_err(w.grad, (g64.reshape(-1, Fout).t() @ x64.reshape(-1, Fin)).numpy()) <= TOL_F64
+    assert orc.max_rel_err(b.grad, g64.reshape(-1, Fout).sum(0).numpy()) <= TOL_F64
