@@ -20,6 +20,9 @@ using namespace dsw_gemm;
 // x3-split fp32 GEMM on the bf16 matrix pipe (dsw_gemm_x3.hip); returns 1 if it took the launch
 int dsw_ts_gemm_x3_try_launch(const TsGemmParams& P, int nt, int col_tiles, int bf16, hipStream_t stream, int* rc);
 
+// streaming-W variant for wide fp32 layers (dsw_gemm_x3s.hip); returns 1 if it took the launch
+int dsw_ts_gemm_x3s_try_launch(const TsGemmParams& P, hipStream_t stream, int* rc);
+
 // wgrad on the bf16 matrix pipe (dsw_wgrad_x3.hip); returns 1 if it took the launch
 int dsw_wgrad_x3_try_launch(WgradParams& P, int nw, int groups, int otiles, int bf16, int64_t max_slabs, int64_t* S_out,
                             hipStream_t stream, int* rc);
@@ -490,6 +493,13 @@ static int launch_ts_gemm(const TsGemmParams& P, hipStream_t stream) {
     // re-reading A once per extra column tile is cheaper than running on the 16x slower fp32 MFMA
     if (P.a_vec && (P.kd_per_plane % BK == 0) && n_total > 32) {
         const int nat = n_total <= 128 ? (n_total + 31) / 32 : 4;
+        if constexpr (!BF16) {
+            // wide fp32 layers: stream W chunk by chunk (dsw_gemm_x3s.hip) instead of narrowing the column tile
+            const size_t ks = (size_t)P.n_planes_a * P.kd_per_plane + 8;
+            const size_t lds_nat = (size_t)BM * LDA * 4 + (size_t)3 * (size_t)(32 * nat) * ks * 2;
+            int rc = DSW_OK;
+            if (lds_nat > 160 * 1024 && dsw_ts_gemm_x3s_try_launch(P, stream, &rc)) return rc;
+        }
         for (int nt = nat - 1; nt >= 1; --nt) {
             int rc = DSW_OK;
             // only when the natural width fails: probe it first through the normal path below

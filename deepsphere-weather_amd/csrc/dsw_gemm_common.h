@@ -66,6 +66,25 @@ struct TsGemmParams {
 };
 
 
+// Position of a persistent workgroup in its (row tile, A plane, chunk) sequence, advanced incrementally: the
+// equivalent  it / total, it % total, c / chunks  are 64-bit divisions that cost ~100 scalar instructions each,
+// and the CU's single scalar unit is shared by all its waves (measured: the GEMM main loops were SALU-bound).
+struct TileChunkIter {
+    long row0;      // first row of the current row tile
+    long it;        // linear iteration index
+    int p, kc, c;   // A plane, chunk inside the plane, c = p * chunks + kc
+    __device__ __forceinline__ void init(const long first_row) { row0 = first_row; it = 0; p = 0; kc = 0; c = 0; }
+    __device__ __forceinline__ void next(const int chunks, const int total, const long row_step) {
+        ++it; ++c; ++kc;
+        if (kc == chunks) { kc = 0; ++p; }
+        if (c == total) { c = 0; p = 0; row0 += row_step; }
+    }
+    // stays on the last valid iteration (tail prefetches re-read it harmlessly)
+    __device__ __forceinline__ void next_clamped(const long n_iter, const int chunks, const int total, const long row_step) {
+        if (it + 1 < n_iter) next(chunks, total, row_step);
+    }
+};
+
 constexpr int WR = 32;  // node rows per staged chunk
 
 struct WgradParams {

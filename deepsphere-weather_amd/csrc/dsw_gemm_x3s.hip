@@ -1,0 +1,286 @@
+// fp32 channel-mix GEMM on the bf16 matrix pipe (exact 3-way split, see dsw_gemm_x3.hip) for WIDE layers:
+// the split W panel of a column tile (3 * Kd * 128 * 2 B, e.g. 1.2 MB at Kd = 1536) does not fit LDS, so W is
+// streamed chunk by chunk next to the activations instead of staying resident.
+//
+//   C (M x n_total) = sum_p A[p] (M x kd) * B[p] (kd x n_total) (+ bias)        [TsGemmParams, fp32 storage]
+//
+// Workgroup = NWV waves, tile = (32 * NWV rows) x (32 * NT columns); a wave owns 32 rows and NT MFMA tiles.
+// Per 32-wide reduction chunk:
+//   A: 3-deep register prefetch ring -> the wave's private staging rows in LDS (no workgroup barrier), split
+//      into bf16 terms in registers right before the MFMAs (as in the resident kernel);
+//   B: the chunk's [32 k][32 * NT cols] fp32 block of W is fetched one chunk ahead into registers, split ONCE per
+//      workgroup into three bf16 planes and written to LDS as [plane][col][k] (k contiguous, 80-byte rows ->
+//      conflict-free ds_read_b128), double buffered: one workgroup barrier per chunk.
+// W is tiny (<= a few MB) and re-read by every workgroup: it lives in L2; HBM sees the A stream and the output.
+// The shapes that take this path are MFMA-bound (arithmetic intensity Kd * n / (Kd + n) >> machine balance), so
+// the tile is as large as registers allow: 8 waves x (32 x 128) -> 48 MFMAs per wave and chunk against 16 staged
+// W elements per lane.
+#include "dsw_gemm_common.h"
+
+using namespace dsw_gemm;
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+constexpr int KSB = 40;   // bf16 elements per B row in LDS: 32 k + 8 pad (80 B)
+
+static __device__ __forceinline__ bf16x8_t pack_trunc8(const float (&f)[8]) {
+    uint4 u;
+    u.x = __builtin_amdgcn_perm(__float_as_uint(f[1]), __float_as_uint(f[0]), 0x07060302u);
+    u.y = __builtin_amdgcn_perm(__float_as_uint(f[3]), __float_as_uint(f[2]), 0x07060302u);
+    u.z = __builtin_amdgcn_perm(__float_as_uint(f[5]), __float_as_uint(f[4]), 0x07060302u);
+    u.w = __builtin_amdgcn_perm(__float_as_uint(f[7]), __float_as_uint(f[6]), 0x07060302u);
+    return __builtin_bit_cast(bf16x8_t, u);
+}
+static __device__ __forceinline__ float trunc_bf16(float f) {
+    return __uint_as_float(__float_as_uint(f) & 0xffff0000u);
+}
+
+// KFAST: the B operand is contiguous along the reduction index (dgrad: W^T), else along the columns (forward).
+template <int NT, int NWV, bool KFAST>
+__global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParams P) {
+    constexpr int BMT = 32 * NWV;
+    constexpr int NTH = 64 * NWV;
+    constexpr int BNT = 32 * NT;
+    constexpr int PF = 3;
+    constexpr int NPAIR = (16 * BNT) / NTH;            // (k, k+1) element pairs of one W chunk per thread
+    static_assert((16 * BNT) % NTH == 0, "W chunk must divide over the threads");
+    constexpr int BPLANE = BNT * KSB;                  // one bf16 plane of one B buffer
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                                               // [2][BMT][LDA]
+    unsigned short* Bt = reinterpret_cast<unsigned short*>(smem + 2 * BMT * LDA);   // [2][3][BNT][KSB]
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int n_total = P.n_planes_c * P.n_per_plane;
+    const int col0 = blockIdx.y * BNT;
+    const int chunks = P.kd_per_plane / BK;
+    const int total = P.n_planes_a * chunks;
+    const long row_tiles = (P.M + BMT - 1) / BMT;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    bool col_ok[NT];
+    char* col_ptr[NT];
+    float col_bias[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int j = col0 + 32 * nt + l31;
+        col_ok[nt] = j < n_total;
+        const int q = col_ok[nt] ? j / P.n_per_plane : 0;
+        const int n = col_ok[nt] ? j - q * P.n_per_plane : 0;
+        char* base = static_cast<char*>((q == 0) ? P.C0 : P.C1);
+        const size_t cbase = (q == 0) ? 0 : (size_t)(q - 1) * P.c_plane_stride;
+        col_ptr[nt] = base + (cbase + (size_t)n) * 4;
+        col_bias[nt] = (P.bias != nullptr) ? static_cast<const float*>(P.bias)[n] : 0.f;
+    }
+
+    // ---- W chunk: this thread's NPAIR (column, k-pair) slots; the global offset of a slot inside chunk 0
+    int bslot_lds[NPAIR];     // element offset of the pair inside a plane of a B buffer
+    long bslot_g[NPAIR];      // element offset of W(k = 2*kp, col) relative to the chunk origin; < 0: column out of range
+#pragma unroll
+    for (int i = 0; i < NPAIR; ++i) {
+        const int e = tid + NTH * i;
+        const int col = KFAST ? e >> 4 : e % BNT;
+        const int kp = KFAST ? e & 15 : e / BNT;
+        bslot_lds[i] = col * KSB + 2 * kp;
+        const int j = col0 + col;
+        if (j < n_total) {
+            const int q = j / P.n_per_plane, n = j - q * P.n_per_plane;
+            bslot_g[i] = (long)q * P.b_sq + (long)n * P.b_sn + (long)(2 * kp) * P.b_skd;
+        } else {
+            bslot_g[i] = -1;
+        }
+    }
+    const float* Bsrc = static_cast<const float*>(P.Bsrc);
+    float rb0[NPAIR][2], rb1[NPAIR][2], rb2[NPAIR][2];   // W ring: same depth / slot numbering as the A ring
+    int bp = 0, bkc = 0;   // (plane, chunk) of the NEXT W chunk to fetch: cycles through the reduction, no clamp
+    auto fetch_b = [&](float (&rb)[NPAIR][2]) __attribute__((always_inline)) {
+        const long origin = (long)bp * P.b_sp + (long)(bkc * BK) * P.b_skd;
+#pragma unroll
+        for (int i = 0; i < NPAIR; ++i) {
+            const long g = bslot_g[i] < 0 ? 0 : bslot_g[i];
+            rb[i][0] = Bsrc[origin + g];            // unconditional (clamped) loads: nothing may consume the value
+            rb[i][1] = Bsrc[origin + g + P.b_skd];  // here, or the compiler parks a vmcnt(0) right behind them
+        }
+        if (++bkc == chunks) { bkc = 0; if (++bp == P.n_planes_a) bp = 0; }
+    };
+    auto store_b = [&](unsigned short* buf, const float (&rb)[NPAIR][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NPAIR; ++i) {
+            const float a = bslot_g[i] < 0 ? 0.f : rb[i][0], b = bslot_g[i] < 0 ? 0.f : rb[i][1];
+            const float ah = trunc_bf16(a), bh = trunc_bf16(b);
+            const float a1 = a - ah, b1 = b - bh;
+            const float am = trunc_bf16(a1), bm = trunc_bf16(b1);
+            const float al = a1 - am, bl = b1 - bm;
+            uint32_t* dst = reinterpret_cast<uint32_t*>(buf + bslot_lds[i]);
+            dst[0] = __builtin_amdgcn_perm(__float_as_uint(bh), __float_as_uint(ah), 0x07060302u);
+            dst[BPLANE / 2] = __builtin_amdgcn_perm(__float_as_uint(bm), __float_as_uint(am), 0x07060302u);
+            dst[BPLANE] = __builtin_amdgcn_perm(__float_as_uint(bl), __float_as_uint(al), 0x07060302u);
+        }
+    };
+
+    // ---- A ring
+    const int ar = wave * 32 + (lane >> 3);
+    const int ac4 = (lane & 7) * 4;
+    f32x4 ra0[4], ra1[4], ra2[4];
+    const long my_tiles = (row_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const long n_iter = my_tiles * total;
+    const long row_step = (long)gridDim.x * BMT;
+    TileChunkIter cur, pre;   // the chunk being multiplied / the chunk being prefetched (PF ahead, clamped)
+    cur.init((long)blockIdx.x * BMT);
+    pre.init((long)blockIdx.x * BMT);
+    auto fetch = [&](f32x4 (&dra)[4]) __attribute__((always_inline)) {   // A rows of chunk `pre`, then advance it
+        const float* A = static_cast<const float*>((pre.p == 0) ? P.A0 : P.A1);
+        const size_t abase = (pre.p == 0) ? 0 : (size_t)(pre.p - 1) * P.a_plane_stride;
+        const int k0 = pre.kc * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long r = pre.row0 + ar + 8 * i;
+            r = r < P.M ? r : P.M - 1;
+            dra[i] = *reinterpret_cast<const f32x4*>(A + abase + (size_t)r * P.lda + k0 + ac4);
+        }
+        pre.next_clamped(n_iter, chunks, total, row_step);
+    };
+    if (n_iter <= 0) return;
+    // Software pipeline.  LDS holds two (A, W) buffer pairs; chunk j lives in pair j & 1.  Stage `it` multiplies
+    // chunk it out of pair it & 1 and, in the SAME barrier interval (so that the scheduler can hide the split /
+    // LDS-store VALU work in the MFMA shadow), stages chunk it+1 from ring slot (it+1) % 3 into the other pair and
+    // refills that slot with chunk it+4.  W loads are issued before the A loads of a stage: vmcnt completes in
+    // order, and the W slot is needed one instruction earlier.
+    auto store_a = [&](float* abuf, const f32x4 (&slot)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&abuf[(ar + 8 * i) * LDA + ac4]) = slot[i];
+    };
+    fetch_b(rb0); fetch(ra0);
+    fetch_b(rb1); fetch(ra1);
+    fetch_b(rb2); fetch(ra2);
+    store_b(Bt, rb0);
+    store_a(As, ra0);
+    fetch_b(rb0); fetch(ra0);
+    const long n_pad = (n_iter + PF - 1) / PF * PF;
+
+    auto stage = [&](auto U, const long it) __attribute__((always_inline)) {
+        constexpr int v = (decltype(U)::value + 1) % 3;     // ring slot of chunk it+1
+        f32x4 (&slot)[4] = *[&]() -> f32x4 (*)[4] {
+            if constexpr (v == 0) return &ra0;
+            else if constexpr (v == 1) return &ra1;
+            else return &ra2;
+        }();
+        float (&bslot)[NPAIR][2] = *[&]() -> float (*)[NPAIR][2] {
+            if constexpr (v == 0) return &rb0;
+            else if constexpr (v == 1) return &rb1;
+            else return &rb2;
+        }();
+        const int par = (int)(it & 1);
+        const float* abuf = As + (size_t)par * BMT * LDA;
+        const unsigned short* bbuf = Bt + (size_t)par * 3 * BPLANE;
+        __syncthreads();   // pair `par` complete; every wave is done reading the other pair (stage it-1)
+        const float* arow = &abuf[(wave * 32 + l31) * LDA + 8 * half];
+        const unsigned short* brow = bbuf + (size_t)l31 * KSB + 8 * half;
+#pragma unroll
+        for (int s2 = 0; s2 < BK / 16; ++s2) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(arow + 16 * s2);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(arow + 16 * s2 + 4);
+            const float f[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            float r1[8], r2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                r1[j] = f[j] - trunc_bf16(f[j]);
+                r2[j] = r1[j] - trunc_bf16(r1[j]);
+            }
+            const bf16x8_t ah = pack_trunc8(f), am = pack_trunc8(r1), al = pack_trunc8(r2);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const unsigned short* bp_ = brow + (size_t)(32 * nt) * KSB + 16 * s2;
+                const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(bp_);
+                const bf16x8_t bm = *reinterpret_cast<const bf16x8_t*>(bp_ + BPLANE);
+                const bf16x8_t bl = *reinterpret_cast<const bf16x8_t*>(bp_ + 2 * BPLANE);
+                f32x16 a_ = acc[nt];
+                a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, a_, 0, 0, 0);
+                a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, a_, 0, 0, 0);
+                a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, a_, 0, 0, 0);
+                a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, a_, 0, 0, 0);
+                a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, a_, 0, 0, 0);
+                a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, a_, 0, 0, 0);
+                acc[nt] = a_;
+            }
+        }
+        // chunk it+1 -> the other pair, then refill its ring slot with chunk it+4
+        store_b(Bt + (size_t)(par ^ 1) * 3 * BPLANE, bslot);
+        store_a(As + (size_t)(par ^ 1) * BMT * LDA, slot);
+        fetch_b(bslot);
+        fetch(slot);
+        if (cur.c == total - 1 && it < n_iter) {
+            const long rbase = cur.row0 + wave * 32 + 4 * half;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float* C = reinterpret_cast<float*>(col_ptr[nt]);
+                const float bias = col_bias[nt];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const long r = rbase + (i & 3) + 8 * (i >> 2);
+                    if (col_ok[nt] && r < P.M) C[(size_t)r * P.ldc] = acc[nt][i] + bias;
+                    acc[nt][i] = 0.f;
+                }
+            }
+        }
+        cur.next(chunks, total, row_step);
+    };
+    for (long base = 0; base < n_pad; base += PF) {
+        stage(std::integral_constant<int, 0>{}, base);
+        stage(std::integral_constant<int, 1>{}, base + 1);
+        stage(std::integral_constant<int, 2>{}, base + 2);
+    }
+}
+
+template <int NT, int NWV, bool KFAST>
+int launch_x3s(const TsGemmParams& P, int col_tiles, hipStream_t stream) {
+    constexpr int BMT = 32 * NWV;
+    const size_t lds = (size_t)2 * BMT * LDA * 4 + (size_t)2 * 3 * (32 * NT) * KSB * 2;
+    const long row_tiles = (P.M + BMT - 1) / BMT;
+    const void* kfn = (const void*)ts_gemm_x3s_kernel<NT, NWV, KFAST>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DSW_ERR_LAUNCH;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64 * NWV, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    long gx = 256L * per_cu / col_tiles;
+    if (gx < 1) gx = 1;
+    if (gx > row_tiles) gx = row_tiles;
+    if (col_tiles > 1 && gx >= 8) gx &= ~7L;   // column tiles of one row tile on one XCD (A re-reads hit its L2)
+    dim3 grid((unsigned)gx, (unsigned)col_tiles);
+    hipLaunchKernelGGL((ts_gemm_x3s_kernel<NT, NWV, KFAST>), grid, dim3(64 * NWV), lds, stream, P);
+    return dsw_check_launch();
+}
+
+}  // namespace
+
+// Streaming-W x3 GEMM: fp32 storage, aligned operands (kd_per_plane % 32 == 0, 16-byte A rows).  Returns 1 when it
+// took the launch (*rc = status).
+int dsw_ts_gemm_x3s_try_launch(const TsGemmParams& P, hipStream_t stream, int* rc) {
+    static const char* x3env = getenv("DSW_GEMM_X3");   // "0": exact fp32 MFMA kernels (diagnostics / A-B)
+    if (x3env && x3env[0] == '0') return 0;
+    static const char* senv = getenv("DSW_GEMM_X3S");   // "0": disable only the streaming variant
+    if (senv && senv[0] == '0') return 0;
+    if (!P.a_vec || P.kd_per_plane % BK != 0 || P.M <= 0) return 0;
+    const int n_total = P.n_planes_c * P.n_per_plane;
+    const bool kfast = P.b_skd == 1;
+    const int nt = n_total > 64 ? 4 : 2;
+    const int col_tiles = (n_total + 32 * nt - 1) / (32 * nt);
+    // 8-wave workgroups (256-row tiles) unless that leaves most CUs without work
+    static const char* nwvenv = getenv("DSW_X3S_NWV");
+    const bool small = nwvenv ? nwvenv[0] == '4' : ((P.M + 255) / 256) * col_tiles < 200;
+#define DSW_X3S(NT_, NWV_) (*rc = kfast ? launch_x3s<NT_, NWV_, true>(P, col_tiles, stream)   \
+                                        : launch_x3s<NT_, NWV_, false>(P, col_tiles, stream))
+    if (nt == 4) { if (small) DSW_X3S(4, 4); else DSW_X3S(4, 8); }
+    else { if (small) DSW_X3S(2, 4); else DSW_X3S(2, 8); }
+#undef DSW_X3S
+    return 1;
+}
