@@ -24,8 +24,7 @@ int dsw_ts_gemm_x3_try_launch(const TsGemmParams& P, int nt, int col_tiles, int 
 int dsw_ts_gemm_x3s_try_launch(const TsGemmParams& P, hipStream_t stream, int* rc);
 
 // wgrad on the bf16 matrix pipe (dsw_wgrad_x3.hip); returns 1 if it took the launch
-int dsw_wgrad_x3_try_launch(WgradParams& P, int nw, int groups, int otiles, int bf16, int64_t max_slabs, int64_t* S_out,
-                            hipStream_t stream, int* rc);
+int dsw_wgrad_x3_try_launch(WgradParams& P, int bf16, int64_t max_slabs, int64_t* S_out, hipStream_t stream, int* rc);
 
 namespace {
 
@@ -610,8 +609,8 @@ int dsw_wgrad_launch(const void* X, const void* T, const void* dY, void* dW, voi
         {   // bf16 matrix pipe (3-way split for fp32 storage) when the problem is aligned
             int rc3 = DSW_OK;
             int64_t S3 = 0;
-            if (aligned && dsw_wgrad_x3_try_launch(P, nw, groups, (int)otiles, dtype == DSW_BF16 ? 1 : 0,
-                                                   wgrad_max_slabs(Fin, Fout, K), &S3, stream, &rc3)) {
+            if (aligned && dsw_wgrad_x3_try_launch(P, dtype == DSW_BF16 ? 1 : 0, wgrad_max_slabs(Fin, Fout, K), &S3,
+                                                   stream, &rc3)) {
                 if (rc3 != DSW_OK) return rc3;
                 S = S3;
                 goto reduce;

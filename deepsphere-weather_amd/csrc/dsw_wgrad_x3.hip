@@ -1,14 +1,20 @@
 // wgrad on the bf16 matrix pipe:  partial[s][(k, f)][o] = sum_{n in slab s} T_k[n, f] * dY[n, o]
 //
-// Both MFMA operands of this contraction are "transposed": the reduction index n is the ROW index of
-// the row-major activations, while v_mfma_f32_32x32x16_bf16 wants 8 consecutive reduction elements per
-// lane.  So the staging pass does the transpose together with the precision split: every fp32 element
-// is split exactly into 3 bf16 terms (or, for bf16 storage, taken as is) and written to LDS as
-// [plane][channel][n] with n contiguous; operand fragments are then plain 8-byte LDS reads.  The split is
-// done once per element by the thread that staged it (the dY tile is shared by all waves of the
-// workgroup), the six leading cross terms accumulate in fp32 - same accuracy argument as dsw_gemm_x3.hip.
-// Structure otherwise as cheb_wgrad_kernel: NW waves = NW (k, f)-tiles of 32 rows x one 64-column o-tile,
-// row slabs -> fp32 partials -> cheb_wgrad_reduce_kernel (deterministic), 3-deep register prefetch ring.
+// Both MFMA operands of this contraction are "transposed": the reduction index n is the ROW index of the
+// row-major activations, while v_mfma_f32_32x32x16_bf16 wants 8 consecutive reduction elements per lane.
+// gfx950 has the instruction for exactly this: ds_read_b64_tr_b16 delivers, to lane l of a 16-lane group, column
+// (l & 15) of a [4 n][16 ch] bf16 block whose rows the group's lanes address 8 bytes each - a free 4x4 transpose
+// on the LDS read path.  So the staging pass keeps the NATURAL row-major layout: every fp32 element is split
+// exactly into 3 bf16 terms (or, for bf16 storage, taken as is), four channels are packed into one 8-byte LDS
+// write per plane, and the tile image is [plane][32 n][32 ch] with 64-byte rows (no padding: a 32-lane read
+// group then covers 4 rows x 64 B = all 64 banks exactly once).  An operand fragment is two transpose reads.
+// The six leading cross terms of the split accumulate in fp32 - same accuracy argument as dsw_gemm_x3.hip.
+//
+// Workgroup = NW waves; wave w owns the (k, f)-tile blockIdx.y * NW + w (32 channel rows of one T plane) times
+// NO 32-column blocks of dY (the workgroup's dY tile is shared by its waves).  NW up to 8 and NO = 4 for
+// Fout % 128 == 0 keep the re-reads of dY (once per workgroup row of the grid) and of T (once per column of the
+// grid) low for wide layers.  Row slabs -> fp32 partials -> cheb_wgrad_reduce_kernel (deterministic), 3-deep
+// register prefetch ring over 32-row chunks.
 #include "dsw_gemm_common.h"
 
 using namespace dsw_gemm;
@@ -17,8 +23,10 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int KSN = 36;   // bf16 elements per LDS row (32 n + 4 pad): 72-byte rows -> conflict-free b64 reads
+constexpr int BLK = 32 * 32;   // bf16 elements of one [32 n][32 ch] block (2 KiB, 64-byte rows)
 
 static __device__ __forceinline__ float trunc_bf16(float f) {
     return __uint_as_float(__float_as_uint(f) & 0xffff0000u);
@@ -37,43 +45,53 @@ static __device__ __forceinline__ f32x4 load4(const void* p, size_t i) {
     }
 }
 
-// split v into NSPLIT bf16 terms and scatter them to plane[p][(ch + j) * KSN + n], j = 0..3
+// truncating pack of 4 fp32 -> 4 bf16 (8 bytes)
+static __device__ __forceinline__ u32x2 pack4(const float a, const float b, const float c, const float d) {
+    u32x2 r;
+    r[0] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+    r[1] = __builtin_amdgcn_perm(__float_as_uint(d), __float_as_uint(c), 0x07060302u);
+    return r;
+}
+
+// split the 4 channels of v into NSPLIT bf16 terms and write them row-major: dst -> (row n, channel c) of plane 0
 template <int NSPLIT>
-static __device__ __forceinline__ void split_store(unsigned short* base, const int plane_elems, const int ch,
-                                                   const int n, const f32x4 v) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float x = v[j];
-        const float h = trunc_bf16(x);
-        unsigned short* dst = base + (size_t)(ch + j) * KSN + n;
-        dst[0] = (unsigned short)(__float_as_uint(h) >> 16);
-        if constexpr (NSPLIT == 3) {
-            const float r1 = x - h, m = trunc_bf16(r1), l = r1 - m;
-            dst[plane_elems] = (unsigned short)(__float_as_uint(m) >> 16);
-            dst[2 * plane_elems] = (unsigned short)(__float_as_uint(l) >> 16);
-        }
+static __device__ __forceinline__ void split_store(unsigned short* dst, const int plane_elems, const f32x4 v) {
+    const float h0 = trunc_bf16(v[0]), h1 = trunc_bf16(v[1]), h2 = trunc_bf16(v[2]), h3 = trunc_bf16(v[3]);
+    *reinterpret_cast<u32x2*>(dst) = pack4(h0, h1, h2, h3);
+    if constexpr (NSPLIT == 3) {
+        const float r0 = v[0] - h0, r1 = v[1] - h1, r2 = v[2] - h2, r3 = v[3] - h3;
+        const float m0 = trunc_bf16(r0), m1 = trunc_bf16(r1), m2 = trunc_bf16(r2), m3 = trunc_bf16(r3);
+        *reinterpret_cast<u32x2*>(dst + plane_elems) = pack4(m0, m1, m2, m3);
+        *reinterpret_cast<u32x2*>(dst + 2 * plane_elems) = pack4(r0 - m0, r1 - m1, r2 - m2, r3 - m3);
     }
 }
 
-static __device__ __forceinline__ bf16x8_t read_frag(const unsigned short* p) {
-    const u32x2 a = *reinterpret_cast<const u32x2*>(p);
-    const u32x2 b = *reinterpret_cast<const u32x2*>(p + 4);
-    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
-    const u32x4_ u = {a[0], a[1], b[0], b[1]};
-    return __builtin_bit_cast(bf16x8_t, u);
+// MFMA operand fragment (8 consecutive n of this lane's column) out of a [32 n][32 ch] block: two transpose reads
+// (rows +0..3 and +4..7 of the lane half's 8-row group).  `p` already carries the lane's offset (frag_off below).
+static __device__ __forceinline__ bf16x8_t read_frag_tr(const unsigned short* p) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * 32));
+    const s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8_t, r);
 }
 
-template <bool BF16IO, int NSPLIT, int NW>
+template <bool BF16IO, int NSPLIT, int NW, int NO>
 __global__ __launch_bounds__(64 * NW) void cheb_wgrad_x3_kernel(const WgradParams P) {
     constexpr int NT_ = 64 * NW;
-    constexpr int RD = (WR * BN / 4 + NT_ - 1) / NT_;   // float4 of the dY tile per thread
+    constexpr int BNO = 32 * NO;                        // dY columns of the workgroup
+    constexpr int CQ = BNO / 4;                         // column quads of the dY tile
+    constexpr int DV = WR * CQ;                         // float4 of the dY tile
+    constexpr int RD = (DV + NT_ - 1) / NT_;            // ... per thread
+    constexpr int G = NT_ / CQ;                         // threads sharing a column quad (NT_ % CQ == 0)
+    static_assert(NT_ % CQ == 0, "column-sum layout");
     constexpr int PF = 3;
-    constexpr int TPLANE = 32 * KSN;                    // one (wave, plane) T^T tile: [32 f][KSN]
-    constexpr int DPLANE = BN * KSN;                    // one dY^T plane: [64 o][KSN]
+    constexpr int TPLANE = BLK;                         // one (wave, plane) T tile
+    constexpr int DPLANE = NO * BLK;                    // one dY plane: NO blocks [32 n][32 o]
     extern __shared__ __attribute__((aligned(16))) unsigned short xs[];
-    unsigned short* TsT = xs;                                  // [NW][NSPLIT][32][KSN]
-    unsigned short* DsT = xs + (size_t)NW * NSPLIT * TPLANE;   // [NSPLIT][64][KSN]
-    float* red = reinterpret_cast<float*>(DsT + (size_t)NSPLIT * DPLANE);   // [NT_/16][64] column-sum scratch
+    unsigned short* TsT = xs;                                  // [NW][NSPLIT][32 n][32 f]
+    unsigned short* DsT = xs + (size_t)NW * NSPLIT * TPLANE;   // [NSPLIT][NO][32 n][32 o]
+    float* red = reinterpret_cast<float*>(DsT + (size_t)NSPLIT * DPLANE);   // [G][BNO] column-sum scratch
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -83,16 +101,18 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_x3_kernel(const WgradParam
     const bool active = tile < ntiles;
     const int k = active ? tile / P.tiles_per_plane : 0;
     const int f0 = active ? (tile - k * P.tiles_per_plane) * 32 : 0;
-    const int o0 = blockIdx.z * BN;
+    const int o0 = blockIdx.z * BNO;
     const int Kd = P.K * P.Fin;
     const long n_begin = (long)blockIdx.x * P.rows_per_slab;
     const long n_end = (n_begin + P.rows_per_slab < P.N) ? n_begin + P.rows_per_slab : P.N;
     const void* A = (k == 0) ? P.X : P.T;
     const size_t abase = (k == 0) ? 0 : (size_t)(k - 1) * P.plane_stride;
 
-    f32x16 acc0, acc1;
+    f32x16 acc[NO];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    for (int t = 0; t < NO; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     float cs[RD][4];
 #pragma unroll
     for (int i = 0; i < RD; ++i)
@@ -109,8 +129,8 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_x3_kernel(const WgradParam
 #pragma unroll
         for (int i = 0; i < RD; ++i) {
             int e = tid + NT_ * i;
-            if ((WR * BN / 4) % NT_ != 0) e = e < WR * BN / 4 ? e : WR * BN / 4 - 1;
-            drd[i] = load4<BF16IO>(P.dY, (size_t)(n0 + (e >> 4)) * P.Fout + o0 + (e & 15) * 4);
+            if (DV % NT_ != 0) e = e < DV ? e : DV - 1;
+            drd[i] = load4<BF16IO>(P.dY, (size_t)(n0 + e / CQ) * P.Fout + o0 + (e % CQ) * 4);
         }
     };
 
@@ -122,6 +142,11 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_x3_kernel(const WgradParam
     }
     const long n_pad = (n_chunks + PF - 1) / PF * PF;
 
+    // this lane's element offset inside a block for the transpose reads: row (i >> 2) of its [4 n] group, 8 rows
+    // further for the upper lane half, 8-byte chunk (i & 3) of the 16-column half (g & 1); i = lane & 15, g = lane >> 4
+    const int frag_off = (((lane & 15) >> 2) + 8 * half) * 32 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    unsigned short* tw = TsT + (size_t)wave * NSPLIT * TPLANE;
+
     auto stage = [&](auto U, const long ci) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value;
         f32x4 (&srt)[4] = *[&]() -> f32x4 (*)[4] {
@@ -130,16 +155,16 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_x3_kernel(const WgradParam
             if constexpr (u == 0) return &rd0; else if constexpr (u == 1) return &rd1; else return &rd2; }();
         __syncthreads();   // previous chunk's fragments fully consumed
         const bool live = ci < n_chunks;
-        // transpose + split into LDS
-        if (P.dbg != 3)
+        // split + row-major LDS image
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            split_store<NSPLIT>(TsT + (size_t)wave * NSPLIT * TPLANE, TPLANE, tc4, tr + 8 * i, srt[i]);
+            split_store<NSPLIT>(tw + (tr + 8 * i) * 32 + tc4, TPLANE, srt[i]);
 #pragma unroll
         for (int i = 0; i < RD; ++i) {
             const int e = tid + NT_ * i;
-            if (e < WR * BN / 4 && P.dbg != 3) {
-                split_store<NSPLIT>(DsT, DPLANE, (e & 15) * 4, e >> 4, srd[i]);
+            if (DV % NT_ == 0 || e < DV) {
+                const int n = e / CQ, c4 = (e % CQ) * 4;
+                split_store<NSPLIT>(DsT + (c4 >> 5) * BLK + n * 32 + (c4 & 31), DPLANE, srd[i]);
                 if (live && blockIdx.y == 0) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) cs[i][j] += srd[i][j];
@@ -147,36 +172,37 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_x3_kernel(const WgradParam
             }
         }
         __syncthreads();
-        if (P.dbg != 4) {
+        {
             const long nx = ci + PF;
             fetch(n_begin + (nx < n_chunks ? nx : n_chunks - 1) * WR, srt, srd);
         }
-        if (live && active && P.dbg != 2) {
-            const unsigned short* ta = TsT + (size_t)wave * NSPLIT * TPLANE + (size_t)l31 * KSN + 8 * half;
-            const unsigned short* db = DsT + (size_t)l31 * KSN + 8 * half;
+        if (live && active) {
+            const unsigned short* ta = tw + frag_off;
+            const unsigned short* db = DsT + frag_off;
 #pragma unroll
             for (int s2 = 0; s2 < WR / 16; ++s2) {
-                const bf16x8_t ah = read_frag(ta + 16 * s2);
-                const bf16x8_t b0h = read_frag(db + 16 * s2);
-                const bf16x8_t b1h = read_frag(db + (size_t)32 * KSN + 16 * s2);
+                const bf16x8_t ah = read_frag_tr(ta + 16 * s2 * 32);
+                bf16x8_t am = ah, al = ah;
                 if constexpr (NSPLIT == 3) {
-                    const bf16x8_t am = read_frag(ta + TPLANE + 16 * s2), al = read_frag(ta + 2 * TPLANE + 16 * s2);
-                    const bf16x8_t b0m = read_frag(db + DPLANE + 16 * s2), b0l = read_frag(db + 2 * DPLANE + 16 * s2);
-                    const bf16x8_t b1m = read_frag(db + DPLANE + (size_t)32 * KSN + 16 * s2);
-                    const bf16x8_t b1l = read_frag(db + 2 * DPLANE + (size_t)32 * KSN + 16 * s2);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0h, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b1h, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b0m, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b1m, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0l, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1l, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b0h, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b1h, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0m, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1m, acc1, 0, 0, 0);
+                    am = read_frag_tr(ta + TPLANE + 16 * s2 * 32);
+                    al = read_frag_tr(ta + 2 * TPLANE + 16 * s2 * 32);
                 }
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0h, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1h, acc1, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NO; ++t) {
+                    const unsigned short* bp = db + t * BLK + 16 * s2 * 32;
+                    const bf16x8_t bh = read_frag_tr(bp);
+                    f32x16 a_ = acc[t];
+                    if constexpr (NSPLIT == 3) {
+                        const bf16x8_t bm = read_frag_tr(bp + DPLANE), bl = read_frag_tr(bp + 2 * DPLANE);
+                        a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, a_, 0, 0, 0);
+                        a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, a_, 0, 0, 0);
+                        a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, a_, 0, 0, 0);
+                        a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, a_, 0, 0, 0);
+                        a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, a_, 0, 0, 0);
+                    }
+                    a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, a_, 0, 0, 0);
+                    acc[t] = a_;
+                }
             }
         }
     };
@@ -188,41 +214,47 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_x3_kernel(const WgradParam
 
     float* out = P.partial + (size_t)blockIdx.x * (size_t)(Kd + 1) * P.Fout;
     if (active) {
-        const int oA = o0 + l31, oB = o0 + 32 + l31;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int f = f0 + (i & 3) + 8 * (i >> 2) + 4 * half;
-            const size_t off = (size_t)(k * P.Fin + f) * P.Fout;
-            out[off + oA] = acc0[i];
-            out[off + oB] = acc1[i];
+        for (int t = 0; t < NO; ++t) {
+            const int o = o0 + 32 * t + l31;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int f = f0 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                out[(size_t)(k * P.Fin + f) * P.Fout + o] = acc[t][i];
+            }
         }
     }
     if (blockIdx.y == 0) {
-        // column sums of dY (db): thread e summed rows (e>>4) + multiples; combine the NT_/16 row groups
+        // column sums of dY (db).  Slot i of a thread is tile element tid + NT_*i; NT_ % CQ == 0, so all slots of a
+        // thread belong to the same column quad tid % CQ: add them up, then combine the G threads of a quad.
         __syncthreads();
-        constexpr int G = NT_ / 16;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float v = cs[0][j];
 #pragma unroll
-            for (int ii = 1; ii < RD; ++ii) v += cs[ii][j];   // same columns (NT_ % 16 == 0), other rows
-            red[(tid >> 4) * BN + (tid & 15) * 4 + j] = v;
+            for (int ii = 1; ii < RD; ++ii) v += cs[ii][j];
+            red[(tid / CQ) * BNO + (tid % CQ) * 4 + j] = v;
         }
         __syncthreads();
-        if (tid < BN) {
+        for (int c = tid; c < BNO; c += NT_) {
             float v = 0.f;
 #pragma unroll
-            for (int g = 0; g < G; ++g) v += red[g * BN + tid];
-            out[(size_t)Kd * P.Fout + o0 + tid] = v;
+            for (int g = 0; g < G; ++g) v += red[g * BNO + c];
+            out[(size_t)Kd * P.Fout + o0 + c] = v;
         }
     }
 }
 
-template <bool BF16IO, int NSPLIT, int NW>
+template <bool BF16IO, int NSPLIT, int NW, int NO>
 int launch_wx3(WgradParams& P, int groups, int otiles, int64_t max_slabs, int64_t* S_out, hipStream_t stream) {
     constexpr int NT_ = 64 * NW;
-    const size_t lds = ((size_t)NW * NSPLIT * 32 * KSN + (size_t)NSPLIT * BN * KSN) * 2 + (size_t)(NT_ / 16) * BN * 4;
-    const void* kfn = (const void*)cheb_wgrad_x3_kernel<BF16IO, NSPLIT, NW>;
+    constexpr int BNO = 32 * NO;
+    constexpr int G = NT_ / (BNO / 4);
+    const size_t lds = ((size_t)NW * NSPLIT * BLK + (size_t)NSPLIT * NO * BLK) * 2 + (size_t)G * BNO * 4;
+    const void* kfn = (const void*)cheb_wgrad_x3_kernel<BF16IO, NSPLIT, NW, NO>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DSW_ERR_LAUNCH;
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, NT_, lds) != hipSuccess || occ < 1) occ = 1;
     int64_t want = 256L * occ / ((int64_t)groups * otiles);
@@ -233,28 +265,40 @@ int launch_wx3(WgradParams& P, int groups, int otiles, int64_t max_slabs, int64_
     if (rps < 4 * WR) rps = 4 * WR;
     const int64_t S = (P.N + rps - 1) / rps;
     P.rows_per_slab = rps;
-    { static const char* d = getenv("DSW_DBG"); P.dbg = d ? atoi(d) : 0; }
     *S_out = S;
     dim3 grid((unsigned)S, (unsigned)groups, (unsigned)otiles);
-    hipLaunchKernelGGL((cheb_wgrad_x3_kernel<BF16IO, NSPLIT, NW>), grid, dim3(NT_), lds, stream, P);
+    hipLaunchKernelGGL((cheb_wgrad_x3_kernel<BF16IO, NSPLIT, NW, NO>), grid, dim3(NT_), lds, stream, P);
     return dsw_check_launch();
 }
 
 }  // namespace
 
 // Takes the launch (returns 1) for aligned problems: Fin % 32 == 0, Fout % 64 == 0, N % 32 == 0, 16-byte rows.
-int dsw_wgrad_x3_try_launch(WgradParams& P, int nw, int groups, int otiles, int bf16, int64_t max_slabs, int64_t* S_out,
-                            hipStream_t stream, int* rc) {
+// The (k, f)-tile / column tiling is chosen here: up to 8 waves per workgroup, 128 columns when Fout % 128 == 0.
+int dsw_wgrad_x3_try_launch(WgradParams& P, int bf16, int64_t max_slabs, int64_t* S_out, hipStream_t stream, int* rc) {
     static const char* x3env = getenv("DSW_GEMM_X3");   // "0": exact fp32 MFMA kernels (diagnostics / A-B)
     if (x3env && x3env[0] == '0') return 0;
+    const int ntiles = P.K * P.tiles_per_plane;
+    const int groups = (ntiles + 7) / 8;
+    const int nw = (ntiles + groups - 1) / groups;
+    const bool wide = P.Fout % 128 == 0 && nw >= 3;   // few waves: the 128-column dY tile would not fit their registers
+    const int otiles = wide ? P.Fout / 128 : P.Fout / 64;
 #define DSW_WX3(NW_)                                                                                              \
     case NW_:                                                                                                     \
-        *rc = bf16 ? launch_wx3<true, 1, NW_>(P, groups, otiles, max_slabs, S_out, stream)                         \
-                   : launch_wx3<false, 3, NW_>(P, groups, otiles, max_slabs, S_out, stream);                       \
+        *rc = bf16 ? (wide ? launch_wx3<true, 1, NW_, 4>(P, groups, otiles, max_slabs, S_out, stream)               \
+                           : launch_wx3<true, 1, NW_, 2>(P, groups, otiles, max_slabs, S_out, stream))              \
+                   : (wide ? launch_wx3<false, 3, NW_, 4>(P, groups, otiles, max_slabs, S_out, stream)              \
+                           : launch_wx3<false, 3, NW_, 2>(P, groups, otiles, max_slabs, S_out, stream));            \
+        return 1;
+#define DSW_WX3_NARROW(NW_)                                                                                       \
+    case NW_:                                                                                                     \
+        *rc = bf16 ? launch_wx3<true, 1, NW_, 2>(P, groups, otiles, max_slabs, S_out, stream)                       \
+                   : launch_wx3<false, 3, NW_, 2>(P, groups, otiles, max_slabs, S_out, stream);                     \
         return 1;
     switch (nw) {
-        DSW_WX3(1) DSW_WX3(2) DSW_WX3(3) DSW_WX3(4)
+        DSW_WX3_NARROW(1) DSW_WX3_NARROW(2) DSW_WX3(3) DSW_WX3(4) DSW_WX3(5) DSW_WX3(6) DSW_WX3(7) DSW_WX3(8)
     }
 #undef DSW_WX3
+#undef DSW_WX3_NARROW
     return 0;
 }
