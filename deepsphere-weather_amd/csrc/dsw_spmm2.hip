@@ -88,14 +88,15 @@ struct Hop2Args {
 };
 
 
-// acc += sum_j val[j] * buf[col[j]] over the first W entries of one ELL row (W even, padded with {own row, 0}).
+// acc += sum_j val[j] * buf[off[j]] over the first W entries {byte offset, value} of one ELL row (W even, padded
+// with {own row, 0}); bufc = staging buffer + this lane's byte offset inside a row.
 // The chain entry -> address -> data -> fma is a sequence of dependent LDS round trips, so entries are
 // read two per ds_read_b128 and 8 (then 4) data rows are requested back to back: two LDS latencies per
 // batch instead of two per non-zero.
 template <bool BF16>
 static __device__ __forceinline__ void gather_ell(const uint2* __restrict__ row_ent, const int W,
-                                                  const unsigned char* __restrict__ buf, const int row_bytes,
-                                                  const int cb, typename Row16<BF16>::V (&acc)[Row16<BF16>::N]) {
+                                                  const unsigned char* __restrict__ bufc,
+                                                  typename Row16<BF16>::V (&acc)[Row16<BF16>::N]) {
     using R = Row16<BF16>;
     using VT = typename R::V;
     constexpr int N = R::N;
@@ -108,8 +109,8 @@ static __device__ __forceinline__ void gather_ell(const uint2* __restrict__ row_
         for (int t = 0; t < 4; ++t) e[t] = e4[(j >> 1) + t];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            d[2 * t] = *reinterpret_cast<const uint4*>(buf + (size_t)e[t].x * row_bytes + cb);
-            d[2 * t + 1] = *reinterpret_cast<const uint4*>(buf + (size_t)e[t].z * row_bytes + cb);
+            d[2 * t] = *reinterpret_cast<const uint4*>(bufc + e[t].x);
+            d[2 * t + 1] = *reinterpret_cast<const uint4*>(bufc + e[t].z);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -126,10 +127,10 @@ static __device__ __forceinline__ void gather_ell(const uint2* __restrict__ row_
     }
     if (j + 4 <= W) {
         const uint4 ea = e4[j >> 1], eb = e4[(j >> 1) + 1];
-        const uint4 d0 = *reinterpret_cast<const uint4*>(buf + (size_t)ea.x * row_bytes + cb);
-        const uint4 d1 = *reinterpret_cast<const uint4*>(buf + (size_t)ea.z * row_bytes + cb);
-        const uint4 d2 = *reinterpret_cast<const uint4*>(buf + (size_t)eb.x * row_bytes + cb);
-        const uint4 d3 = *reinterpret_cast<const uint4*>(buf + (size_t)eb.z * row_bytes + cb);
+        const uint4 d0 = *reinterpret_cast<const uint4*>(bufc + ea.x);
+        const uint4 d1 = *reinterpret_cast<const uint4*>(bufc + ea.z);
+        const uint4 d2 = *reinterpret_cast<const uint4*>(bufc + eb.x);
+        const uint4 d3 = *reinterpret_cast<const uint4*>(bufc + eb.z);
         VT x0[N], x1[N], x2[N], x3[N];
         R::unpack(d0, x0); R::unpack(d1, x1); R::unpack(d2, x2); R::unpack(d3, x3);
         const VT v0 = R::splat(__uint_as_float(ea.y)), v1 = R::splat(__uint_as_float(ea.w));
@@ -145,8 +146,8 @@ static __device__ __forceinline__ void gather_ell(const uint2* __restrict__ row_
     }
     if (j < W) {   // W is even: one last pair
         const uint4 ea = e4[j >> 1];
-        const uint4 d0 = *reinterpret_cast<const uint4*>(buf + (size_t)ea.x * row_bytes + cb);
-        const uint4 d1 = *reinterpret_cast<const uint4*>(buf + (size_t)ea.z * row_bytes + cb);
+        const uint4 d0 = *reinterpret_cast<const uint4*>(bufc + ea.x);
+        const uint4 d1 = *reinterpret_cast<const uint4*>(bufc + ea.z);
         VT x0[N], x1[N];
         R::unpack(d0, x0); R::unpack(d1, x1);
         const VT v0 = R::splat(__uint_as_float(ea.y)), v1 = R::splat(__uint_as_float(ea.w));
@@ -208,8 +209,10 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
         const int p0 = P.lrowptr[rp_off + i], p1 = P.lrowptr[rp_off + i + 1];
         const int p = p0 + j;
         if (j == 0 && p1 - p0 > 2) atomicMax(tile_w, p1 - p0);
-        ell[t] = (p < p1) ? make_uint2((unsigned)P.lcol[nnz_off + p], __float_as_uint(P.lval[nnz_off + p]))
-                          : make_uint2((unsigned)i, 0u);     // padding: own row, weight 0
+        // entries hold the BYTE offset of the source row inside a staging buffer (one multiply less per gather)
+        ell[t] = (p < p1) ? make_uint2((unsigned)P.lcol[nnz_off + p] * (unsigned)P.row_bytes,
+                                       __float_as_uint(P.lval[nnz_off + p]))
+                          : make_uint2((unsigned)i * (unsigned)P.row_bytes, 0u);     // padding: own row, weight 0
     }
     __syncthreads();
 
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
                 VT acc[N];
 #pragma unroll
                 for (int j = 0; j < N; ++j) acc[j] = R::splat(0.f);
-                gather_ell<BF16>(ell + (size_t)i * W, Wt, bufX, P.row_bytes, cb, acc);
+                gather_ell<BF16>(ell + (size_t)i * W, Wt, bufX + cb, acc);
                 VT o[N];
 #pragma unroll
                 for (int j = 0; j < N; ++j) o[j] = R::splat(P.a1) * acc[j];
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
                 VT acc[N];
 #pragma unroll
                 for (int j = 0; j < N; ++j) acc[j] = R::splat(0.f);
-                gather_ell<BF16>(ell + (size_t)i * W, Wt, bufT, P.row_bytes, cb, acc);
+                gather_ell<BF16>(ell + (size_t)i * W, Wt, bufT + cb, acc);
                 VT u[N], o[N];
                 R::unpack(*reinterpret_cast<const uint4*>(bufX + (size_t)i * P.row_bytes + cb), u);
 #pragma unroll
