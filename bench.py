@@ -232,6 +232,7 @@ def main():
     rank, world, local = init_from_env()
     assert torch.cuda.is_available(), "bench.py measures the HIP path; a ROCm device is required"
     _native.load()
+    local = local % torch.cuda.device_count()   # (gloo smoke runs of the N>1 path put two ranks on one device)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     wl = WORKLOADS[args.workload]

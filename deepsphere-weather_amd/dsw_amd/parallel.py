@@ -25,8 +25,8 @@ def init_from_env(backend: str | None = None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:   # DSW_DIST_BACKEND=gloo: run the N>1 path of a GPU script on a single-GPU box (tests)
+            backend = os.environ.get("DSW_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
@@ -63,15 +63,25 @@ class FlatGradAllReduce:
     def __call__(self):
         if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
             return
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                v.zero_()
-            else:
-                v.copy_(p.grad)
-        dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
-        self.bucket.div_(dist.get_world_size(self.group))
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+        have = [p.grad is not None for p in self.params]
+        if all(have):
+            torch._foreach_copy_(self.views, [p.grad for p in self.params])   # one launch for the whole bucket
+        else:
+            for p, v in zip(self.params, self.views):
+                if p.grad is None:
+                    v.zero_()
+                else:
+                    v.copy_(p.grad)
+        if dist.get_backend(self.group) == "nccl":     # RCCL averages in the collective: no separate scale kernel
+            dist.all_reduce(self.bucket, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
+            self.bucket.div_(dist.get_world_size(self.group))
+        if all(have):
+            torch._foreach_copy_([p.grad for p in self.params], self.views)
+        else:
+            for p, v in zip(self.params, self.views):
+                if p.grad is None:
+                    p.grad = v.clone()
+                else:
+                    p.grad.copy_(v)
