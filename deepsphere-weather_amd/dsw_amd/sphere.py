@@ -165,6 +165,8 @@ def knn_graph_laplacian(coords: np.ndarray, k: int, lap_type: str = "normalized"
     and irregular where the sampling is anisotropic, e.g. equiangular poles).
     """
     n = coords.shape[0]
+    if k >= n:
+        raise ValueError(f"a {k}-nearest-neighbour graph needs more than {k} vertices (the sampling has {n})")
     tree = cKDTree(coords)
     dist, idx = tree.query(coords, k=k + 1)
     dist = dist[:, 1:]
