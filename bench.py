@@ -39,6 +39,9 @@ WORKLOADS = {
     "ns": dict(nside=64, K=3, fin=32, fout=64, batch=16, dtype="f32"),
     "c3": dict(nside=64, K=5, fin=64, fout=128, batch=16, dtype="bf16"),
     "unet": dict(nside=32, K=3, fin=18, fout=2, batch=8, dtype="f32"),
+    # BASELINE configs[4]: equiangular 200 x 400 (V = 80 000, irregular degree at the poles), k = 20, K = 3, 32 ch,
+    # interpolation pooling to the HEALPix nside=32 sampling and back (pooling BETWEEN samplings)
+    "c5": dict(nside=0, nlat=200, nlon=400, K=3, fin=32, fout=32, batch=8, dtype="f32"),
 }
 
 
@@ -63,6 +66,30 @@ def make_layer(wl, knn, device, dtype):
     torch.manual_seed(10)  # seed_model_weights of the reference configs
     layer = ConvCheb(wl["fin"], wl["fout"], wl["K"], laplacian=lap, bias=True)
     return layer.to(device).to(dtype), lap
+
+
+class _C5Block(torch.nn.Module):
+    """ConvCheb on the equiangular graph -> interp-pool to a HEALPix sampling -> ConvCheb there -> unpool back."""
+
+    def __init__(self, wl):
+        super().__init__()
+        from dsw_amd import sphere
+        from modules.layers import ConvCheb, GeneralAvgPool, GeneralAvgUnpool, prepare_torch_laplacian
+
+        fine = sphere.SphereEquiangular(nlat=wl["nlat"], nlon=wl["nlon"], k=20)
+        coarse = sphere.SphereHealpix(32, nest=True, k=20)
+        pool_m, unpool_m = sphere.knn_interp_pool_matrices(fine.coords, coarse.coords, k=9)
+        torch.manual_seed(10)
+        self.conv_fine = ConvCheb(wl["fin"], wl["fout"], wl["K"], laplacian=prepare_torch_laplacian(fine.L, lmax=1.95))
+        self.pool = GeneralAvgPool(pool_m)
+        self.conv_coarse = ConvCheb(wl["fout"], wl["fout"], wl["K"],
+                                    laplacian=prepare_torch_laplacian(coarse.L, lmax=1.95))
+        self.unpool = GeneralAvgUnpool(unpool_m)
+
+    def forward(self, x):
+        y = self.conv_fine(x)
+        z, idx = self.pool(y)
+        return y + self.unpool(self.conv_coarse(z), idx)
 
 
 def make_unet(wl, knn, device):
@@ -237,7 +264,7 @@ def main():
     device = torch.device("cuda", local)
     wl = WORKLOADS[args.workload]
     dtype = torch.bfloat16 if wl["dtype"] == "bf16" else torch.float32
-    V = 12 * wl["nside"] ** 2
+    V = wl["nlat"] * wl["nlon"] if args.workload == "c5" else 12 * wl["nside"] ** 2
     B = wl["batch"]
     torch.manual_seed(1234 + rank)
 
@@ -252,7 +279,10 @@ def main():
             loss = ((model(x) - target) ** 2).mean()
             loss.backward()
     else:
-        model, lap = make_layer(wl, args.knn, device, dtype)
+        if args.workload == "c5":
+            model, lap = _C5Block(wl).to(device), None
+        else:
+            model, lap = make_layer(wl, args.knn, device, dtype)
         x = torch.randn(B, V, wl["fin"], device=device, dtype=dtype).requires_grad_(True)
         gy = torch.randn(B, V, wl["fout"], device=device, dtype=dtype)
 
@@ -299,13 +329,14 @@ def main():
                 "ns": "single ConvCheb layer, HEALPix nside=64 nested (V=49152), K=3, 32->64 ch, B=16/GPU, fp32 (north-star shape)",
                 "c3": "single ConvCheb layer, HEALPix nside=64 nested, K=5, 64->128 ch, B=16/GPU, bf16 storage + fp32 accumulate",
                 "unet": "UNetSpherical, HEALPix nside=32 nested, K=3, B=8/GPU, fp32, interp pooling (11 ConvCheb + 4 RemapBlock)",
+                "c5": "equiangular 200x400 (V=80000, k=20, irregular degree) ConvCheb K=3 32ch + interp pooling to HEALPix nside=32 and back, B=8/GPU, fp32",
             }[args.workload],
-            "knn": args.knn if args.workload != "unet" else (args.knn if args.knn != 8 else 20),
+            "knn": 20 if args.workload == "c5" else args.knn if args.workload != "unet" else (args.knn if args.knn != 8 else 20),
             "batch_per_gpu": B, "global_batch": B * world, "nodes": V,
             "parallelism": "dp%d (batch shards, flat-bucket RCCL grad all-reduce)" % world,
         },
     }
-    if rank == 0 and world == 1 and args.workload != "unet":
+    if rank == 0 and world == 1 and args.workload not in ("unet", "c5"):
         if not args.no_roofline:
             out["roofline"] = roofline_leg(model, x.detach(), max(10, args.steps), 5)
         if not args.no_cpu_baseline:

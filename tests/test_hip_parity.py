@@ -457,3 +457,43 @@ def test_config_driven_training_driver(tmp_path):
                        "--ar_iterations", "1"])
     assert all(np.isfinite(losses))
     assert losses[-1] < losses[0]
+
+
+def test_equiangular_conv_and_cross_sampling_pooling():
+    """BASELINE configs[4] in small: equiangular 24 x 48 k-NN Laplacian (irregular degree at the poles), K = 3,
+    32 channels, interpolation pooling to a HEALPix sampling and back - every piece against the fp64 oracle."""
+    from dsw_amd import sphere
+    from modules.layers import ConvCheb, GeneralAvgPool, GeneralAvgUnpool, prepare_torch_laplacian
+    from scipy import sparse
+
+    fine = sphere.SphereEquiangular(nlat=24, nlon=48, k=20)
+    coarse = sphere.SphereHealpix(4, nest=True, k=8)
+    deg = np.diff(fine.L.tocsr().indptr)
+    assert deg.max() > deg.min()                       # the stress: rows of different length
+    pool_m, unpool_m = sphere.knn_interp_pool_matrices(fine.coords, coarse.coords, k=9)
+    lap = prepare_torch_laplacian(fine.L, lmax=1.95)
+    torch.manual_seed(5)
+    conv = ConvCheb(32, 32, 3, laplacian=lap).to(DEV)
+    with torch.no_grad():
+        conv.bias.normal_(0, 0.1)
+    pool, unpool = GeneralAvgPool(pool_m).to(DEV), GeneralAvgUnpool(unpool_m).to(DEV)
+    V = fine.n_vertices
+    x = torch.randn(3, V, 32, device=DEV, requires_grad=True)
+    y = conv(x)
+    z, idx = pool(y)
+    out = unpool(z, idx)
+    gy = torch.randn_like(out)
+    out.backward(gy)
+    rp, ci, va = orc.csr_arrays_from_coo(conv.laplacian.cpu())
+    xn, wn, bn = (t.detach().cpu().numpy() for t in (x, conv.weight, conv.bias))
+    y64 = orc.cheb_forward_f64(rp, ci, va, xn, wn, bn)
+    P = sparse.csr_matrix(pool_m).astype(np.float32).astype(np.float64)
+    U = sparse.csr_matrix(unpool_m).astype(np.float32).astype(np.float64)
+    out64 = np.stack([U @ (P @ y64[b]) for b in range(3)])
+    assert orc.max_rel_err(y, y64) <= TOL_F64
+    assert orc.max_rel_err(out, out64) <= TOL_F64
+    g_y64 = np.stack([P.T @ (U.T @ gy[b].double().cpu().numpy()) for b in range(3)])
+    dx64, dw64, db64 = orc.cheb_backward_f64(rp, ci, va, xn, wn, g_y64, True)
+    assert orc.max_rel_err(x.grad, dx64) <= TOL_F64
+    assert orc.max_rel_err(conv.weight.grad, dw64) <= 2 * TOL_F64
+    assert orc.max_rel_err(conv.bias.grad, db64) <= 2 * TOL_F64
