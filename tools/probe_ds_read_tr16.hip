@@ -1,3 +1,5 @@
+// Probe of gfx950 ds_read_b64_tr_b16 lane semantics (used to design dsw_wgrad_x3.hip).
+// build+run on the GPU box: hipcc --offload-arch=gfx950 -O2 -o /tmp/tr_probe tools/probe_ds_read_tr16.hip && /tmp/tr_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef short s4 __attribute__((ext_vector_type(4)));
