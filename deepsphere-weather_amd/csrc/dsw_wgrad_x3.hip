@@ -245,6 +245,181 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_x3_kernel(const WgradParam
     }
 }
 
+
+// bf16 storage: the operands ARE bf16, so the tile image is a raw copy - 64-row chunks (the same bytes per chunk
+// and 16 B per lane as the fp32 path), ds_write_b128 staging, one MFMA term.  Same tiling / slabs / ring otherwise.
+template <int NW, int NO>
+__global__ __launch_bounds__(64 * NW) void cheb_wgrad_bf16_kernel(const WgradParams P) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int NT_ = 64 * NW;
+    constexpr int BNO = 32 * NO;
+    constexpr int WRB = 64;                             // rows per chunk
+    constexpr int CO = BNO / 8;                         // column octets (16-byte vectors) per dY row
+    constexpr int DV = WRB * CO;
+    constexpr int RD = (DV + NT_ - 1) / NT_;
+    constexpr int G = NT_ / CO;
+    static_assert(NT_ % CO == 0, "column-sum layout");
+    constexpr int PF = 3;
+    constexpr int BLKB = WRB * 32;                      // one [64 n][32 ch] block (4 KiB)
+    extern __shared__ __attribute__((aligned(16))) unsigned short xs[];
+    unsigned short* TsT = xs;                           // [NW][64 n][32 f]
+    unsigned short* DsT = xs + (size_t)NW * BLKB;       // [NO][64 n][32 o]
+    float* red = reinterpret_cast<float*>(DsT + (size_t)NO * BLKB);   // [G][BNO]
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int tile = blockIdx.y * NW + wave;
+    const int ntiles = P.K * P.tiles_per_plane;
+    const bool active = tile < ntiles;
+    const int k = active ? tile / P.tiles_per_plane : 0;
+    const int f0 = active ? (tile - k * P.tiles_per_plane) * 32 : 0;
+    const int o0 = blockIdx.z * BNO;
+    const int Kd = P.K * P.Fin;
+    const long n_begin = (long)blockIdx.x * P.rows_per_slab;
+    const long n_end = (n_begin + P.rows_per_slab < P.N) ? n_begin + P.rows_per_slab : P.N;
+    const uint16_t* A = static_cast<const uint16_t*>((k == 0) ? P.X : P.T) + ((k == 0) ? 0 : (size_t)(k - 1) * P.plane_stride);
+    const uint16_t* dY = static_cast<const uint16_t*>(P.dY);
+
+    f32x16 acc[NO];
+#pragma unroll
+    for (int t = 0; t < NO; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    float cs[RD][8];
+#pragma unroll
+    for (int i = 0; i < RD; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs[i][j] = 0.f;
+
+    const int tr = lane >> 2, tc8 = (lane & 3) * 8;   // T tile (per wave): rows tr + 16*i (i<4), channels tc8..+7
+    u32x4 rt0[4], rt1[4], rt2[4], rd0[RD], rd1[RD], rd2[RD];
+    auto fetch = [&](long n0, u32x4 (&drt)[4], u32x4 (&drd)[RD]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            drt[i] = *reinterpret_cast<const u32x4*>(A + (size_t)(n0 + tr + 16 * i) * P.Fin + f0 + tc8);
+#pragma unroll
+        for (int i = 0; i < RD; ++i) {
+            int e = tid + NT_ * i;
+            if (DV % NT_ != 0) e = e < DV ? e : DV - 1;
+            drd[i] = *reinterpret_cast<const u32x4*>(dY + (size_t)(n0 + e / CO) * P.Fout + o0 + (e % CO) * 8);
+        }
+    };
+    const long n_chunks = (n_end - n_begin) / WRB;
+    if (n_chunks > 0) {
+        fetch(n_begin, rt0, rd0);
+        fetch(n_begin + (1 < n_chunks ? 1 : n_chunks - 1) * WRB, rt1, rd1);
+        fetch(n_begin + (2 < n_chunks ? 2 : n_chunks - 1) * WRB, rt2, rd2);
+    }
+    const long n_pad = (n_chunks + PF - 1) / PF * PF;
+    const int frag_off = (((lane & 15) >> 2) + 8 * half) * 32 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    unsigned short* tw = TsT + (size_t)wave * BLKB;
+
+    auto stage = [&](auto U, const long ci) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value;
+        u32x4 (&srt)[4] = *[&]() -> u32x4 (*)[4] {
+            if constexpr (u == 0) return &rt0; else if constexpr (u == 1) return &rt1; else return &rt2; }();
+        u32x4 (&srd)[RD] = *[&]() -> u32x4 (*)[RD] {
+            if constexpr (u == 0) return &rd0; else if constexpr (u == 1) return &rd1; else return &rd2; }();
+        __syncthreads();
+        const bool live = ci < n_chunks;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(tw + (tr + 16 * i) * 32 + tc8) = srt[i];
+#pragma unroll
+        for (int i = 0; i < RD; ++i) {
+            const int e = tid + NT_ * i;
+            if (DV % NT_ == 0 || e < DV) {
+                const int n = e / CO, c8 = (e % CO) * 8;
+                *reinterpret_cast<u32x4*>(DsT + (c8 >> 5) * BLKB + n * 32 + (c8 & 31)) = srd[i];
+                if (live && blockIdx.y == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        cs[i][2 * j] += __uint_as_float(srd[i][j] << 16);
+                        cs[i][2 * j + 1] += __uint_as_float(srd[i][j] & 0xffff0000u);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const long nx = ci + PF;
+            fetch(n_begin + (nx < n_chunks ? nx : n_chunks - 1) * WRB, srt, srd);
+        }
+        if (live && active) {
+            const unsigned short* ta = tw + frag_off;
+            const unsigned short* db = DsT + frag_off;
+#pragma unroll
+            for (int s2 = 0; s2 < WRB / 16; ++s2) {
+                const bf16x8_t a = read_frag_tr(ta + 16 * s2 * 32);
+#pragma unroll
+                for (int t = 0; t < NO; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, read_frag_tr(db + t * BLKB + 16 * s2 * 32), acc[t], 0, 0, 0);
+            }
+        }
+    };
+    for (long cb = 0; cb < n_pad; cb += PF) {
+        stage(std::integral_constant<int, 0>{}, cb);
+        stage(std::integral_constant<int, 1>{}, cb + 1);
+        stage(std::integral_constant<int, 2>{}, cb + 2);
+    }
+
+    float* out = P.partial + (size_t)blockIdx.x * (size_t)(Kd + 1) * P.Fout;
+    if (active) {
+#pragma unroll
+        for (int t = 0; t < NO; ++t) {
+            const int o = o0 + 32 * t + l31;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int f = f0 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                out[(size_t)(k * P.Fin + f) * P.Fout + o] = acc[t][i];
+            }
+        }
+    }
+    if (blockIdx.y == 0) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = cs[0][j];
+#pragma unroll
+            for (int ii = 1; ii < RD; ++ii) v += cs[ii][j];
+            red[(tid / CO) * BNO + (tid % CO) * 8 + j] = v;
+        }
+        __syncthreads();
+        for (int c = tid; c < BNO; c += NT_) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < G; ++g) v += red[g * BNO + c];
+            out[(size_t)Kd * P.Fout + o0 + c] = v;
+        }
+    }
+}
+
+template <int NW, int NO>
+int launch_wbf16(WgradParams& P, int groups, int otiles, int64_t max_slabs, int64_t* S_out, hipStream_t stream) {
+    constexpr int NT_ = 64 * NW;
+    constexpr int BNO = 32 * NO;
+    constexpr int G = NT_ / (BNO / 8);
+    const size_t lds = ((size_t)NW + NO) * 64 * 32 * 2 + (size_t)G * BNO * 4;
+    const void* kfn = (const void*)cheb_wgrad_bf16_kernel<NW, NO>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DSW_ERR_LAUNCH;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, NT_, lds) != hipSuccess || occ < 1) occ = 1;
+    int64_t want = 256L * occ / ((int64_t)groups * otiles);
+    if (want < 32) want = 32;
+    if (want > max_slabs) want = max_slabs;
+    int64_t rps = (P.N + want - 1) / want;
+    rps = ((rps + 63) / 64) * 64;
+    if (rps < 256) rps = 256;
+    const int64_t S = (P.N + rps - 1) / rps;
+    P.rows_per_slab = rps;
+    *S_out = S;
+    dim3 grid((unsigned)S, (unsigned)groups, (unsigned)otiles);
+    hipLaunchKernelGGL((cheb_wgrad_bf16_kernel<NW, NO>), grid, dim3(NT_), lds, stream, P);
+    return dsw_check_launch();
+}
+
 template <bool BF16IO, int NSPLIT, int NW, int NO>
 int launch_wx3(WgradParams& P, int groups, int otiles, int64_t max_slabs, int64_t* S_out, hipStream_t stream) {
     constexpr int NT_ = 64 * NW;
@@ -283,6 +458,20 @@ int dsw_wgrad_x3_try_launch(WgradParams& P, int bf16, int64_t max_slabs, int64_t
     const int nw = (ntiles + groups - 1) / groups;
     const bool wide = P.Fout % 128 == 0 && nw >= 3;   // few waves: the 128-column dY tile would not fit their registers
     const int otiles = wide ? P.Fout / 128 : P.Fout / 64;
+    // bf16 storage, whole 64-row chunks, 16-byte aligned 8-channel groups: raw-copy staging kernel
+    const bool raw = bf16 && P.N % 64 == 0 && P.Fin % 8 == 0 && P.Fout % 8 == 0 && dsw_aligned16(P.X) &&
+                     (P.K == 1 || dsw_aligned16(P.T)) && dsw_aligned16(P.dY) && P.plane_stride % 8 == 0;
+    if (raw) {
+#define DSW_WB(NW_)                                                                                               \
+    case NW_:                                                                                                     \
+        *rc = wide ? launch_wbf16<NW_, 4>(P, groups, otiles, max_slabs, S_out, stream)                              \
+                   : launch_wbf16<NW_, 2>(P, groups, otiles, max_slabs, S_out, stream);                             \
+        return 1;
+        switch (nw) {
+            DSW_WB(1) DSW_WB(2) DSW_WB(3) DSW_WB(4) DSW_WB(5) DSW_WB(6) DSW_WB(7) DSW_WB(8)
+        }
+#undef DSW_WB
+    }
 #define DSW_WX3(NW_)                                                                                              \
     case NW_:                                                                                                     \
         *rc = bf16 ? (wide ? launch_wx3<true, 1, NW_, 4>(P, groups, otiles, max_slabs, S_out, stream)               \
