@@ -126,7 +126,7 @@ def _native_lib():
     return _native.load()
 
 
-def roofline_leg(layer, x, steps, warmup):
+def roofline_leg(layer, x, steps, warmup, traffic_key=None):
     """Time exactly the SpMM launches of one fwd+bwd (K-1 basis hops + K-1 adjoint hops)."""
     from dsw_amd import functional as F_
 
@@ -185,11 +185,11 @@ def roofline_leg(layer, x, steps, warmup):
     t1.record(stream)
     torch.cuda.synchronize()
     fwd_s = t0.elapsed_time(t1) * 1e-3 / steps
-    traffic = None
+    traffic = None   # HBM bytes per launch from the PMC passes (tools/prof_pmc.sh + tools/make_traffic_json.py)
     tpath = os.path.join(REPO, "profiles", "spmm_traffic.json")
-    if os.path.exists(tpath):
+    if traffic_key and os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tpath)).get(traffic_key, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     return {
@@ -338,7 +338,8 @@ def main():
     }
     if rank == 0 and world == 1 and args.workload not in ("unet", "c5"):
         if not args.no_roofline:
-            out["roofline"] = roofline_leg(model, x.detach(), max(10, args.steps), 5)
+            out["roofline"] = roofline_leg(model, x.detach(), max(10, args.steps), 5,
+                                           traffic_key=args.workload if args.knn == 8 else None)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(wl, lap, model)
     if rank == 0:

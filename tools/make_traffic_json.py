@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Turn the FETCH_SIZE / WRITE_SIZE passes of tools/prof_pmc.sh into profiles/spmm_traffic.json.
+
+usage: tools/make_traffic_json.py <workload key> <tag> [<workload key> <tag> ...]
+Reads gpurun_out/pmc_<tag>_{A,B}/**/*counter_collection.csv.  HBM bytes per dispatch of the SpMM recurrence
+kernels = (2 * FETCH_SIZE + WRITE_SIZE) KiB: FETCH_SIZE reports half of wide (16 B/lane) coalesced reads on gfx950
+(MI355X_MICROARCH.md, HBM section), WRITE_SIZE is exact.  The per-launch figure bench.py reports next to the
+algorithmic bytes is the mean over the SpMM launches of one step (forward recurrence + adjoint recurrence)."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out_path = os.path.join(ROOT, "profiles", "spmm_traffic.json")
+result = json.load(open(out_path)) if os.path.exists(out_path) else {}
+if "hbm_bytes_per_launch" in result:      # old single-workload layout
+    result = {}
+args = sys.argv[1:]
+for key, tag in zip(args[0::2], args[1::2]):
+    vals = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(f"{ROOT}/gpurun_out/pmc_{tag}_[AB]/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            m = re.search(r"(spmm2_fused_kernel<[^>]*>|spmm_csr_rowsplit<[^>]*>)", r["Kernel_Name"])
+            if m and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                vals[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    kernels, total, launches = {}, 0.0, 0
+    for name, d in sorted(vals.items()):
+        if not d["FETCH_SIZE"] or not d["WRITE_SIZE"]:
+            continue
+        rd = 2.0 * 1024 * sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"])
+        wr = 1024.0 * sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
+        n = len(d["WRITE_SIZE"])
+        kernels[name] = {"read": round(rd), "write": round(wr), "dispatches_sampled": n}
+        total += (rd + wr) * n
+        launches += n
+    if launches:
+        result[key] = {"hbm_bytes_per_launch": round(total / launches), "kernels": kernels,
+                       "source": f"tools/prof_pmc.sh {tag} (passes A: FETCH_SIZE x2, B: WRITE_SIZE), dispatch-weighted mean"}
+json.dump(result, open(out_path, "w"), indent=1)
+print(json.dumps(result, indent=1))
