@@ -44,8 +44,8 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
     constexpr int NTH = 64 * NWV;
     constexpr int BNT = 32 * NT;
     constexpr int PF = 3;
-    constexpr int NPAIR = (16 * BNT) / NTH;            // (k, k+1) element pairs of one W chunk per thread
-    static_assert((16 * BNT) % NTH == 0, "W chunk must divide over the threads");
+    constexpr int NPAIR = (16 * BNT + NTH - 1) / NTH;  // (k, k+1) element pairs of one W chunk per thread
+    constexpr bool BTAIL = (16 * BNT) % NTH != 0;      // last slot only partly populated (6- and 7-wave workgroups)
     constexpr int BPLANE = BNT * KSB;                  // one bf16 plane of one B buffer
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                                                               // [2][BMT][LDA]
@@ -86,10 +86,12 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
     long bslot_g[NPAIR];      // element offset of W(k = 2*kp, col) relative to the chunk origin; < 0: column out of range
 #pragma unroll
     for (int i = 0; i < NPAIR; ++i) {
-        const int e = tid + NTH * i;
+        int e = tid + NTH * i;
+        const bool slot_ok = !BTAIL || e < 16 * BNT;
+        if (!slot_ok) e = 16 * BNT - 1;
         const int col = KFAST ? e >> 4 : e % BNT;
         const int kp = KFAST ? e & 15 : e / BNT;
-        bslot_lds[i] = col * KSB + 2 * kp;
+        bslot_lds[i] = slot_ok ? col * KSB + 2 * kp : -1;
         const int j = col0 + col;
         if (j < n_total) {
             const int q = j / P.n_per_plane, n = j - q * P.n_per_plane;
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
             const float a1 = a - ah, b1 = b - bh;
             const float am = trunc_bf16(a1), bm = trunc_bf16(b1);
             const float al = a1 - am, bl = b1 - bm;
+            if (BTAIL && bslot_lds[i] < 0) continue;
             uint32_t* dst = reinterpret_cast<uint32_t*>(buf + bslot_lds[i]);
             dst[0] = __builtin_amdgcn_perm(__float_as_uint(bh), __float_as_uint(ah), 0x07060302u);
             dst[BPLANE / 2] = __builtin_amdgcn_perm(__float_as_uint(bm), __float_as_uint(am), 0x07060302u);
@@ -274,13 +277,18 @@ int dsw_ts_gemm_x3s_try_launch(const TsGemmParams& P, hipStream_t stream, int* r
     const bool kfast = P.b_skd == 1;
     const int nt = n_total > 64 ? 4 : 2;
     const int col_tiles = (n_total + 32 * nt - 1) / (32 * nt);
-    // 8-wave workgroups (256-row tiles) unless that leaves most CUs without work
+    // waves per workgroup (tile rows = 32 * waves).  Measured over the UNet shapes: a chunk step costs about the same
+    // for 4..8 waves (it is latency- not throughput-bound), so the 256-row tile wins whenever it still gives at
+    // least half of the CUs a workgroup; tiny grids (nside=8 levels) take 128-row tiles to spread over more CUs.
     static const char* nwvenv = getenv("DSW_X3S_NWV");
-    const bool small = nwvenv ? nwvenv[0] == '4' : ((P.M + 255) / 256) * col_tiles < 200;
+    const long tiles8 = ((P.M + 255) / 256) * col_tiles;
+    const int nwv = nwvenv ? atoi(nwvenv) : (tiles8 < 128 ? 4 : 8);
 #define DSW_X3S(NT_, NWV_) (*rc = kfast ? launch_x3s<NT_, NWV_, true>(P, col_tiles, stream)   \
                                         : launch_x3s<NT_, NWV_, false>(P, col_tiles, stream))
-    if (nt == 4) { if (small) DSW_X3S(4, 4); else DSW_X3S(4, 8); }
-    else { if (small) DSW_X3S(2, 4); else DSW_X3S(2, 8); }
+#define DSW_X3S_NWV(NT_)                                                                     \
+    if (nwv == 4) DSW_X3S(NT_, 4); else DSW_X3S(NT_, 8);
+    if (nt == 4) { DSW_X3S_NWV(4) } else { DSW_X3S_NWV(2) }
+#undef DSW_X3S_NWV
 #undef DSW_X3S
     return 1;
 }
