@@ -20,9 +20,29 @@ int dsw_spmm2_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const 
                      float a2, float b2, float c2, int dtype, hipStream_t stream);
 int dsw_wgrad_launch(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
                      int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream);
+int dsw_wgrad_launch_ex(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
+                        int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
+                        int64_t K_out, int64_t k_off);
+int dsw_zmix_launch(const void* X, const void* W, const void* bias, void* Z0, void* Zrest, int64_t N, int64_t Fin,
+                    int64_t Fout, int64_t K, int dtype, hipStream_t stream);
+int dsw_zdgrad_launch(const void* dY, const void* D, const void* W, void* dX, int64_t N, int64_t Fin, int64_t Fout,
+                      int64_t K, int dtype, hipStream_t stream);
 
 static inline int64_t elem_size(int dtype) { return dtype == DSW_BF16 ? 2 : 4; }
 static inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// Evaluation order of the layer.  Y = sum_k T_k(L) X W_k can run the recurrence on the Fin channels of X and mix
+// afterwards (basis-first), or mix first (Z_k = X W_k) and run the Clenshaw-form recurrence
+// c_{K-1} = Z_{K-1}, c_j = a_j L c_{j+1} + Z_j - c_{j+2} (a_j = 2, a_0 = 1), Y = c_0 on the Fout channels.
+// Same result (association differs: fp32 rounding only), same GEMM flops; the SpMM hops - the HBM/gather-bound
+// part - scale with the channel count they run on, so layers that shrink the channel count (the decoder half of the
+// UNet, 64 -> 2 output layer) take the mix-first order.  Its backward is the dual: Chebyshev basis of dY under L^T,
+// dX = sum_k D_k W_k^T, dW_k = X^T D_k - and needs nothing saved from the forward except X.
+static bool mix_first(int64_t Fin, int64_t Fout, int64_t K) {
+    static const char* env = getenv("DSW_MIX_FIRST");   // "0": always basis-first (diagnostics / A-B)
+    if (env && env[0] == '0') return false;
+    return K >= 2 && 2 * Fout <= Fin;
+}
 
 extern "C" {
 
@@ -149,11 +169,27 @@ int dsw_cheb_mix_fwd(const void* X, const void* T, const void* W, const void* bi
     return dsw_mix_fwd_launch(X, T, W, bias, Y, N, Fin, Fout, K, dtype, (hipStream_t)stream);
 }
 
+int dsw_cheb_mix_first(int64_t Fin, int64_t Fout, int64_t K) { return mix_first(Fin, Fout, K) ? 1 : 0; }
+
 int dsw_cheb_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V, int64_t nnz,
                  const void* X, const void* W, const void* bias, void* Y, void* T, int64_t B, int64_t Fin,
                  int64_t Fout, int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan) {
     if (K <= 0) return DSW_ERR_BAD_ARG;
     int rc = DSW_OK;
+    if (mix_first(Fin, Fout, K)) {
+        // T is scratch here: (K-1) planes of [N, Fin] hold the K-1 (+2 spare for K >= 4) planes of [N, Fout]
+        if (B < 0 || V < 0 || Fin <= 0 || Fout <= 0) return DSW_ERR_BAD_ARG;
+        if (B == 0 || V == 0) return DSW_OK;
+        if (!X || !W || !Y || !T || !rowptr) return DSW_ERR_BAD_ARG;
+        if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
+        const int64_t N = B * V;
+        rc = dsw_zmix_launch(X, W, bias, Y, T, N, Fin, Fout, K, dtype, (hipStream_t)stream);
+        if (rc != DSW_OK) return rc;
+        char* spare = static_cast<char*>(T) + (K - 1) * N * Fout * elem_size(dtype);
+        // the Clenshaw recurrence has exactly the form of the adjoint recurrence (with L instead of L^T)
+        return dsw_cheb_basis_adj(rowptr, colind, vals, V, nnz, Y, T, B, Fout, K, dtype, stream, plan,
+                                  K >= 4 ? spare : nullptr);
+    }
     if (K > 1) {
         rc = dsw_cheb_basis_fwd(rowptr, colind, vals, V, nnz, X, T, B, Fin, K, dtype, stream, plan);
         if (rc != DSW_OK) return rc;
@@ -164,6 +200,11 @@ int dsw_cheb_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals
 int64_t dsw_cheb_bwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t Fout, int64_t K, int dtype) {
     if (B < 0 || V < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
     const int64_t N = B * V;
+    if (mix_first(Fin, Fout, K)) {   // D_1..D_{K-1} planes of [N, Fout] + the partials of one K = 1 wgrad launch
+        const int64_t d = round_up((K - 1) * N * Fout * elem_size(dtype), 256);
+        const int64_t S1 = dsw_wgrad_slabs(N, Fin, Fout, 1);
+        return d + round_up((S1 > 0 ? S1 : 1) * (Fin + 1) * Fout * 4, 256) + 256;
+    }
     // G_1..G_{K-1} planes, plus two spare planes for the pairwise fused adjoint when K >= 4
     const int64_t g = round_up((K - 1 + (K >= 4 ? 2 : 0)) * N * Fin * elem_size(dtype), 256);
     const int64_t S = dsw_wgrad_slabs(N, Fin, Fout, K);
@@ -179,11 +220,25 @@ int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* 
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     const int64_t need = dsw_cheb_bwd_workspace_bytes(B, V, Fin, Fout, K, dtype);
     if (!workspace || workspace_bytes < need) return DSW_ERR_WORKSPACE;
-    if (!dY || !X || !W || (K > 1 && !T)) return DSW_ERR_BAD_ARG;
+    const bool mf = mix_first(Fin, Fout, K);
+    if (!dY || !X || !W || (K > 1 && !T && !mf)) return DSW_ERR_BAD_ARG;
     const int64_t N = B * V;
     hipStream_t s = (hipStream_t)stream;
     // carve the workspace (256-byte aligned base)
     char* ws = reinterpret_cast<char*>(round_up((int64_t)(uintptr_t)workspace, 256));
+    if (mf) {
+        if (N == 0 || (!dX && !dW)) return DSW_OK;
+        if (!rowptr_t) return DSW_ERR_BAD_ARG;
+        const int64_t dplane = N * Fout * elem_size(dtype);
+        char* D = ws;                                                     // D_1 .. D_{K-1}
+        float* part = reinterpret_cast<float*>(ws + round_up((K - 1) * dplane, 256));
+        int rcm = dsw_cheb_basis_fwd(rowptr_t, colind_t, vals_t, V, nnz, dY, D, B, Fout, K, dtype, stream, plan_t);
+        if (rcm == DSW_OK && dX != nullptr) rcm = dsw_zdgrad_launch(dY, D, W, dX, N, Fin, Fout, K, dtype, s);
+        for (int64_t k = 0; k < K && rcm == DSW_OK && dW != nullptr; ++k)
+            rcm = dsw_wgrad_launch_ex(X, nullptr, k == 0 ? dY : static_cast<const void*>(D + (k - 1) * dplane), dW,
+                                      k == 0 ? db : nullptr, part, N, Fin, Fout, 1, dtype, s, K, k);
+        return rcm;
+    }
     const int64_t plane = N * Fin * elem_size(dtype);
     char* G = ws;                                                    // G_1 .. G_{K-1}
     char* spare = G + (K - 1) * plane;

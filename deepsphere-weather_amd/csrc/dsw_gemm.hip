@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void ts_gemm_kernel(const TsGemmParams P) {
         char* base = static_cast<char*>((q == 0) ? P.C0 : P.C1);
         const size_t cbase = (q == 0) ? 0 : (size_t)(q - 1) * P.c_plane_stride;
         col_ptr[nt] = base + (cbase + (size_t)n) * (BF16 ? 2 : 4);
-        col_bias[nt] = (P.bias != nullptr) ? ld1<BF16>(P.bias, n) : 0.f;
+        col_bias[nt] = (P.bias != nullptr && !(P.bias_plane0 && q != 0)) ? ld1<BF16>(P.bias, n) : 0.f;
     }
 
     // A staging.  RESIDENT: every wave stages exactly the 32 rows it consumes (rows wave*32 + (lane>>3)
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_kernel(const WgradParams P
 template <bool BF16>
 __global__ __launch_bounds__(256) void cheb_wgrad_reduce_kernel(const float* __restrict__ partial, int S,
                                                                 int Fin, int Fout, int K, void* dW,
-                                                                void* db) {
+                                                                void* db, int K_out, int k_off) {
     __shared__ float red[8][32];
     const int Kd = K * Fin;
     const long total = (long)(Kd + 1) * Fout;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void cheb_wgrad_reduce_kernel(const float* __r
             if (db != nullptr) st1<BF16>(db, o, v);
         } else {
             const int k = kd / Fin, f = kd - k * Fin;
-            st1<BF16>(dW, ((size_t)f * K + k) * Fout + o, v);
+            st1<BF16>(dW, ((size_t)f * K_out + k_off + k) * Fout + o, v);   // dW is [Fin, K_out, Fout]
         }
     }
 }
@@ -525,7 +525,7 @@ int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* 
     if (N == 0) return DSW_OK;
     if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
     const int es = dtype == DSW_BF16 ? 2 : 4;
-    TsGemmParams P;
+    TsGemmParams P{};
     P.A0 = X; P.A1 = T; P.a_plane_stride = (size_t)N * Fin; P.lda = (int)Fin;
     P.n_planes_a = (int)K; P.kd_per_plane = (int)Fin;
     P.Bsrc = W; P.b_sp = Fout; P.b_sq = 0; P.b_skd = K * Fout; P.b_sn = 1;
@@ -545,7 +545,7 @@ int dsw_mix_dgrad_launch(const void* dY, const void* W, void* G0, void* Grest, i
     if (N == 0) return DSW_OK;
     if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
     const int es = dtype == DSW_BF16 ? 2 : 4;
-    TsGemmParams P;
+    TsGemmParams P{};
     P.A0 = dY; P.A1 = dY; P.a_plane_stride = 0; P.lda = (int)Fout; P.n_planes_a = 1; P.kd_per_plane = (int)Fout;
     P.Bsrc = W; P.b_sp = 0; P.b_sq = Fout; P.b_skd = 1; P.b_sn = K * Fout;
     P.C0 = G0; P.C1 = Grest; P.c_plane_stride = (size_t)N * Fin; P.ldc = (int)Fin; P.n_planes_c = (int)K;
@@ -554,6 +554,46 @@ int dsw_mix_dgrad_launch(const void* dY, const void* W, void* G0, void* Grest, i
     { static const char* d = getenv("DSW_DBG"); P.dbg = d ? atoi(d) : 0; }
     const uintptr_t am = (uintptr_t)(4 * es) - 1;
     P.a_vec = (Fout % 4 == 0) && (((uintptr_t)dY & am) == 0);
+    if (dtype == DSW_F32) return launch_ts_gemm<false>(P, stream);
+    if (dtype == DSW_BF16) return launch_ts_gemm<true>(P, stream);
+    return DSW_ERR_BAD_DTYPE;
+}
+
+
+// ---- mix-first evaluation order (Fout <= Fin / 2):  Y = sum_k T_k(L) (X W_k)  - the recurrence runs on Fout channels
+// Z_k = X W_k (+ bias on k = 0):  Z_0 -> Z0 buffer (the caller's Y), Z_1.. -> Zrest planes of [N, Fout]
+int dsw_zmix_launch(const void* X, const void* W, const void* bias, void* Z0, void* Zrest, int64_t N, int64_t Fin,
+                    int64_t Fout, int64_t K, int dtype, hipStream_t stream) {
+    if (N == 0) return DSW_OK;
+    if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
+    const int es = dtype == DSW_BF16 ? 2 : 4;
+    TsGemmParams P{};
+    P.A0 = X; P.A1 = X; P.a_plane_stride = 0; P.lda = (int)Fin; P.n_planes_a = 1; P.kd_per_plane = (int)Fin;
+    P.Bsrc = W; P.b_sp = 0; P.b_sq = Fout; P.b_skd = K * Fout; P.b_sn = 1;      // element (q = k, kd = f, n = o) = W[f, k, o]
+    P.C0 = Z0; P.C1 = Zrest; P.c_plane_stride = (size_t)N * Fout; P.ldc = (int)Fout; P.n_planes_c = (int)K;
+    P.n_per_plane = (int)Fout;
+    P.bias = bias; P.bias_plane0 = 1; P.M = N;
+    const uintptr_t am = (uintptr_t)(4 * es) - 1;
+    P.a_vec = (Fin % 4 == 0) && (((uintptr_t)X & am) == 0);
+    if (dtype == DSW_F32) return launch_ts_gemm<false>(P, stream);
+    if (dtype == DSW_BF16) return launch_ts_gemm<true>(P, stream);
+    return DSW_ERR_BAD_DTYPE;
+}
+
+// dX = sum_k D_k W_k^T with D_0 = dY and D_1.. = planes of [N, Fout] (the Chebyshev basis of dY under L^T)
+int dsw_zdgrad_launch(const void* dY, const void* D, const void* W, void* dX, int64_t N, int64_t Fin, int64_t Fout,
+                      int64_t K, int dtype, hipStream_t stream) {
+    if (N == 0) return DSW_OK;
+    if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
+    const int es = dtype == DSW_BF16 ? 2 : 4;
+    TsGemmParams P{};
+    P.A0 = dY; P.A1 = D; P.a_plane_stride = (size_t)N * Fout; P.lda = (int)Fout; P.n_planes_a = (int)K;
+    P.kd_per_plane = (int)Fout;
+    P.Bsrc = W; P.b_sp = Fout; P.b_sq = 0; P.b_skd = 1; P.b_sn = K * Fout;      // element (p = k, kd = o, n = f) = W[f, k, o]
+    P.C0 = dX; P.C1 = dX; P.c_plane_stride = 0; P.ldc = (int)Fin; P.n_planes_c = 1; P.n_per_plane = (int)Fin;
+    P.bias = nullptr; P.M = N;
+    const uintptr_t am = (uintptr_t)(4 * es) - 1;
+    P.a_vec = (Fout % 4 == 0) && (((uintptr_t)dY & am) == 0) && (K == 1 || ((uintptr_t)D & am) == 0);
     if (dtype == DSW_F32) return launch_ts_gemm<false>(P, stream);
     if (dtype == DSW_BF16) return launch_ts_gemm<true>(P, stream);
     return DSW_ERR_BAD_DTYPE;
@@ -585,8 +625,20 @@ int64_t dsw_wgrad_slabs(int64_t N, int64_t Fin, int64_t Fout, int64_t K) {
     return N > 0 ? (N + rps - 1) / rps : 0;
 }
 
+// K_out / k_off: the launch fills planes k_off .. k_off + K - 1 of a dW laid out [Fin, K_out, Fout] (the plain
+// wgrad has K_out = K, k_off = 0; the mix-first backward issues one K = 1 launch per Chebyshev order)
+int dsw_wgrad_launch_ex(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
+                        int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
+                        int64_t K_out, int64_t k_off);
+
 int dsw_wgrad_launch(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
                      int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream) {
+    return dsw_wgrad_launch_ex(X, T, dY, dW, db, partial, N, Fin, Fout, K, dtype, stream, K, 0);
+}
+
+int dsw_wgrad_launch_ex(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
+                        int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
+                        int64_t K_out, int64_t k_off) {
     if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     const int es = dtype == DSW_BF16 ? 2 : 4;
@@ -653,9 +705,9 @@ reduce:
     dim3 rgrid((unsigned)((total + 31) / 32));
     if (dtype == DSW_F32)
         hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, stream, partial, (int)S,
-                           (int)Fin, (int)Fout, (int)K, dW, db);
+                           (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off);
     else
         hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, stream, partial, (int)S,
-                           (int)Fin, (int)Fout, (int)K, dW, db);
+                           (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off);
     return dsw_check_launch();
 }

@@ -60,6 +60,7 @@ struct TsGemmParams {
     int n_planes_c;
     int n_per_plane;        // valid columns per output plane
     const void* bias;       // [n_per_plane] or null (same dtype as the data)
+    int bias_plane0;        // 1: the bias belongs to output plane 0 only (mix-first forward: Z_0 = X W_0 + b)
     long M;
     int a_vec;              // 1 if float4/bf16x4 loads of A are legal
     int dbg;                // diagnostics (DSW_DBG env): 1 = skip the epilogue stores, 2 = skip the MFMAs

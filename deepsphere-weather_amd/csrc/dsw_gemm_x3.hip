@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3_kernel(const TsGemmParams
         char* base = static_cast<char*>((q == 0) ? P.C0 : P.C1);
         const size_t cbase = (q == 0) ? 0 : (size_t)(q - 1) * P.c_plane_stride;
         col_ptr[nt] = base + (cbase + (size_t)n) * (BF16IO ? 2 : 4);
-        col_bias[nt] = (P.bias != nullptr) ? ld1<BF16IO>(P.bias, n) : 0.f;
+        col_bias[nt] = (P.bias != nullptr && !(P.bias_plane0 && q != 0)) ? ld1<BF16IO>(P.bias, n) : 0.f;
     }
 
     const int ar = wave * 32 + (lane >> 3);           // wave-local staging rows ar + 8*i

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
         char* base = static_cast<char*>((q == 0) ? P.C0 : P.C1);
         const size_t cbase = (q == 0) ? 0 : (size_t)(q - 1) * P.c_plane_stride;
         col_ptr[nt] = base + (cbase + (size_t)n) * 4;
-        col_bias[nt] = (P.bias != nullptr) ? static_cast<const float*>(P.bias)[n] : 0.f;
+        col_bias[nt] = (P.bias != nullptr && !(P.bias_plane0 && q != 0)) ? static_cast<const float*>(P.bias)[n] : 0.f;
     }
 
     // ---- W chunk: this thread's NPAIR (column, k-pair) slots; the global offset of a slot inside chunk 0

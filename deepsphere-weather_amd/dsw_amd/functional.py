@@ -154,11 +154,12 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
-def _plan_ptr(op, x):
-    """Address of the dsw_hop2_plan struct for this operator / row size, or None."""
-    if _plan_ptr.disabled:
+def _plan_ptr(op, x, channels=None):
+    """Address of the dsw_hop2_plan struct for this operator / row size (``channels`` of x's dtype, default the
+    last axis of x), or None."""
+    if _plan_ptr.disabled or op is None:
         return None, None
-    plan = op.hop2_plan(x.shape[-1] * x.element_size())
+    plan = op.hop2_plan((x.shape[-1] if channels is None else channels) * x.element_size())
     if plan is None:
         return None, None
     import ctypes
@@ -209,7 +210,11 @@ class _HipBackend:
         _, K, Fout = w.shape
         y = torch.empty((B, V, Fout), dtype=x.dtype, device=x.device)
         T = torch.empty((K - 1, B, V, Fin), dtype=x.dtype, device=x.device) if K > 1 else None
-        pp, _keep = _plan_ptr(op, x) if (K > 2 and _FWD_FUSED) else (None, None)
+        # mix-first layers (channel-shrinking, see dsw_cheb_mix_first) run their hops on Fout channels, use T as
+        # scratch only and need nothing but x for backward
+        mix_first = bool(lib.dsw_cheb_mix_first(Fin, Fout, K))
+        pp, _keep = (_plan_ptr(op, x, Fout if mix_first else Fin)
+                     if (K > 2 and (_FWD_FUSED or mix_first)) else (None, None))
         csr = (None, None, None, V, 0) if op is None else (
             op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz)
         with torch.cuda.device(x.device):
@@ -219,7 +224,7 @@ class _HipBackend:
                 _DTYPES[x.dtype], _stream(x), pp,
             )
         _native.check(rc, "dsw_cheb_fwd")
-        return y, T
+        return y, (None if mix_first else T)
 
     def cheb_bwd(self, op, x, T, w, dy, need_dx, need_dw, need_db):
         lib = _native.load()
@@ -234,8 +239,10 @@ class _HipBackend:
         if nbytes < 0:
             _native.check(nbytes, "dsw_cheb_bwd_workspace_bytes")
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
-        opt = op.transpose() if (need_dx and K > 1) else op
-        pp, _keep = _plan_ptr(opt, x) if (need_dx and K > 2) else (None, None)
+        mix_first = bool(lib.dsw_cheb_mix_first(Fin, Fout, K))
+        need_hops = K > 1 and (need_dx or (mix_first and want_w))
+        opt = op.transpose() if need_hops else op
+        pp, _keep = _plan_ptr(opt, x, Fout if mix_first else Fin) if (need_hops and K > 2) else (None, None)
         csr = (None, None, None, V, 0) if opt is None else (
             opt.rowptr.data_ptr(), opt.colind.data_ptr(), opt.values.data_ptr(), V, opt.nnz)
         with torch.cuda.device(x.device):

@@ -114,8 +114,18 @@ int dsw_cheb_mix_fwd(const void* X, const void* T, const void* W, const void* bi
                      int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype,
                      dsw_stream_t stream);
 
+/* Evaluation order chosen for a layer shape (1 = mix-first, 0 = basis-first).  Layers that shrink the channel
+ * count (2 * Fout <= Fin, K >= 2) evaluate  Y = sum_k T_k(L) (X W_k)  - channel mix first, then the recurrence
+ * in Clenshaw form on the Fout channels (same value as layers.py:163-178 up to fp32 rounding; the SpMM hops, the
+ * HBM-bound part, run on Fout instead of Fin channels).  Callers use it to size the tile plan they pass
+ * (rows of Fout vs Fin channels) and to know whether T comes back as the basis. */
+int dsw_cheb_mix_first(int64_t Fin, int64_t Fout, int64_t K);
+
 /* Whole ConvCheb.forward (layers.py:365-376) = dsw_cheb_basis_fwd + dsw_cheb_mix_fwd.
- * T ([K-1,B,V,Fin], may be NULL iff K == 1) receives the basis and is what backward needs. */
+ * T ([K-1,B,V,Fin], may be NULL iff K == 1) receives the basis and is what backward needs.
+ * When dsw_cheb_mix_first(Fin, Fout, K): T is required as SCRATCH of the same size (its content afterwards is
+ * unspecified; backward then needs only X, W, dY and accepts T = NULL), and `plan` / `plan_t` must be built for
+ * rows of Fout channels. */
 int dsw_cheb_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals,
                  int64_t V, int64_t nnz, const void* X, const void* W, const void* bias,
                  void* Y, void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K,

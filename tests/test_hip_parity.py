@@ -171,6 +171,13 @@ CASES = [
     (1000, 2, 12, 20, 5, True, "irregular"),  # rows with 0..64 entries, non-symmetric
     (3072, 2, 32, 32, 2, True, "healpix"),
     (130, 1, 1, 1, 3, True, "irregular"),
+    # channel-shrinking layers: mix-first evaluation order (dsw_cheb_mix_first)
+    (768, 3, 64, 32, 3, True, "healpix"),     # K = 3: one fused Clenshaw pair
+    (768, 2, 128, 64, 2, True, "healpix"),    # K = 2: single hop
+    (192, 2, 64, 16, 4, False, "healpix"),    # K = 4
+    (192, 3, 96, 40, 5, True, "healpix"),     # K = 5, Fout not a multiple of 32
+    (1000, 2, 48, 20, 3, True, "irregular"),  # non-symmetric operator: pins L vs L^T in both directions
+    (3072, 4, 256, 128, 3, True, "healpix"),  # decoder shape of the UNet
 ]
 
 
@@ -193,7 +200,8 @@ def test_conv_vs_oracle_fp32(V, B, Fin, Fout, K, bias, op):
         assert orc.max_rel_err(db, db64) <= 2 * TOL_F64
 
 
-@pytest.mark.parametrize("V,B,Fin,Fout,K", [(768, 4, 64, 128, 5), (768, 3, 32, 64, 3), (192, 2, 24, 40, 3), (192, 1, 6, 10, 2)])
+@pytest.mark.parametrize("V,B,Fin,Fout,K", [(768, 4, 64, 128, 5), (768, 3, 32, 64, 3), (192, 2, 24, 40, 3), (192, 1, 6, 10, 2),
+                                            (768, 4, 128, 64, 3), (192, 2, 64, 32, 5)])   # last two: mix-first order
 def test_conv_vs_oracle_bf16(V, B, Fin, Fout, K):
     from modules.layers import ConvCheb
 
@@ -497,3 +505,33 @@ def test_equiangular_conv_and_cross_sampling_pooling():
     assert orc.max_rel_err(x.grad, dx64) <= TOL_F64
     assert orc.max_rel_err(conv.weight.grad, dw64) <= 2 * TOL_F64
     assert orc.max_rel_err(conv.bias.grad, db64) <= 2 * TOL_F64
+
+
+def test_mix_first_equals_basis_first(monkeypatch):
+    """The two evaluation orders of a channel-shrinking layer agree to fp32 rounding (same inputs, both through
+    the C ABI; DSW_MIX_FIRST is read once per process, so the basis-first side is evaluated via the explicit
+    basis + mix entry points)."""
+    from dsw_amd import _native, functional as F_
+    from dsw_amd import sphere
+    from modules.layers import ConvCheb, prepare_torch_laplacian
+
+    lib = _native.load()
+    assert lib.dsw_cheb_mix_first(64, 32, 3) == 1 and lib.dsw_cheb_mix_first(32, 64, 3) == 0
+    assert lib.dsw_cheb_mix_first(64, 32, 1) == 0 and lib.dsw_cheb_mix_first(64, 33, 3) == 0
+    g = sphere.SphereHealpix(8, nest=True, k=8)
+    lap = prepare_torch_laplacian(g.L, lmax=1.9)
+    torch.manual_seed(11)
+    layer = ConvCheb(64, 32, 3, laplacian=lap).to(DEV)
+    with torch.no_grad():
+        layer.bias.normal_(0, 0.2)
+    x = torch.randn(2, 768, 64, device=DEV)
+    y = layer(x)                                            # mix-first
+    op = F_.get_operator(layer.laplacian)
+    T = F_.cheb_basis(op, x, 3)                             # basis-first pieces
+    yb = torch.empty_like(y)
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.dsw_cheb_mix_fwd(x.data_ptr(), T.data_ptr(), layer.weight.data_ptr(), layer.bias.data_ptr(), yb.data_ptr(),
+                              2 * 768, 64, 32, 3, 0, st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert orc.max_rel_err(y, yb.cpu().numpy()) <= TOL_F64
