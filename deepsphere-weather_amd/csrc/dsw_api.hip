@@ -23,6 +23,8 @@ int dsw_wgrad_launch(const void* X, const void* T, const void* dY, void* dW, voi
 int dsw_wgrad_launch_ex(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
                         int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
                         int64_t K_out, int64_t k_off);
+int dsw_wgrad_mixfirst_launch(const void* X, const void* dY, const void* D, void* dW, void* db, float* partial,
+                              int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream);
 int dsw_zmix_launch(const void* X, const void* W, const void* bias, void* Z0, void* Zrest, int64_t N, int64_t Fin,
                     int64_t Fout, int64_t K, int dtype, hipStream_t stream);
 int dsw_zdgrad_launch(const void* dY, const void* D, const void* W, void* dX, int64_t N, int64_t Fin, int64_t Fout,
@@ -202,8 +204,10 @@ int64_t dsw_cheb_bwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t 
     const int64_t N = B * V;
     if (mix_first(Fin, Fout, K)) {   // D_1..D_{K-1} planes of [N, Fout] + the partials of one K = 1 wgrad launch
         const int64_t d = round_up((K - 1) * N * Fout * elem_size(dtype), 256);
-        const int64_t S1 = dsw_wgrad_slabs(N, Fin, Fout, 1);
-        return d + round_up((S1 > 0 ? S1 : 1) * (Fin + 1) * Fout * 4, 256) + 256;
+        const int64_t S1 = dsw_wgrad_slabs(N, Fin, Fout, 1), SK = dsw_wgrad_slabs(N, Fin, Fout, K);
+        const int64_t p1 = (S1 > 0 ? S1 : 1) * (Fin + 1) * Fout * 4;        // one K = 1 launch per order (fallback)
+        const int64_t pk = (SK > 0 ? SK : 1) * (K * Fin + 1) * Fout * 4;    // single launch over all orders
+        return d + round_up(p1 > pk ? p1 : pk, 256) + 256;
     }
     // G_1..G_{K-1} planes, plus two spare planes for the pairwise fused adjoint when K >= 4
     const int64_t g = round_up((K - 1 + (K >= 4 ? 2 : 0)) * N * Fin * elem_size(dtype), 256);
@@ -234,9 +238,8 @@ int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* 
         float* part = reinterpret_cast<float*>(ws + round_up((K - 1) * dplane, 256));
         int rcm = dsw_cheb_basis_fwd(rowptr_t, colind_t, vals_t, V, nnz, dY, D, B, Fout, K, dtype, stream, plan_t);
         if (rcm == DSW_OK && dX != nullptr) rcm = dsw_zdgrad_launch(dY, D, W, dX, N, Fin, Fout, K, dtype, s);
-        for (int64_t k = 0; k < K && rcm == DSW_OK && dW != nullptr; ++k)
-            rcm = dsw_wgrad_launch_ex(X, nullptr, k == 0 ? dY : static_cast<const void*>(D + (k - 1) * dplane), dW,
-                                      k == 0 ? db : nullptr, part, N, Fin, Fout, 1, dtype, s, K, k);
+        if (rcm == DSW_OK && dW != nullptr)
+            rcm = dsw_wgrad_mixfirst_launch(X, dY, D, dW, db, part, N, Fin, Fout, K, dtype, s);
         return rcm;
     }
     const int64_t plane = N * Fin * elem_size(dtype);

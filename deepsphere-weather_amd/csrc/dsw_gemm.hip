@@ -711,3 +711,51 @@ reduce:
                            (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off);
     return dsw_check_launch();
 }
+
+// mix-first backward: dW[f, k, o] = sum_n X[n, f] * D_k[n, o] (D_0 = dY, D_1.. = planes of [N, Fout]), db = column sums
+// of dY.  One launch over (slab, f-tiles, (k, o-tile)) when the problem is aligned (bf16-pipe kernels); otherwise one
+// plain K = 1 wgrad per Chebyshev order.
+int dsw_wgrad_launch_ex(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
+                        int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
+                        int64_t K_out, int64_t k_off);
+static int64_t wgrad_max_slabs(int64_t Fin, int64_t Fout, int64_t K);
+
+int dsw_wgrad_mixfirst_launch(const void* X, const void* dY, const void* D, void* dW, void* db, float* partial,
+                              int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream) {
+    if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
+    if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
+    const int es = dtype == DSW_BF16 ? 2 : 4;
+    const uintptr_t am = (uintptr_t)(4 * es) - 1;
+    if (N > 0 && K > 1) {
+        WgradParams P{};
+        P.X = X; P.T = nullptr; P.plane_stride = 0; P.dY = dY; P.partial = partial;
+        P.N = N; P.Fin = (int)Fin; P.Fout = (int)Fout; P.K = 1;
+        P.tiles_per_plane = (int)((Fin + 31) / 32);
+        P.dY1 = D; P.dy_plane_stride = (size_t)N * Fout; P.dy_planes = (int)K;
+        P.t_vec = (Fin % 4 == 0) && (((uintptr_t)X & am) == 0);
+        P.dy_vec = (Fout % 4 == 0) && (((uintptr_t)dY & am) == 0) && (((uintptr_t)D & am) == 0);
+        const bool aligned = P.t_vec && P.dy_vec && (Fin % 32 == 0) && (Fout % BN == 0) && (N % WR == 0);
+        int rc3 = DSW_OK;
+        int64_t S3 = 0;
+        if (aligned && dsw_wgrad_x3_try_launch(P, dtype == DSW_BF16 ? 1 : 0, wgrad_max_slabs(Fin, Fout, K), &S3, stream,
+                                               &rc3)) {
+            if (rc3 != DSW_OK) return rc3;
+            const long total = (long)(K * Fin + 1) * Fout;
+            dim3 rgrid((unsigned)((total + 31) / 32));
+            if (dtype == DSW_F32)
+                hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, stream, partial, (int)S3,
+                                   (int)Fin, (int)Fout, (int)K, dW, db, (int)K, 0);
+            else
+                hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, stream, partial, (int)S3,
+                                   (int)Fin, (int)Fout, (int)K, dW, db, (int)K, 0);
+            return dsw_check_launch();
+        }
+    }
+    int rc = DSW_OK;
+    const size_t dplane = (size_t)N * Fout * es;
+    for (int64_t k = 0; k < K && rc == DSW_OK; ++k)
+        rc = dsw_wgrad_launch_ex(X, nullptr, k == 0 ? dY : static_cast<const void*>(static_cast<const char*>(D) + (k - 1) * dplane),
+                                 dW, k == 0 ? db : nullptr, partial, N, Fin, Fout, 1, dtype, stream, K, k);
+    return rc;
+}
+

@@ -99,6 +99,12 @@ struct WgradParams {
     long rows_per_slab;
     int tiles_per_plane;    // ceil(Fin / 32)
     int t_vec, dy_vec;
+    // mix-first backward (dW_k = X^T D_k): the dY side has `dy_planes` planes (plane 0 = dY, plane z >= 1 =
+    // dY1 + (z-1) * dy_plane_stride elements) and K == 1 on the T side; blockIdx.z = z * otiles + o-tile and the
+    // partial rows of plane z are (z * Fin + f).  dy_planes <= 1: plain wgrad.
+    const void* dY1;
+    size_t dy_plane_stride;
+    int dy_planes, otiles;
     int dbg;                // diagnostics (DSW_DBG env): 2 = skip MFMAs, 3 = skip LDS staging, 4 = skip refetch
 };
 

@@ -101,12 +101,17 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_x3_kernel(const WgradParam
     const bool active = tile < ntiles;
     const int k = active ? tile / P.tiles_per_plane : 0;
     const int f0 = active ? (tile - k * P.tiles_per_plane) * 32 : 0;
-    const int o0 = blockIdx.z * BNO;
-    const int Kd = P.K * P.Fin;
+    const int zk = P.dy_planes > 1 ? blockIdx.z / P.otiles : 0;    // dY plane (mix-first backward), else 0
+    const int o0 = (blockIdx.z - zk * P.otiles) * BNO;
+    const int Kd = (P.dy_planes > 1 ? P.dy_planes : P.K) * P.Fin;     // rows of dW in one partial slab
+    const int k_out = P.dy_planes > 1 ? zk : k;                     // dW plane this wave's tile belongs to
+    const bool do_db = blockIdx.y == 0 && zk == 0;
     const long n_begin = (long)blockIdx.x * P.rows_per_slab;
     const long n_end = (n_begin + P.rows_per_slab < P.N) ? n_begin + P.rows_per_slab : P.N;
     const void* A = (k == 0) ? P.X : P.T;
     const size_t abase = (k == 0) ? 0 : (size_t)(k - 1) * P.plane_stride;
+    const void* dYp = zk == 0 ? P.dY : P.dY1;
+    const size_t dybase = zk == 0 ? 0 : (size_t)(zk - 1) * P.dy_plane_stride;
 
     f32x16 acc[NO];
 #pragma unroll
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_x3_kernel(const WgradParam
         for (int i = 0; i < RD; ++i) {
             int e = tid + NT_ * i;
             if (DV % NT_ != 0) e = e < DV ? e : DV - 1;
-            drd[i] = load4<BF16IO>(P.dY, (size_t)(n0 + e / CQ) * P.Fout + o0 + (e % CQ) * 4);
+            drd[i] = load4<BF16IO>(dYp, dybase + (size_t)(n0 + e / CQ) * P.Fout + o0 + (e % CQ) * 4);
         }
     };
 
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_x3_kernel(const WgradParam
             if (DV % NT_ == 0 || e < DV) {
                 const int n = e / CQ, c4 = (e % CQ) * 4;
                 split_store<NSPLIT>(DsT + (c4 >> 5) * BLK + n * 32 + (c4 & 31), DPLANE, srd[i]);
-                if (live && blockIdx.y == 0) {
+                if (live && do_db) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) cs[i][j] += srd[i][j];
                 }
@@ -220,11 +225,11 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_x3_kernel(const WgradParam
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int f = f0 + (i & 3) + 8 * (i >> 2) + 4 * half;
-                out[(size_t)(k * P.Fin + f) * P.Fout + o] = acc[t][i];
+                out[(size_t)(k_out * P.Fin + f) * P.Fout + o] = acc[t][i];
             }
         }
     }
-    if (blockIdx.y == 0) {
+    if (do_db) {
         // column sums of dY (db).  Slot i of a thread is tile element tid + NT_*i; NT_ % CQ == 0, so all slots of a
         // thread belong to the same column quad tid % CQ: add them up, then combine the G threads of a quad.
         __syncthreads();
@@ -274,12 +279,16 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_bf16_kernel(const WgradPar
     const bool active = tile < ntiles;
     const int k = active ? tile / P.tiles_per_plane : 0;
     const int f0 = active ? (tile - k * P.tiles_per_plane) * 32 : 0;
-    const int o0 = blockIdx.z * BNO;
-    const int Kd = P.K * P.Fin;
+    const int zk = P.dy_planes > 1 ? blockIdx.z / P.otiles : 0;
+    const int o0 = (blockIdx.z - zk * P.otiles) * BNO;
+    const int Kd = (P.dy_planes > 1 ? P.dy_planes : P.K) * P.Fin;
+    const int k_out = P.dy_planes > 1 ? zk : k;
+    const bool do_db = blockIdx.y == 0 && zk == 0;
     const long n_begin = (long)blockIdx.x * P.rows_per_slab;
     const long n_end = (n_begin + P.rows_per_slab < P.N) ? n_begin + P.rows_per_slab : P.N;
     const uint16_t* A = static_cast<const uint16_t*>((k == 0) ? P.X : P.T) + ((k == 0) ? 0 : (size_t)(k - 1) * P.plane_stride);
-    const uint16_t* dY = static_cast<const uint16_t*>(P.dY);
+    const uint16_t* dY = zk == 0 ? static_cast<const uint16_t*>(P.dY)
+                                 : static_cast<const uint16_t*>(P.dY1) + (size_t)(zk - 1) * P.dy_plane_stride;
 
     f32x16 acc[NO];
 #pragma unroll
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_bf16_kernel(const WgradPar
             if (DV % NT_ == 0 || e < DV) {
                 const int n = e / CO, c8 = (e % CO) * 8;
                 *reinterpret_cast<u32x4*>(DsT + (c8 >> 5) * BLKB + n * 32 + (c8 & 31)) = srd[i];
-                if (live && blockIdx.y == 0) {
+                if (live && do_db) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         cs[i][2 * j] += __uint_as_float(srd[i][j] << 16);
@@ -371,11 +380,11 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_bf16_kernel(const WgradPar
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int f = f0 + (i & 3) + 8 * (i >> 2) + 4 * half;
-                out[(size_t)(k * P.Fin + f) * P.Fout + o] = acc[t][i];
+                out[(size_t)(k_out * P.Fin + f) * P.Fout + o] = acc[t][i];
             }
         }
     }
-    if (blockIdx.y == 0) {
+    if (do_db) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -406,7 +415,9 @@ int launch_wbf16(WgradParams& P, int groups, int otiles, int64_t max_slabs, int6
         return DSW_ERR_LAUNCH;
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, NT_, lds) != hipSuccess || occ < 1) occ = 1;
-    int64_t want = 256L * occ / ((int64_t)groups * otiles);
+    const int zdim = otiles * (P.dy_planes > 1 ? P.dy_planes : 1);
+    P.otiles = otiles;
+    int64_t want = 256L * occ / ((int64_t)groups * zdim);
     if (want < 32) want = 32;
     if (want > max_slabs) want = max_slabs;
     int64_t rps = (P.N + want - 1) / want;
@@ -415,7 +426,7 @@ int launch_wbf16(WgradParams& P, int groups, int otiles, int64_t max_slabs, int6
     const int64_t S = (P.N + rps - 1) / rps;
     P.rows_per_slab = rps;
     *S_out = S;
-    dim3 grid((unsigned)S, (unsigned)groups, (unsigned)otiles);
+    dim3 grid((unsigned)S, (unsigned)groups, (unsigned)zdim);
     hipLaunchKernelGGL((cheb_wgrad_bf16_kernel<NW, NO>), grid, dim3(NT_), lds, stream, P);
     return dsw_check_launch();
 }
@@ -432,7 +443,9 @@ int launch_wx3(WgradParams& P, int groups, int otiles, int64_t max_slabs, int64_
         return DSW_ERR_LAUNCH;
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, NT_, lds) != hipSuccess || occ < 1) occ = 1;
-    int64_t want = 256L * occ / ((int64_t)groups * otiles);
+    const int zdim = otiles * (P.dy_planes > 1 ? P.dy_planes : 1);
+    P.otiles = otiles;
+    int64_t want = 256L * occ / ((int64_t)groups * zdim);
     if (want < 32) want = 32;
     if (want > max_slabs) want = max_slabs;
     int64_t rps = (P.N + want - 1) / want;
@@ -441,7 +454,7 @@ int launch_wx3(WgradParams& P, int groups, int otiles, int64_t max_slabs, int64_
     const int64_t S = (P.N + rps - 1) / rps;
     P.rows_per_slab = rps;
     *S_out = S;
-    dim3 grid((unsigned)S, (unsigned)groups, (unsigned)otiles);
+    dim3 grid((unsigned)S, (unsigned)groups, (unsigned)zdim);
     hipLaunchKernelGGL((cheb_wgrad_x3_kernel<BF16IO, NSPLIT, NW, NO>), grid, dim3(NT_), lds, stream, P);
     return dsw_check_launch();
 }
@@ -460,7 +473,8 @@ int dsw_wgrad_x3_try_launch(WgradParams& P, int bf16, int64_t max_slabs, int64_t
     const int otiles = wide ? P.Fout / 128 : P.Fout / 64;
     // bf16 storage, whole 64-row chunks, 16-byte aligned 8-channel groups: raw-copy staging kernel
     const bool raw = bf16 && P.N % 64 == 0 && P.Fin % 8 == 0 && P.Fout % 8 == 0 && dsw_aligned16(P.X) &&
-                     (P.K == 1 || dsw_aligned16(P.T)) && dsw_aligned16(P.dY) && P.plane_stride % 8 == 0;
+                     (P.K == 1 || dsw_aligned16(P.T)) && dsw_aligned16(P.dY) && P.plane_stride % 8 == 0 &&
+                     (P.dy_planes <= 1 || (dsw_aligned16(P.dY1) && P.dy_plane_stride % 8 == 0));
     if (raw) {
 #define DSW_WB(NW_)                                                                                               \
     case NW_:                                                                                                     \
