@@ -535,3 +535,25 @@ def test_mix_first_equals_basis_first(monkeypatch):
     assert rc == 0
     torch.cuda.synchronize()
     assert orc.max_rel_err(y, yb.cpu().numpy()) <= TOL_F64
+
+
+def test_c_abi_from_a_c_client(tmp_path):
+    """The boundary is a C ABI, not a torch extension: tests/cabi/cabi_client.cpp (HIP runtime + include/dsw_hip.h,
+    no Python, no torch) runs forward + backward through libdsw_hip.so and checks them against the plain-C oracle."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from oracle import c_oracle
+
+    c_oracle.lib()   # make sure oracle/_build/libcheb_oracle.so exists
+    libdir = os.path.join(root, "deepsphere-weather_amd", "dsw_amd")
+    odir = os.path.join(root, "oracle", "_build")
+    exe = str(tmp_path / "cabi_client")
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "cabi", "cabi_client.cpp"), "-L", libdir, "-ldsw_hip", "-L", odir,
+                    "-lcheb_oracle", f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{odir}", "-o", exe],
+                   check=True, capture_output=True, timeout=600)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(out.stdout)
+    assert out.returncode == 0 and "C-ABI CLIENT: PASS" in out.stdout, out.stdout + out.stderr
