@@ -18,6 +18,7 @@
 // HBM-bound by construction: every U row is fetched ~|S2|/R times, but only the first fetch
 // misses L2 (blocks of one XCD walk contiguous tiles), and the gathers - k+1 per row and hop,
 // the limiter of the one-hop kernel on the L1/TA path - run on the LDS pipe at 4x the rate.
+#include <cstdlib>
 #include <type_traits>
 #include "dsw_common.h"
 #include "../../include/dsw_hip.h"
@@ -399,11 +400,22 @@ int dsw_spmm2_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const 
     A.row_bytes = (int)(C * es); A.lpr = A.row_bytes / 16; A.B = (int)B;
     A.ell_w = hop2_ell_w(plan);
     const size_t lds = hop2_lds_bytes(plan, A.row_bytes);
-    // batch chunks: enough workgroups for ~4 rounds over the resident slots, >= 2 samples per workgroup
-    // so that the plan staging and the first U load are amortised and the register double buffer pays
-    long slots = 256L * ((160 * 1024) / (long)lds > 0 ? (160 * 1024) / (long)lds : 1);
-    long chunks = (4 * slots + plan->n_tiles - 1) / plan->n_tiles;
-    if (chunks > (B + 1) / 2) chunks = (B + 1) / 2;
+    // batch chunks.  A workgroup = (tile, chunk of the batch); the launch runs in ceil(n_tiles * chunks / slots) rounds
+    // over the resident slots, each round costing the plan staging (about 1.5 samples' worth) plus the samples of a
+    // chunk: pick the chunk count that minimises rounds * (1.5 + samples per chunk).  (NS: 768 tiles on 512 slots -> 2
+    // chunks = exactly 3 rounds, 91 us; the former "about 4 rounds" rule gave 3 chunks = 4.5 rounds, 102 us.)
+    const long slots = 256L * ((160 * 1024) / (long)lds > 0 ? (160 * 1024) / (long)lds : 1);
+    long chunks = 1;
+    {
+        double best = -1.0;
+        const long cmax = B > 1 ? (B + 1) / 2 : 1;       // >= 2 samples per workgroup: the register double buffer
+        for (long c = 1; c <= cmax && c <= 16; ++c) {
+            const long rounds = (plan->n_tiles * c + slots - 1) / slots;
+            const double cost = (double)rounds * (1.5 + (double)((B + c - 1) / c));
+            if (best < 0 || cost < best - 1e-9) { best = cost; chunks = c; }
+        }
+    }
+    { static const char* ce = getenv("DSW_H2_CHUNKS"); if (ce) chunks = atol(ce); }   // diagnostics
     if (chunks < 1) chunks = 1;
     A.spc = (int)((B + chunks - 1) / chunks);
     A.n_chunks = (int)((B + A.spc - 1) / A.spc);
