@@ -201,23 +201,16 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
     const int W = P.ell_w;
     const size_t sample_bytes = (size_t)P.V * P.row_bytes;
 
-    // ---- the tile's plan slice -> LDS (CSR expanded to ELL), once for all samples of this workgroup
+    // ---- the tile's plan slice -> LDS, once for all samples of this workgroup.  Ordered so that nothing waits on
+    // a chain of dependent global loads: (1) gather list + local row pointers (parked in bufT, free until the first
+    // phase 1), (2) the first sample's input rows are REQUESTED, (3) the CSR -> ELL expansion runs under them with
+    // independent loads only (row pointers come from LDS).
+    int* lrp = reinterpret_cast<int*>(bufT);          // [n1 + 1] local row pointers (relative to nnz_off)
     if (tid == 0) *tile_w = 2;
     for (int i = tid; i < n2; i += NTHREADS) rows[i] = P.s2_rows[s2_off + i];
-    __syncthreads();
-    for (int t = tid; t < n1 * W; t += NTHREADS) {
-        const int i = t / W, j = t - i * W;
-        const int p0 = P.lrowptr[rp_off + i], p1 = P.lrowptr[rp_off + i + 1];
-        const int p = p0 + j;
-        if (j == 0 && p1 - p0 > 2) atomicMax(tile_w, p1 - p0);
-        // entries hold the BYTE offset of the source row inside a staging buffer (one multiply less per gather)
-        ell[t] = (p < p1) ? make_uint2((unsigned)P.lcol[nnz_off + p] * (unsigned)P.row_bytes,
-                                       __float_as_uint(P.lval[nnz_off + p]))
-                          : make_uint2((unsigned)i * (unsigned)P.row_bytes, 0u);     // padding: own row, weight 0
-    }
+    for (int i = tid; i <= n1; i += NTHREADS) lrp[i] = P.lrowptr[rp_off + i];
     __syncthreads();
 
-    const int Wt = (*tile_w + 1) & ~1;              // gather loop length of this tile (<= W, even)
     const int lpr = P.lpr;
     const int rpp = NTHREADS / lpr;                 // rows per pass
     const int grp0 = tid / lpr;
@@ -241,6 +234,26 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
 #pragma unroll
         for (int k = 0; k < NST; ++k) su[k] = *reinterpret_cast<const u32x4*>(P.U + sb + offU[k]);
     }
+    // CSR -> ELL (entries hold the BYTE offset of the source row inside a staging buffer: one multiply less per
+    // gather), padding = {own row, weight 0}
+    const int tile_nnz = lrp[n1];
+    for (int t = tid; t < n1 * W; t += NTHREADS) {
+        const int i = t / W, j = t - i * W;
+        const int p0 = lrp[i], p1 = lrp[i + 1];
+        unsigned col = 0;
+        float val = 0.f;
+        if (tile_nnz > 0) {                         // uniform; the loads are unconditional and index-clamped
+            const int p = max(0, min(p0 + j, tile_nnz - 1));
+            col = P.lcol[nnz_off + p];
+            val = P.lval[nnz_off + p];
+        }
+        if (j == 0 && p1 - p0 > 2) atomicMax(tile_w, p1 - p0);
+        ell[t] = (p0 + j < p1) ? make_uint2(col * (unsigned)P.row_bytes, __float_as_uint(val))
+                               : make_uint2((unsigned)i * (unsigned)P.row_bytes, 0u);
+    }
+    __syncthreads();   // ELL complete (and lrp in bufT dead) before the first phase 1
+    const int Wt = (*tile_w + 1) & ~1;              // gather loop length of this tile (<= W, even)
+
     for (int b = b_begin; b < b_end; ++b) {
         unsigned char* bufX = ((b - b_begin) & 1) ? bufX1 : bufX0;
 #pragma unroll
