@@ -86,9 +86,7 @@ class _NodeLinear(Linear):
     MFMA GEMM kernels (the K = 1 channel mix) instead of a rocBLAS call."""
 
     def forward(self, x):
-        if not x.is_cuda:
-            return super().forward(x)
-        return dsw_functional.dense_mix(x, self.weight.t(), self.bias)
+        return dsw_functional.dense_mix(x, self.weight.t(), self.bias)   # raises on CPU tensors like every layer here
 
 
 class ResBlock(torch.nn.Module):
