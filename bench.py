@@ -365,6 +365,18 @@ def main():
             "launch": "hip graph replay of one fwd+bwd" if graph is not None else "eager",
         },
     }
+    if rank == 0 and world == 1:
+        # per-iteration HIP-event times (outside the timed region above): median and p10 / p90
+        n_ev = 100
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+        for a, b in evs:
+            a.record()
+            full_step()
+            b.record()
+        torch.cuda.synchronize()
+        us = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+        out["per_step_us"] = {"n": n_ev, "median": round(us[n_ev // 2], 1), "p10": round(us[n_ev // 10], 1),
+                              "p90": round(us[(9 * n_ev) // 10], 1)}
     if rank == 0 and world == 1 and args.workload not in ("unet", "c5"):
         if not args.no_roofline:
             out["roofline"] = roofline_leg(model, x.detach(), max(10, args.steps), 5,
