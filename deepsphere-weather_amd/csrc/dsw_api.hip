@@ -25,6 +25,9 @@ int dsw_wgrad_launch_ex(const void* X, const void* T, const void* dY, void* dW, 
                         int64_t K_out, int64_t k_off);
 int dsw_wgrad_mixfirst_launch(const void* X, const void* dY, const void* D, void* dW, void* db, float* partial,
                               int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream);
+int dsw_bwd_gemm_fused_try(const void* X, const void* T, const void* W, const void* dY, void* dW, void* db, void* G0,
+                           void* Grest, float* partial, int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype,
+                           hipStream_t stream, int* rc);
 int dsw_zmix_launch(const void* X, const void* W, const void* bias, void* Z0, void* Zrest, int64_t N, int64_t Fin,
                     int64_t Fout, int64_t K, int dtype, hipStream_t stream);
 int dsw_zdgrad_launch(const void* dY, const void* D, const void* W, void* dX, int64_t N, int64_t Fin, int64_t Fout,
@@ -247,6 +250,18 @@ int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* 
     char* spare = G + (K - 1) * plane;
     float* partial = reinterpret_cast<float*>(ws + round_up((K - 1 + (K >= 4 ? 2 : 0)) * plane, 256));
     int rc = DSW_OK;
+    if (dX != nullptr && dW != nullptr && N > 0) {
+        // small aligned fp32 layers: dgrad planes and dW partials from ONE pass over dY (dsw_wgrad_x3.hip, FUSE)
+        if (K > 1 && !rowptr_t) return DSW_ERR_BAD_ARG;
+        int rcf = DSW_OK;
+        if (dsw_bwd_gemm_fused_try(X, T, W, dY, dW, db, dX, G, partial, N, Fin, Fout, K, dtype, s, &rcf)) {
+            if (rcf != DSW_OK) return rcf;
+            if (K > 1)
+                rcf = dsw_cheb_basis_adj(rowptr_t, colind_t, vals_t, V, nnz, dX, G, B, Fin, K, dtype, stream, plan_t,
+                                         K >= 4 ? spare : nullptr);
+            return rcf;
+        }
+    }
     if (dX != nullptr && N > 0) {
         if (K > 1 && !rowptr_t) return DSW_ERR_BAD_ARG;
         rc = dsw_mix_dgrad_launch(dY, W, dX, G, N, Fin, Fout, K, dtype, s);

@@ -105,6 +105,11 @@ struct WgradParams {
     const void* dY1;
     size_t dy_plane_stride;
     int dy_planes, otiles;
+    // fused dgrad (cheb_wgrad_x3_kernel<..., FUSE>): the workgroup also writes G_k[n, f] = sum_o dY[n, o] W[f, k, o] for
+    // the rows it streams (plane 0 -> G0, plane k >= 1 -> Grest + (k-1) * plane_stride elements)
+    const void* W;
+    void* G0;
+    void* Grest;
     int dbg;                // diagnostics (DSW_DBG env): 2 = skip MFMAs, 3 = skip LDS staging, 4 = skip refetch
 };
 

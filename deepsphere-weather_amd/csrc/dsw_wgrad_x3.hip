@@ -76,8 +76,14 @@ static __device__ __forceinline__ bf16x8_t read_frag_tr(const unsigned short* p)
     return __builtin_bit_cast(bf16x8_t, r);
 }
 
-template <bool BF16IO, int NSPLIT, int NW, int NO>
-__global__ __launch_bounds__(64 * NW) void cheb_wgrad_x3_kernel(const WgradParams P) {
+// FUSE (fp32, one o-tile covering all of Fout, one (k,f)-group): the workgroup holds the dY rows it needs for dW
+// anyway, so it also evaluates the dgrad of those rows, G_k[n, f] = sum_o dY[n, o] W[f, k, o]: wave w multiplies the
+// staged dY image (row-major blocks: plain 16-byte A fragments) with its 32 columns of the pre-split W^T panel (LDS,
+// [plane][col][o], 16-byte padded rows) and writes its 32 x 32 tile of G.  dY is then read from HBM once for the
+// whole backward GEMM work instead of twice (NS: 200 MB less traffic, one launch less).
+template <bool BF16IO, int NSPLIT, int NW, int NO, bool FUSE = false>
+__global__ __launch_bounds__(64 * NW, FUSE ? 2 : 1) void cheb_wgrad_x3_kernel(const WgradParams P) {
+    static_assert(!FUSE || (!BF16IO && NSPLIT == 3), "fused dgrad: fp32 storage");
     constexpr int NT_ = 64 * NW;
     constexpr int BNO = 32 * NO;                        // dY columns of the workgroup
     constexpr int CQ = BNO / 4;                         // column quads of the dY tile
@@ -85,13 +91,16 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_x3_kernel(const WgradParam
     constexpr int RD = (DV + NT_ - 1) / NT_;            // ... per thread
     constexpr int G = NT_ / CQ;                         // threads sharing a column quad (NT_ % CQ == 0)
     static_assert(NT_ % CQ == 0, "column-sum layout");
-    constexpr int PF = 3;
+    constexpr int PF = FUSE ? 2 : 3;                    // the fused variant needs the registers of the third slot
     constexpr int TPLANE = BLK;                         // one (wave, plane) T tile
     constexpr int DPLANE = NO * BLK;                    // one dY plane: NO blocks [32 n][32 o]
     extern __shared__ __attribute__((aligned(16))) unsigned short xs[];
     unsigned short* TsT = xs;                                  // [NW][NSPLIT][32 n][32 f]
     unsigned short* DsT = xs + (size_t)NW * NSPLIT * TPLANE;   // [NSPLIT][NO][32 n][32 o]
     float* red = reinterpret_cast<float*>(DsT + (size_t)NSPLIT * DPLANE);   // [G][BNO] column-sum scratch
+    constexpr int WKS = BNO + 8;                        // bf16 elements per W^T panel row (o contiguous, 16 B pad)
+    unsigned short* Wp = reinterpret_cast<unsigned short*>(red + (size_t)G * BNO);   // FUSE: [3][NW * 32 cols][WKS]
+    constexpr int WPLANE = NW * 32 * WKS;
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -113,6 +122,24 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_x3_kernel(const WgradParam
     const void* dYp = zk == 0 ? P.dY : P.dY1;
     const size_t dybase = zk == 0 ? 0 : (size_t)(zk - 1) * P.dy_plane_stride;
 
+    if constexpr (FUSE) {
+        // W^T panel of this workgroup's (k, f) columns, split once: Wp[plane][w * 32 + fl][o] = split(W[f0(w) + fl, k(w), o])
+        const float* Wsrc = static_cast<const float*>(P.W);
+        for (int e = tid; e < NW * 32 * BNO; e += NT_) {
+            const int c = e / BNO, o = e - c * BNO;
+            const int t_ = blockIdx.y * NW + (c >> 5);
+            float v = 0.f;
+            if (t_ < ntiles) {
+                const int kk = t_ / P.tiles_per_plane, ff = (t_ - kk * P.tiles_per_plane) * 32 + (c & 31);
+                v = Wsrc[((size_t)ff * P.K + kk) * P.Fout + o];
+            }
+            const float h = trunc_bf16(v), r1 = v - h, m = trunc_bf16(r1), l = r1 - m;
+            Wp[c * WKS + o] = (unsigned short)(__float_as_uint(h) >> 16);
+            Wp[WPLANE + c * WKS + o] = (unsigned short)(__float_as_uint(m) >> 16);
+            Wp[2 * WPLANE + c * WKS + o] = (unsigned short)(__float_as_uint(l) >> 16);
+        }
+        // visible to every wave after the first __syncthreads() of the chunk loop
+    }
     f32x16 acc[NO];
 #pragma unroll
     for (int t = 0; t < NO; ++t)
@@ -143,7 +170,7 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_x3_kernel(const WgradParam
     if (n_chunks > 0) {
         fetch(n_begin, rt0, rd0);
         fetch(n_begin + (1 < n_chunks ? 1 : n_chunks - 1) * WR, rt1, rd1);
-        fetch(n_begin + (2 < n_chunks ? 2 : n_chunks - 1) * WR, rt2, rd2);
+        if constexpr (PF == 3) fetch(n_begin + (2 < n_chunks ? 2 : n_chunks - 1) * WR, rt2, rd2);
     }
     const long n_pad = (n_chunks + PF - 1) / PF * PF;
 
@@ -209,12 +236,42 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_x3_kernel(const WgradParam
                     acc[t] = a_;
                 }
             }
+            if constexpr (FUSE) {
+                // G tile of this wave: rows = the chunk's 32 nodes, cols = its 32 (k, f) channels, reduction over o
+                f32x16 g;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) g[i] = 0.f;
+                const unsigned short* da = DsT + (size_t)l31 * 32 + 8 * half;                     // A: dY[n = l31][o ..]
+                const unsigned short* wb = Wp + (size_t)(wave * 32 + l31) * WKS + 8 * half;        // B: W^T[col = l31][o ..]
+#pragma unroll
+                for (int s = 0; s < BNO / 16; ++s) {
+                    const unsigned short* ap = da + ((16 * s) >> 5) * BLK + ((16 * s) & 31);
+                    const bf16x8_t xh = *reinterpret_cast<const bf16x8_t*>(ap);
+                    const bf16x8_t xm = *reinterpret_cast<const bf16x8_t*>(ap + DPLANE);
+                    const bf16x8_t xl = *reinterpret_cast<const bf16x8_t*>(ap + 2 * DPLANE);
+                    const bf16x8_t wh = *reinterpret_cast<const bf16x8_t*>(wb + 16 * s);
+                    const bf16x8_t wm = *reinterpret_cast<const bf16x8_t*>(wb + WPLANE + 16 * s);
+                    const bf16x8_t wl = *reinterpret_cast<const bf16x8_t*>(wb + 2 * WPLANE + 16 * s);
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, g, 0, 0, 0);
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, wm, g, 0, 0, 0);
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, g, 0, 0, 0);
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, wh, g, 0, 0, 0);
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wm, g, 0, 0, 0);
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, g, 0, 0, 0);
+                }
+                float* Gp = (k == 0) ? static_cast<float*>(P.G0)
+                                     : static_cast<float*>(P.Grest) + (size_t)(k - 1) * P.plane_stride;
+                const long nrow = n_begin + ci * WR + 4 * half;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    Gp[(size_t)(nrow + (i & 3) + 8 * (i >> 2)) * P.Fin + f0 + l31] = g[i];
+            }
         }
     };
     for (long cb = 0; cb < n_pad; cb += PF) {
         stage(std::integral_constant<int, 0>{}, cb);
         stage(std::integral_constant<int, 1>{}, cb + 1);
-        stage(std::integral_constant<int, 2>{}, cb + 2);
+        if constexpr (PF == 3) stage(std::integral_constant<int, 2>{}, cb + 2);
     }
 
     float* out = P.partial + (size_t)blockIdx.x * (size_t)(Kd + 1) * P.Fout;
@@ -431,13 +488,14 @@ int launch_wbf16(WgradParams& P, int groups, int otiles, int64_t max_slabs, int6
     return dsw_check_launch();
 }
 
-template <bool BF16IO, int NSPLIT, int NW, int NO>
+template <bool BF16IO, int NSPLIT, int NW, int NO, bool FUSE = false>
 int launch_wx3(WgradParams& P, int groups, int otiles, int64_t max_slabs, int64_t* S_out, hipStream_t stream) {
     constexpr int NT_ = 64 * NW;
     constexpr int BNO = 32 * NO;
     constexpr int G = NT_ / (BNO / 4);
-    const size_t lds = ((size_t)NW * NSPLIT * BLK + (size_t)NSPLIT * NO * BLK) * 2 + (size_t)G * BNO * 4;
-    const void* kfn = (const void*)cheb_wgrad_x3_kernel<BF16IO, NSPLIT, NW, NO>;
+    const size_t lds = ((size_t)NW * NSPLIT * BLK + (size_t)NSPLIT * NO * BLK) * 2 + (size_t)G * BNO * 4 +
+                       (FUSE ? (size_t)3 * NW * 32 * (BNO + 8) * 2 : 0);
+    const void* kfn = (const void*)cheb_wgrad_x3_kernel<BF16IO, NSPLIT, NW, NO, FUSE>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DSW_ERR_LAUNCH;
@@ -455,7 +513,7 @@ int launch_wx3(WgradParams& P, int groups, int otiles, int64_t max_slabs, int64_
     P.rows_per_slab = rps;
     *S_out = S;
     dim3 grid((unsigned)S, (unsigned)groups, (unsigned)zdim);
-    hipLaunchKernelGGL((cheb_wgrad_x3_kernel<BF16IO, NSPLIT, NW, NO>), grid, dim3(NT_), lds, stream, P);
+    hipLaunchKernelGGL((cheb_wgrad_x3_kernel<BF16IO, NSPLIT, NW, NO, FUSE>), grid, dim3(NT_), lds, stream, P);
     return dsw_check_launch();
 }
 
@@ -503,5 +561,28 @@ int dsw_wgrad_x3_try_launch(WgradParams& P, int bf16, int64_t max_slabs, int64_t
     }
 #undef DSW_WX3
 #undef DSW_WX3_NARROW
+    return 0;
+}
+
+// wgrad with the dgrad of the same rows fused in (fp32, aligned, plain basis-first backward).  Applies when one
+// workgroup sees all of Fout (64 or 128 columns) and all (k, f) tiles (<= 4 waves) and the W^T panel keeps two
+// workgroups per CU: the small layers of the path (north-star shape 32 -> 64, K = 3).  Returns 1 when it took the launch.
+int dsw_wgrad_dgrad_fused_try_launch(WgradParams& P, int64_t max_slabs, int64_t* S_out, hipStream_t stream, int* rc) {
+    static const char* x3env = getenv("DSW_GEMM_X3");
+    if (x3env && x3env[0] == '0') return 0;
+    static const char* fenv = getenv("DSW_BWD_FUSED");   // "0": separate dgrad and wgrad launches (A-B)
+    if (fenv && fenv[0] == '0') return 0;
+    if (P.dy_planes > 1 || !P.W || !P.G0 || (P.K > 1 && !P.Grest)) return 0;
+    const int ntiles = P.K * P.tiles_per_plane;
+    if (ntiles < 3 || ntiles > 4 || P.Fin % 32 != 0) return 0;   // 1-2 wave workgroups would spill registers
+    if (P.Fout != 64) return 0;                          // one 64-column o-tile (128 would need nw >= 3 and 2x the panel)
+#define DSW_WF(NW_)                                                                                        \
+    case NW_:                                                                                              \
+        *rc = launch_wx3<false, 3, NW_, 2, true>(P, 1, 1, max_slabs, S_out, stream);                       \
+        return 1;
+    switch (ntiles) {
+        DSW_WF(3) DSW_WF(4)
+    }
+#undef DSW_WF
     return 0;
 }
