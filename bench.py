@@ -35,6 +35,8 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
 
+GRAPH_STEPS = 10   # steps per captured graph on a single GPU (see main)
+
 WORKLOADS = {
     "ns": dict(nside=64, K=3, fin=32, fout=64, batch=16, dtype="f32"),
     "c3": dict(nside=64, K=5, fin=64, fout=128, batch=16, dtype="bf16"),
@@ -298,6 +300,7 @@ def main():
     # them.  Capture one fwd+bwd into a HIP graph and replay it (same kernels, same work, same buffers); the gradient
     # all-reduce stays outside the graph.  Falls back to eager launches if capture is not possible.
     graph = None
+    graph_multi = None
     if not args.no_graph:
         try:
             side = torch.cuda.Stream()
@@ -312,10 +315,21 @@ def main():
                 step()
             torch.cuda.synchronize()
             graph = g
+            # single GPU: consecutive graph launches leave the GPU idle for ~40 us (hipGraphLaunch latency), 8 % of
+            # this step; a second graph holding GRAPH_STEPS whole steps amortises it.  With N > 1 every step is
+            # followed by the gradient all-reduce, so steps stay one graph each.
+            if world == 1 and args.steps >= GRAPH_STEPS:
+                gm = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gm):
+                    for _ in range(GRAPH_STEPS):
+                        step()
+                torch.cuda.synchronize()
+                graph_multi = gm
         except Exception as exc:  # noqa: BLE001 - any capture problem -> eager
             if rank == 0:
                 print("bench: HIP graph capture unavailable (%s); running eagerly" % type(exc).__name__, file=sys.stderr)
             graph = None
+            graph_multi = None
             torch.cuda.synchronize()
 
     def full_step():
@@ -325,15 +339,22 @@ def main():
             step()
         sync_grads()
 
-    for _ in range(args.warmup):
-        full_step()
+    def run_steps(n):
+        """exactly n steps"""
+        if graph_multi is not None:
+            for _ in range(n // GRAPH_STEPS):
+                graph_multi.replay()
+            n = n % GRAPH_STEPS
+        for _ in range(n):
+            full_step()
+
+    run_steps(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        full_step()
+    run_steps(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -362,7 +383,8 @@ def main():
             "knn": 20 if args.workload == "c5" else args.knn if args.workload != "unet" else (args.knn if args.knn != 8 else 20),
             "batch_per_gpu": B, "global_batch": B * world, "nodes": V,
             "parallelism": "dp%d (batch shards, flat-bucket RCCL grad all-reduce)" % world,
-            "launch": "hip graph replay of one fwd+bwd" if graph is not None else "eager",
+            "launch": ("hip graph replay, %d steps per graph" % GRAPH_STEPS if graph_multi is not None
+                       else "hip graph replay of one fwd+bwd" if graph is not None else "eager"),
         },
     }
     if rank == 0 and world == 1:

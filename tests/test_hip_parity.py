@@ -178,6 +178,11 @@ CASES = [
     (192, 3, 96, 40, 5, True, "healpix"),     # K = 5, Fout not a multiple of 32
     (1000, 2, 48, 20, 3, True, "irregular"),  # non-symmetric operator: pins L vs L^T in both directions
     (3072, 4, 256, 128, 3, True, "healpix"),  # decoder shape of the UNet
+    # shapes of the fused dgrad + wgrad pass (fp32, Fout = 64, 3-4 (k, f) tiles)
+    (192, 2, 32, 64, 4, True, "healpix"),
+    (768, 2, 64, 64, 2, False, "healpix"),
+    (1000, 3, 32, 64, 3, True, "irregular"),  # N % 32 != 0 -> falls back to the separate kernels; same answer
+    (1024, 2, 32, 64, 3, True, "irregular"),
 ]
 
 
