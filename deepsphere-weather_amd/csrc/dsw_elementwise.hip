@@ -1,0 +1,166 @@
+// Elementwise pieces of the residual block around the Chebyshev convolutions (my_models_graph.py:205-216):
+//   forward   y = w * c + r            (ReZero scale of the conv stack's output + residual branch), one pass
+//   backward  grad_c = w * g,  grad_w = sum(g * c)   (one pass over g and c + a tiny deterministic second stage);
+//             grad_r = g needs no kernel.
+// The reference does this with an in-place mul and an in-place add (two passes forward; mul, mul, reduce backward).
+// Pure streaming kernels: 16 bytes per lane, grid-stride, HBM-bound.
+#include "dsw_common.h"
+#include "../../include/dsw_hip.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+constexpr int EW_MAX_BLOCKS = 2048;   // also the size of the partial-sum buffer the caller provides (floats)
+
+template <bool BF16>
+struct Ew {
+    static constexpr int V = BF16 ? 8 : 4;   // elements per 16 bytes
+    static __device__ __forceinline__ void load(const void* p, size_t i, float (&v)[V]) {
+        const uint4 t = *reinterpret_cast<const uint4*>(static_cast<const char*>(p) + i * (BF16 ? 2 : 4));
+        if constexpr (BF16) {
+            const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+        } else {
+            v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
+        }
+    }
+    static __device__ __forceinline__ void store(void* p, size_t i, const float (&v)[V]) {
+        uint4 t;
+        if constexpr (BF16) {
+            t.x = f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16); t.y = f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            t.z = f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16); t.w = f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+        } else {
+            t = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+        }
+        *reinterpret_cast<uint4*>(static_cast<char*>(p) + i * (BF16 ? 2 : 4)) = t;
+    }
+    static __device__ __forceinline__ float load1(const void* p, size_t i) {
+        if constexpr (BF16) return bf16_to_f32(static_cast<const uint16_t*>(p)[i]);
+        else return static_cast<const float*>(p)[i];
+    }
+    static __device__ __forceinline__ void store1(void* p, size_t i, float v) {
+        if constexpr (BF16) static_cast<uint16_t*>(p)[i] = f32_to_bf16(v);
+        else static_cast<float*>(p)[i] = v;
+    }
+};
+
+template <bool BF16>
+__global__ __launch_bounds__(EW_THREADS) void rezero_fwd_kernel(const void* c, const void* r, const void* wp, void* y, long n) {
+    using E = Ew<BF16>;
+    constexpr int V = E::V;
+    const float w = E::load1(wp, 0);
+    const long nv = n / V;
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < nv; i += (long)gridDim.x * EW_THREADS) {
+        float a[V], b[V], o[V];
+        E::load(c, (size_t)i * V, a);
+        E::load(r, (size_t)i * V, b);
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] = fmaf(w, a[j], b[j]);
+        E::store(y, (size_t)i * V, o);
+    }
+    if (blockIdx.x == 0)
+        for (long i = nv * V + threadIdx.x; i < n; i += EW_THREADS)
+            E::store1(y, i, fmaf(w, E::load1(c, i), E::load1(r, i)));
+}
+
+// grad_c = w * g; partial[block] = sum over the block's elements of g * c (fixed order -> reproducible)
+template <bool BF16>
+__global__ __launch_bounds__(EW_THREADS) void rezero_bwd_kernel(const void* g, const void* c, const void* wp, void* gc,
+                                                                float* partial, long n) {
+    using E = Ew<BF16>;
+    constexpr int V = E::V;
+    __shared__ float red[EW_THREADS / 64];
+    const float w = E::load1(wp, 0);
+    const long nv = n / V;
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < nv; i += (long)gridDim.x * EW_THREADS) {
+        float a[V], b[V], o[V];
+        E::load(g, (size_t)i * V, a);
+        E::load(c, (size_t)i * V, b);
+#pragma unroll
+        for (int j = 0; j < V; ++j) { o[j] = w * a[j]; acc = fmaf(a[j], b[j], acc); }
+        if (gc != nullptr) E::store(gc, (size_t)i * V, o);
+    }
+    if (blockIdx.x == 0)
+        for (long i = nv * V + threadIdx.x; i < n; i += EW_THREADS) {
+            const float a = E::load1(g, i);
+            if (gc != nullptr) E::store1(gc, i, w * a);
+            acc = fmaf(a, E::load1(c, i), acc);
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < EW_THREADS / 64; ++k) s += red[k];
+        partial[blockIdx.x] = s;
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void rezero_bwd_final_kernel(const float* partial, int nblocks, void* gw) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) Ew<BF16>::store1(gw, 0, red[0]);
+}
+
+static int ew_blocks(long n, int v) {
+    long b = (n / v + EW_THREADS - 1) / EW_THREADS;
+    if (b < 1) b = 1;
+    if (b > EW_MAX_BLOCKS) b = EW_MAX_BLOCKS;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t dsw_rezero_residual_workspace_bytes(void) { return (int64_t)EW_MAX_BLOCKS * 4; }
+
+int dsw_rezero_residual_fwd(const void* c, const void* r, const void* w, void* y, int64_t n, int dtype,
+                            dsw_stream_t stream) {
+    if (n < 0) return DSW_ERR_BAD_ARG;
+    if (n == 0) return DSW_OK;
+    if (!c || !r || !w || !y) return DSW_ERR_BAD_ARG;
+    if (!dsw_aligned16(c) || !dsw_aligned16(r) || !dsw_aligned16(y)) return DSW_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DSW_F32)
+        hipLaunchKernelGGL(rezero_fwd_kernel<false>, dim3(ew_blocks(n, 4)), dim3(EW_THREADS), 0, s, c, r, w, y, (long)n);
+    else if (dtype == DSW_BF16)
+        hipLaunchKernelGGL(rezero_fwd_kernel<true>, dim3(ew_blocks(n, 8)), dim3(EW_THREADS), 0, s, c, r, w, y, (long)n);
+    else
+        return DSW_ERR_BAD_DTYPE;
+    return dsw_check_launch();
+}
+
+int dsw_rezero_residual_bwd(const void* g, const void* c, const void* w, void* grad_c, void* grad_w, void* workspace,
+                            int64_t workspace_bytes, int64_t n, int dtype, dsw_stream_t stream) {
+    if (n < 0) return DSW_ERR_BAD_ARG;
+    if (!g || !c || !w || !grad_w) return DSW_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < dsw_rezero_residual_workspace_bytes()) return DSW_ERR_WORKSPACE;
+    if (!dsw_aligned16(g) || !dsw_aligned16(c) || (grad_c && !dsw_aligned16(grad_c))) return DSW_ERR_ALIGN;
+    if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = static_cast<float*>(workspace);
+    const int nb = ew_blocks(n, dtype == DSW_BF16 ? 8 : 4);
+    if (dtype == DSW_F32) {
+        hipLaunchKernelGGL(rezero_bwd_kernel<false>, dim3(nb), dim3(EW_THREADS), 0, s, g, c, w, grad_c, partial, (long)n);
+        hipLaunchKernelGGL(rezero_bwd_final_kernel<false>, dim3(1), dim3(256), 0, s, partial, nb, grad_w);
+    } else {
+        hipLaunchKernelGGL(rezero_bwd_kernel<true>, dim3(nb), dim3(EW_THREADS), 0, s, g, c, w, grad_c, partial, (long)n);
+        hipLaunchKernelGGL(rezero_bwd_final_kernel<true>, dim3(1), dim3(256), 0, s, partial, nb, grad_w);
+    }
+    return dsw_check_launch();
+}
+
+}  // extern "C"

@@ -255,6 +255,28 @@ class _HipBackend:
         return dx, (dw if need_dw else None), (db if need_db else None)
 
 
+    def rezero_fwd(self, c, r, w):
+        lib = _native.load()
+        y = torch.empty_like(c)
+        with torch.cuda.device(c.device):
+            rc = lib.dsw_rezero_residual_fwd(c.data_ptr(), r.data_ptr(), w.data_ptr(), y.data_ptr(), c.numel(),
+                                             _DTYPES[c.dtype], _stream(c))
+        _native.check(rc, "dsw_rezero_residual_fwd")
+        return y
+
+    def rezero_bwd(self, g, c, w, need_c):
+        lib = _native.load()
+        gc = torch.empty_like(g) if need_c else None
+        gw = torch.empty_like(w)
+        nb = int(lib.dsw_rezero_residual_workspace_bytes())
+        ws = torch.empty((nb,), dtype=torch.uint8, device=g.device)
+        with torch.cuda.device(g.device):
+            rc = lib.dsw_rezero_residual_bwd(g.data_ptr(), c.data_ptr(), w.data_ptr(), _ptr(gc), gw.data_ptr(),
+                                             ws.data_ptr(), nb, g.numel(), _DTYPES[g.dtype], _stream(g))
+        _native.check(rc, "dsw_rezero_residual_bwd")
+        return gc, gw
+
+
 _HIP = _HipBackend()
 _test_backend = None
 
@@ -318,6 +340,24 @@ class _ChebConvFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _RezeroResidualFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, c, r, w):
+        be = _backend_for(c)
+        cc, rc = c.contiguous(), r.contiguous()
+        ctx.save_for_backward(cc, w)
+        ctx.be = be
+        return be.rezero_fwd(cc, rc, w)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        c, w = ctx.saved_tensors
+        g = g.contiguous()
+        gc, gw = ctx.be.rezero_bwd(g, c, w, ctx.needs_input_grad[0])
+        return gc, (g if ctx.needs_input_grad[1] else None), (gw if ctx.needs_input_grad[2] else None)
+
+
 class _RemapFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, op):
@@ -354,6 +394,15 @@ def dense_mix(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
     lead = x.shape[:-1]
     y = _ChebConvFn.apply(x.reshape(1, -1, x.shape[-1]), weight.unsqueeze(1), bias, None)
     return y.reshape(*lead, weight.shape[1])
+
+
+def rezero_residual(c: torch.Tensor, r: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """``w * c + r`` with ``w`` a one-element tensor (the ReZero parameter): the epilogue of the residual block
+    (my_models_graph.py:211-215) in one pass forward and one pass + a tiny reduction backward."""
+    if c.shape != r.shape or w.numel() != 1:
+        raise ValueError("expected c and r of one shape and a one-element w")
+    _check_dtype(c, r, w)
+    return _RezeroResidualFn.apply(c, r, w)
 
 
 def sparse_remap(op: CsrOperator, x: torch.Tensor) -> torch.Tensor:

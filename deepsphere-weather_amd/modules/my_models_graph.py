@@ -121,8 +121,8 @@ class ResBlock(torch.nn.Module):
         y = x
         for name in self.conv_names_list:
             y = getattr(self, name)(y)
-        if self.rezero:
-            y *= self.rezero_weight
+        if self.rezero:   # rezero_weight * y + residual in one pass (the reference: in-place mul, then in-place add)
+            return dsw_functional.rezero_residual(y, self.res_connection(x), self.rezero_weight)
         y += self.res_connection(x)
         return y
 

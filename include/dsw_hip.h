@@ -147,6 +147,17 @@ int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* 
                  int64_t workspace_bytes, int64_t B, int64_t Fin, int64_t Fout, int64_t K,
                  int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan_t);
 
+/* Residual block epilogue (my_models_graph.py:205-216: `x_out *= rezero_weight; x_out += res_connection(x)`):
+ *   forward   y[i] = w * c[i] + r[i]        (w: ONE device scalar of the data dtype - the ReZero parameter)
+ *   backward  grad_c[i] = w * g[i] (grad_c may be NULL),  grad_w = sum_i g[i] * c[i]   (deterministic two-stage sum);
+ *             the gradient of r is g itself.
+ * n elements, 16-byte aligned tensors; y may alias c or r.  workspace: dsw_rezero_residual_workspace_bytes(). */
+int64_t dsw_rezero_residual_workspace_bytes(void);
+int dsw_rezero_residual_fwd(const void* c, const void* r, const void* w, void* y, int64_t n, int dtype,
+                            dsw_stream_t stream);
+int dsw_rezero_residual_bwd(const void* g, const void* c, const void* w, void* grad_c, void* grad_w,
+                            void* workspace, int64_t workspace_bytes, int64_t n, int dtype, dsw_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,3 +52,11 @@ class OracleBackend:
             torch.from_numpy(dw).to(w.dtype) if need_dw else None,
             torch.from_numpy(db).to(w.dtype) if need_db else None,
         )
+
+    def rezero_fwd(self, c, r, w):
+        return (w.double() * c.double() + r.double()).to(c.dtype)
+
+    def rezero_bwd(self, g, c, w, need_c):
+        gc = (w.double() * g.double()).to(g.dtype) if need_c else None
+        gw = (g.double() * c.double()).sum().reshape(w.shape).to(w.dtype)
+        return gc, gw

@@ -562,3 +562,25 @@ def test_c_abi_from_a_c_client(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(out.stdout)
     assert out.returncode == 0 and "C-ABI CLIENT: PASS" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("shape,dt", [((3, 768, 64), torch.float32), ((2, 193, 7), torch.float32), ((4, 3072, 128), torch.bfloat16),
+                                      ((1, 5, 3), torch.bfloat16)])
+def test_rezero_residual(shape, dt):
+    """y = w * c + r and its gradients against fp64 (odd sizes exercise the scalar tails)."""
+    from dsw_amd import functional as F_
+
+    torch.manual_seed(9)
+    c = torch.randn(*shape, device=DEV, dtype=dt, requires_grad=True)
+    r = torch.randn(*shape, device=DEV, dtype=dt, requires_grad=True)
+    w = torch.tensor([0.37], device=DEV, dtype=dt, requires_grad=True)
+    g = torch.randn(*shape, device=DEV, dtype=dt)
+    y = F_.rezero_residual(c, r, w)
+    y.backward(g)
+    c64, r64, w64, g64 = (t.detach().double().cpu() for t in (c, r, w, g))
+    tol = TOL_F64 if dt == torch.float32 else TOL_BF16
+    assert orc.max_rel_err(y, (w64 * c64 + r64).numpy()) <= tol
+    assert orc.max_rel_err(c.grad, (w64 * g64).numpy()) <= tol
+    assert torch.equal(r.grad, g)
+    ref_gw = float((g64 * c64).sum())
+    assert abs(float(w.grad) - ref_gw) <= (1e-5 if dt == torch.float32 else 2e-2) * max(1.0, float((g64 * c64).abs().sum()) ** 0.5 * 10)
