@@ -761,12 +761,13 @@ int dsw_wgrad_mixfirst_launch(const void* X, const void* dY, const void* D, void
 
 // Backward GEMM work of the plain (basis-first) layer in one launch: dW / db partials AND the dgrad planes G_k
 // (dsw_wgrad_x3.hip, FUSE variant) followed by the partial reduce.  Returns 1 when it took the work (*rc = status).
-int dsw_wgrad_dgrad_fused_try_launch(WgradParams& P, int64_t max_slabs, int64_t* S_out, hipStream_t stream, int* rc);
+int dsw_wgrad_dgrad_fused_try_launch(WgradParams& P, int bf16, int64_t max_slabs, int64_t* S_out, hipStream_t stream,
+                                     int* rc);
 
 int dsw_bwd_gemm_fused_try(const void* X, const void* T, const void* W, const void* dY, void* dW, void* db, void* G0,
                            void* Grest, float* partial, int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype,
                            hipStream_t stream, int* rc) {
-    if (dtype != DSW_F32 || N <= 0 || !dW || !G0) return 0;
+    if ((dtype != DSW_F32 && dtype != DSW_BF16) || N <= 0 || !dW || !G0) return 0;
     WgradParams P{};
     P.X = X; P.T = T; P.plane_stride = (size_t)N * Fin; P.dY = dY; P.partial = partial;
     P.N = N; P.Fin = (int)Fin; P.Fout = (int)Fout; P.K = (int)K;
@@ -777,14 +778,18 @@ int dsw_bwd_gemm_fused_try(const void* X, const void* T, const void* W, const vo
     P.dy_vec = (Fout % 4 == 0) && (((uintptr_t)dY & am) == 0);
     const bool aligned = P.t_vec && P.dy_vec && (Fin % 32 == 0) && (Fout % BN == 0) && (N % WR == 0) &&
                          (((uintptr_t)G0 & am) == 0) && (K == 1 || ((uintptr_t)Grest & am) == 0);
-    if (!aligned) return 0;
+    if (!aligned || (dtype == DSW_BF16 && (Fin % 8 != 0 || P.plane_stride % 8 != 0))) return 0;
     int64_t S = 0;
-    if (!dsw_wgrad_dgrad_fused_try_launch(P, wgrad_max_slabs(Fin, Fout, K), &S, stream, rc)) return 0;
+    if (!dsw_wgrad_dgrad_fused_try_launch(P, dtype == DSW_BF16 ? 1 : 0, wgrad_max_slabs(Fin, Fout, K), &S, stream, rc)) return 0;
     if (*rc != DSW_OK) return 1;
     const long total = (long)(K * Fin + 1) * Fout;
     dim3 rgrid((unsigned)((total + 31) / 32));
-    hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, stream, partial, (int)S, (int)Fin, (int)Fout,
-                       (int)K, dW, db, (int)K, 0);
+    if (dtype == DSW_F32)
+        hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, stream, partial, (int)S, (int)Fin,
+                           (int)Fout, (int)K, dW, db, (int)K, 0);
+    else
+        hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, stream, partial, (int)S, (int)Fin,
+                           (int)Fout, (int)K, dW, db, (int)K, 0);
     *rc = dsw_check_launch();
     return 1;
 }

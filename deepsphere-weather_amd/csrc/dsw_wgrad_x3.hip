@@ -310,8 +310,12 @@ __global__ __launch_bounds__(64 * NW, FUSE ? 2 : 1) void cheb_wgrad_x3_kernel(co
 
 // bf16 storage: the operands ARE bf16, so the tile image is a raw copy - 64-row chunks (the same bytes per chunk
 // and 16 B per lane as the fp32 path), ds_write_b128 staging, one MFMA term.  Same tiling / slabs / ring otherwise.
-template <int NW, int NO>
-__global__ __launch_bounds__(64 * NW) void cheb_wgrad_bf16_kernel(const WgradParams P) {
+// FUSE: as in the fp32 kernel - the workgroup also writes the dgrad tile G_k[n, f] = sum_o dY[n, o] W[f, k, o] of the
+// rows it streams (needs one o-tile covering all of Fout).  The W^T panel is a raw bf16 copy; the wave's G tile is
+// converted with v_cvt_pk and transposed through the wave's own T rows (dead after the wgrad MFMAs of the chunk) so
+// that it leaves as 16 bytes per lane.
+template <int NW, int NO, bool FUSE = false>
+__global__ __launch_bounds__(64 * NW, FUSE ? 2 : 1) void cheb_wgrad_bf16_kernel(const WgradParams P) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     constexpr int NT_ = 64 * NW;
     constexpr int BNO = 32 * NO;
@@ -321,12 +325,14 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_bf16_kernel(const WgradPar
     constexpr int RD = (DV + NT_ - 1) / NT_;
     constexpr int G = NT_ / CO;
     static_assert(NT_ % CO == 0, "column-sum layout");
-    constexpr int PF = 3;
+    constexpr int PF = FUSE ? 2 : 3;
     constexpr int BLKB = WRB * 32;                      // one [64 n][32 ch] block (4 KiB)
     extern __shared__ __attribute__((aligned(16))) unsigned short xs[];
     unsigned short* TsT = xs;                           // [NW][64 n][32 f]
     unsigned short* DsT = xs + (size_t)NW * BLKB;       // [NO][64 n][32 o]
     float* red = reinterpret_cast<float*>(DsT + (size_t)NO * BLKB);   // [G][BNO]
+    constexpr int WKS = BNO + 8;                        // bf16 elements per W^T panel row
+    unsigned short* Wp = reinterpret_cast<unsigned short*>(red + (size_t)G * BNO);   // FUSE: [NW * 32 cols][WKS]
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -347,6 +353,19 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_bf16_kernel(const WgradPar
     const uint16_t* dY = zk == 0 ? static_cast<const uint16_t*>(P.dY)
                                  : static_cast<const uint16_t*>(P.dY1) + (size_t)(zk - 1) * P.dy_plane_stride;
 
+    if constexpr (FUSE) {
+        const uint16_t* Wsrc = static_cast<const uint16_t*>(P.W);
+        for (int e = tid; e < NW * 32 * BNO; e += NT_) {
+            const int c = e / BNO, o = e - c * BNO;
+            const int t_ = blockIdx.y * NW + (c >> 5);
+            unsigned short v = 0;
+            if (t_ < ntiles) {
+                const int kk = t_ / P.tiles_per_plane, ff = (t_ - kk * P.tiles_per_plane) * 32 + (c & 31);
+                v = Wsrc[((size_t)ff * P.K + kk) * P.Fout + o];
+            }
+            Wp[c * WKS + o] = v;
+        }
+    }
     f32x16 acc[NO];
 #pragma unroll
     for (int t = 0; t < NO; ++t)
@@ -359,7 +378,7 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_bf16_kernel(const WgradPar
         for (int j = 0; j < 8; ++j) cs[i][j] = 0.f;
 
     const int tr = lane >> 2, tc8 = (lane & 3) * 8;   // T tile (per wave): rows tr + 16*i (i<4), channels tc8..+7
-    u32x4 rt0[4], rt1[4], rt2[4], rd0[RD], rd1[RD], rd2[RD];
+    u32x4 rt0[4], rt1[4], rt2[4], rd0[RD], rd1[RD], rd2[RD];   // (the third slot is dead code when PF == 2)
     auto fetch = [&](long n0, u32x4 (&drt)[4], u32x4 (&drd)[RD]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -375,7 +394,7 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_bf16_kernel(const WgradPar
     if (n_chunks > 0) {
         fetch(n_begin, rt0, rd0);
         fetch(n_begin + (1 < n_chunks ? 1 : n_chunks - 1) * WRB, rt1, rd1);
-        fetch(n_begin + (2 < n_chunks ? 2 : n_chunks - 1) * WRB, rt2, rd2);
+        if constexpr (PF == 3) fetch(n_begin + (2 < n_chunks ? 2 : n_chunks - 1) * WRB, rt2, rd2);
     }
     const long n_pad = (n_chunks + PF - 1) / PF * PF;
     const int frag_off = (((lane & 15) >> 2) + 8 * half) * 32 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
@@ -421,12 +440,51 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_bf16_kernel(const WgradPar
                 for (int t = 0; t < NO; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, read_frag_tr(db + t * BLKB + 16 * s2 * 32), acc[t], 0, 0, 0);
             }
+            if constexpr (FUSE) {
+                f32x16 g0, g1;     // rows 0..31 / 32..63 of the chunk x this wave's 32 (k, f) channels
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { g0[i] = 0.f; g1[i] = 0.f; }
+                const unsigned short* wb = Wp + (size_t)(wave * 32 + l31) * WKS + 8 * half;
+#pragma unroll
+                for (int s = 0; s < BNO / 16; ++s) {
+                    const unsigned short* ap = DsT + ((16 * s) >> 5) * BLKB + (size_t)l31 * 32 + ((16 * s) & 31) + 8 * half;
+                    const bf16x8_t bw = *reinterpret_cast<const bf16x8_t*>(wb + 16 * s);
+                    g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(ap), bw, g0, 0, 0, 0);
+                    g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(ap + 32 * 32), bw, g1, 0, 0, 0);
+                }
+                // bf16 tile -> the wave's own T rows (its fragments of this chunk are consumed) -> 16 B per lane out
+                typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+                typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int rr = (i & 3) + 8 * (i >> 2) + 4 * half;
+                    const f32x2_ v = {g0[i], g1[i]};
+                    const bf16x2_ pk = __builtin_convertvector(v, bf16x2_);
+                    const unsigned int u = __builtin_bit_cast(unsigned int, pk);
+                    tw[rr * 32 + l31] = (unsigned short)(u & 0xffffu);
+                    tw[(rr + 32) * 32 + l31] = (unsigned short)(u >> 16);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                uint16_t* Gp = (k == 0) ? static_cast<uint16_t*>(P.G0)
+                                        : static_cast<uint16_t*>(P.Grest) + (size_t)(k - 1) * P.plane_stride;
+                const long nrow = n_begin + ci * WRB;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rr = (lane >> 2) + 16 * j, c8 = (lane & 3) * 8;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(tw + rr * 32 + c8);
+                    *reinterpret_cast<u32x4*>(Gp + (size_t)(nrow + rr) * P.Fin + f0 + c8) = v;
+                }
+            }
         }
     };
     for (long cb = 0; cb < n_pad; cb += PF) {
         stage(std::integral_constant<int, 0>{}, cb);
         stage(std::integral_constant<int, 1>{}, cb + 1);
-        stage(std::integral_constant<int, 2>{}, cb + 2);
+        if constexpr (PF == 3) stage(std::integral_constant<int, 2>{}, cb + 2);
     }
 
     float* out = P.partial + (size_t)blockIdx.x * (size_t)(Kd + 1) * P.Fout;
@@ -460,13 +518,13 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_bf16_kernel(const WgradPar
     }
 }
 
-template <int NW, int NO>
+template <int NW, int NO, bool FUSE = false>
 int launch_wbf16(WgradParams& P, int groups, int otiles, int64_t max_slabs, int64_t* S_out, hipStream_t stream) {
     constexpr int NT_ = 64 * NW;
     constexpr int BNO = 32 * NO;
     constexpr int G = NT_ / (BNO / 8);
-    const size_t lds = ((size_t)NW + NO) * 64 * 32 * 2 + (size_t)G * BNO * 4;
-    const void* kfn = (const void*)cheb_wgrad_bf16_kernel<NW, NO>;
+    const size_t lds = ((size_t)NW + NO) * 64 * 32 * 2 + (size_t)G * BNO * 4 + (FUSE ? (size_t)NW * 32 * (BNO + 8) * 2 : 0);
+    const void* kfn = (const void*)cheb_wgrad_bf16_kernel<NW, NO, FUSE>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DSW_ERR_LAUNCH;
@@ -484,7 +542,7 @@ int launch_wbf16(WgradParams& P, int groups, int otiles, int64_t max_slabs, int6
     P.rows_per_slab = rps;
     *S_out = S;
     dim3 grid((unsigned)S, (unsigned)groups, (unsigned)zdim);
-    hipLaunchKernelGGL((cheb_wgrad_bf16_kernel<NW, NO>), grid, dim3(NT_), lds, stream, P);
+    hipLaunchKernelGGL((cheb_wgrad_bf16_kernel<NW, NO, FUSE>), grid, dim3(NT_), lds, stream, P);
     return dsw_check_launch();
 }
 
@@ -567,15 +625,35 @@ int dsw_wgrad_x3_try_launch(WgradParams& P, int bf16, int64_t max_slabs, int64_t
 // wgrad with the dgrad of the same rows fused in (fp32, aligned, plain basis-first backward).  Applies when one
 // workgroup sees all of Fout (64 or 128 columns) and all (k, f) tiles (<= 4 waves) and the W^T panel keeps two
 // workgroups per CU: the small layers of the path (north-star shape 32 -> 64, K = 3).  Returns 1 when it took the launch.
-int dsw_wgrad_dgrad_fused_try_launch(WgradParams& P, int64_t max_slabs, int64_t* S_out, hipStream_t stream, int* rc) {
+int dsw_wgrad_dgrad_fused_try_launch(WgradParams& P, int bf16, int64_t max_slabs, int64_t* S_out, hipStream_t stream,
+                                     int* rc) {
     static const char* x3env = getenv("DSW_GEMM_X3");
     if (x3env && x3env[0] == '0') return 0;
     static const char* fenv = getenv("DSW_BWD_FUSED");   // "0": separate dgrad and wgrad launches (A-B)
     if (fenv && fenv[0] == '0') return 0;
     if (P.dy_planes > 1 || !P.W || !P.G0 || (P.K > 1 && !P.Grest)) return 0;
     const int ntiles = P.K * P.tiles_per_plane;
-    if (ntiles < 3 || ntiles > 4 || P.Fin % 32 != 0) return 0;   // 1-2 wave workgroups would spill registers
-    if (P.Fout != 64) return 0;                          // one 64-column o-tile (128 would need nw >= 3 and 2x the panel)
+    if (P.Fin % 32 != 0) return 0;
+    if (bf16) {
+        // raw-copy kernel: whole 64-row chunks, one o-tile = all of Fout (64 or 128 columns), 3..8 waves per group
+        if (P.N % 64 != 0 || (P.Fout != 64 && P.Fout != 128)) return 0;
+        const int groups = (ntiles + 7) / 8;
+        const int nw = (ntiles + groups - 1) / groups;
+        if (nw < 3) return 0;
+        const bool wide = P.Fout == 128;
+#define DSW_WFB(NW_)                                                                                       \
+    case NW_:                                                                                              \
+        *rc = wide ? launch_wbf16<NW_, 4, true>(P, groups, 1, max_slabs, S_out, stream)                    \
+                   : launch_wbf16<NW_, 2, true>(P, groups, 1, max_slabs, S_out, stream);                   \
+        return 1;
+        switch (nw) {
+            DSW_WFB(3) DSW_WFB(4) DSW_WFB(5) DSW_WFB(6) DSW_WFB(7) DSW_WFB(8)
+        }
+#undef DSW_WFB
+        return 0;
+    }
+    if (ntiles < 3 || ntiles > 4) return 0;               // fp32: 1-2 wave workgroups would spill registers
+    if (P.Fout != 64) return 0;                          // one 64-column o-tile (128 would need 2x the panel and registers)
 #define DSW_WF(NW_)                                                                                        \
     case NW_:                                                                                              \
         *rc = launch_wx3<false, 3, NW_, 2, true>(P, 1, 1, max_slabs, S_out, stream);                       \
