@@ -430,7 +430,7 @@ def test_fused_recurrences_equal_unfused(K):
     assert orc.max_rel_err(res[True][0], Tref) <= TOL_F64
 
 
-@pytest.mark.parametrize("N,Fin,Fout", [(768 * 3, 256, 128), (1000, 48, 20), (64, 512, 256)])
+@pytest.mark.parametrize("N,Fin,Fout", [(768 * 3, 256, 128), (1000, 48, 20), (64, 512, 256), (768 * 3, 128, 64), (1024, 96, 64)])
 def test_dense_mix_vs_f64(N, Fin, Fout):
     """K = 1 channel mix (residual branch of ResBlock) against an fp64 matmul: forward, dX, dW, db."""
     from dsw_amd import functional as F_
