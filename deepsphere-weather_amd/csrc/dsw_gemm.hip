@@ -531,7 +531,9 @@ int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* 
     P.Bsrc = W; P.b_sp = Fout; P.b_sq = 0; P.b_skd = K * Fout; P.b_sn = 1;
     P.C0 = Y; P.C1 = Y; P.c_plane_stride = 0; P.ldc = (int)Fout; P.n_planes_c = 1; P.n_per_plane = (int)Fout;
     P.bias = bias; P.M = N;
+#ifdef DSW_ABLATION   // build with -DDSW_ABLATION to enable the DSW_DBG ablation knobs (they produce wrong results by design)
     { static const char* d = getenv("DSW_DBG"); P.dbg = d ? atoi(d) : 0; }
+#endif
     const uintptr_t am = (uintptr_t)(4 * es) - 1;
     P.a_vec = (Fin % 4 == 0) && (((uintptr_t)X & am) == 0) && (K == 1 || ((uintptr_t)T & am) == 0);
     if (dtype == DSW_F32) return launch_ts_gemm<false>(P, stream);
@@ -551,7 +553,9 @@ int dsw_mix_dgrad_launch(const void* dY, const void* W, void* G0, void* Grest, i
     P.C0 = G0; P.C1 = Grest; P.c_plane_stride = (size_t)N * Fin; P.ldc = (int)Fin; P.n_planes_c = (int)K;
     P.n_per_plane = (int)Fin;
     P.bias = nullptr; P.M = N;
+#ifdef DSW_ABLATION   // build with -DDSW_ABLATION to enable the DSW_DBG ablation knobs (they produce wrong results by design)
     { static const char* d = getenv("DSW_DBG"); P.dbg = d ? atoi(d) : 0; }
+#endif
     const uintptr_t am = (uintptr_t)(4 * es) - 1;
     P.a_vec = (Fout % 4 == 0) && (((uintptr_t)dY & am) == 0);
     if (dtype == DSW_F32) return launch_ts_gemm<false>(P, stream);

@@ -63,7 +63,7 @@ struct TsGemmParams {
     int bias_plane0;        // 1: the bias belongs to output plane 0 only (mix-first forward: Z_0 = X W_0 + b)
     long M;
     int a_vec;              // 1 if float4/bf16x4 loads of A are legal
-    int dbg;                // diagnostics (DSW_DBG env): 1 = skip the epilogue stores, 2 = skip the MFMAs
+    int dbg;                // ablation builds only (-DDSW_ABLATION + DSW_DBG env): 1 = skip the epilogue stores, 2 = skip the MFMAs; else 0
 };
 
 
@@ -110,7 +110,7 @@ struct WgradParams {
     const void* W;
     void* G0;
     void* Grest;
-    int dbg;                // diagnostics (DSW_DBG env): 2 = skip MFMAs, 3 = skip LDS staging, 4 = skip refetch
+    int dbg;                // reserved for ablation builds; 0
 };
 
 
