@@ -318,7 +318,7 @@ def main():
             # single GPU: consecutive graph launches leave the GPU idle for ~40 us (hipGraphLaunch latency), 8 % of
             # this step; a second graph holding GRAPH_STEPS whole steps amortises it.  With N > 1 every step is
             # followed by the gradient all-reduce, so steps stay one graph each.
-            if world == 1 and args.steps >= GRAPH_STEPS:
+            if world == 1 and args.steps >= GRAPH_STEPS and os.environ.get("DSW_FORCE_GRAD_SYNC") != "1":
                 gm = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gm):
                     for _ in range(GRAPH_STEPS):

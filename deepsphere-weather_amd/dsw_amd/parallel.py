@@ -24,7 +24,8 @@ def init_from_env(backend: str | None = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("DSW_FORCE_GRAD_SYNC") == "1"   # probe: run the collective path in a 1-rank world
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:   # DSW_DIST_BACKEND=gloo: run the N>1 path of a GPU script on a single-GPU box (tests)
             backend = os.environ.get("DSW_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -61,7 +62,8 @@ class FlatGradAllReduce:
             off += p.numel()
 
     def __call__(self):
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        if not dist.is_initialized() or (dist.get_world_size(self.group) == 1
+                                         and os.environ.get("DSW_FORCE_GRAD_SYNC") != "1"):
             return
         have = [p.grad is not None for p in self.params]
         if all(have):
