@@ -287,3 +287,48 @@ def test_hop2_plan_matches_two_plain_hops():
             r2 = 1.5 * (L @ r1) - U + 0.5 * Z2
             np.testing.assert_allclose(y1, r1, atol=1e-12)
             np.testing.assert_allclose(y2, r2, atol=1e-12)
+
+
+def test_training_driver_config_and_ar_logic():
+    """scripts_training/train_synthetic_state.py host logic: config schema, tensor_info, model factory convention and the
+    autoregressive window update (CPU; a stand-in model, no kernels involved)."""
+    import json
+    import os
+    import sys
+    import types
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts_training"))
+    import train_synthetic_state as drv
+
+    cfg = drv.read_config(os.path.join(root, "configs/UNetSpherical/Healpix_400km/InterpPool-Graph_knn.synthetic.json"))
+    info = drv.synthetic_tensor_info(cfg)
+    assert info["input_n_feature"] == 6 and info["output_n_feature"] == 2 and info["input_n_time"] == 3
+    assert info["input_shape_info"]["dynamic"]["node"] == 12 * 16 ** 2
+
+    class Toy(torch.nn.Module):
+        def __init__(self, tensor_info, knn=3, not_in_config=7):
+            super().__init__()
+            self.knn, self.extra = knn, not_in_config
+            self.scale = torch.nn.Parameter(torch.ones(1))
+
+        def forward(self, x):                      # predicts the dynamic features of the last step, scaled
+            return self.scale * x[:, -1:, :, -2:]
+
+    mod = types.ModuleType("toy_arch")
+    mod.Toy = Toy
+    ms = dict(cfg["model_settings"], architecture_name="Toy", tensor_info=info)
+    model = drv.get_pytorch_model(mod, ms)
+    assert model.knn == 20 and model.extra == 7     # config keys the ctor declares are passed, the rest filtered out
+    with pytest.raises(TypeError):
+        drv.get_pytorch_model("not a module", ms)
+
+    x = torch.arange(2 * 3 * 4 * 6, dtype=torch.float32).reshape(2, 3, 4, 6)
+    targets = [torch.zeros(2, 1, 4, 2) for _ in range(3)]
+    loss = drv.ar_training_step(model, x, targets, n_dyn=2)
+    # iteration 2 sees a window whose last step carries the previous prediction in its dynamic features
+    y0 = x[:, -1:, :, -2:]
+    expect = 3 * torch.mean(y0 ** 2)               # the toy model reproduces the same prediction every iteration
+    assert torch.allclose(loss, expect)
+    loss.backward()
+    assert model.scale.grad is not None
