@@ -46,11 +46,12 @@ struct Ew {
 };
 
 template <bool BF16>
-__global__ __launch_bounds__(EW_THREADS) void rezero_fwd_kernel(const void* c, const void* r, const void* wp, void* y, long n) {
+__global__ __launch_bounds__(EW_THREADS) void rezero_fwd_kernel(const void* c, const void* r, const void* wp, void* y, long n,
+                                                                int vec) {
     using E = Ew<BF16>;
     constexpr int V = E::V;
     const float w = E::load1(wp, 0);
-    const long nv = n / V;
+    const long nv = vec ? n / V : 0;   // vec = 0: some base pointer is not 16-byte aligned -> every element takes the scalar path
     for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < nv; i += (long)gridDim.x * EW_THREADS) {
         float a[V], b[V], o[V];
         E::load(c, (size_t)i * V, a);
@@ -59,20 +60,19 @@ __global__ __launch_bounds__(EW_THREADS) void rezero_fwd_kernel(const void* c, c
         for (int j = 0; j < V; ++j) o[j] = fmaf(w, a[j], b[j]);
         E::store(y, (size_t)i * V, o);
     }
-    if (blockIdx.x == 0)
-        for (long i = nv * V + threadIdx.x; i < n; i += EW_THREADS)
-            E::store1(y, i, fmaf(w, E::load1(c, i), E::load1(r, i)));
+    for (long i = nv * V + (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * EW_THREADS)
+        E::store1(y, i, fmaf(w, E::load1(c, i), E::load1(r, i)));
 }
 
 // grad_c = w * g; partial[block] = sum over the block's elements of g * c (fixed order -> reproducible)
 template <bool BF16>
 __global__ __launch_bounds__(EW_THREADS) void rezero_bwd_kernel(const void* g, const void* c, const void* wp, void* gc,
-                                                                float* partial, long n) {
+                                                                float* partial, long n, int vec) {
     using E = Ew<BF16>;
     constexpr int V = E::V;
     __shared__ float red[EW_THREADS / 64];
     const float w = E::load1(wp, 0);
-    const long nv = n / V;
+    const long nv = vec ? n / V : 0;
     float acc = 0.f;
     for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < nv; i += (long)gridDim.x * EW_THREADS) {
         float a[V], b[V], o[V];
@@ -82,12 +82,11 @@ __global__ __launch_bounds__(EW_THREADS) void rezero_bwd_kernel(const void* g, c
         for (int j = 0; j < V; ++j) { o[j] = w * a[j]; acc = fmaf(a[j], b[j], acc); }
         if (gc != nullptr) E::store(gc, (size_t)i * V, o);
     }
-    if (blockIdx.x == 0)
-        for (long i = nv * V + threadIdx.x; i < n; i += EW_THREADS) {
-            const float a = E::load1(g, i);
-            if (gc != nullptr) E::store1(gc, i, w * a);
-            acc = fmaf(a, E::load1(c, i), acc);
-        }
+    for (long i = nv * V + (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * EW_THREADS) {
+        const float a = E::load1(g, i);
+        if (gc != nullptr) E::store1(gc, i, w * a);
+        acc = fmaf(a, E::load1(c, i), acc);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -115,7 +114,7 @@ __global__ __launch_bounds__(256) void rezero_bwd_final_kernel(const float* part
 }
 
 static int ew_blocks(long n, int v) {
-    long b = (n / v + EW_THREADS - 1) / EW_THREADS;
+    long b = ((n + v - 1) / v + EW_THREADS - 1) / EW_THREADS;
     if (b < 1) b = 1;
     if (b > EW_MAX_BLOCKS) b = EW_MAX_BLOCKS;
     return (int)b;
@@ -132,12 +131,16 @@ int dsw_rezero_residual_fwd(const void* c, const void* r, const void* w, void* y
     if (n < 0) return DSW_ERR_BAD_ARG;
     if (n == 0) return DSW_OK;
     if (!c || !r || !w || !y) return DSW_ERR_BAD_ARG;
-    if (!dsw_aligned16(c) || !dsw_aligned16(r) || !dsw_aligned16(y)) return DSW_ERR_ALIGN;
+    // contiguous views with a storage offset (batch slices, an Identity residual of a sliced input) need not be 16-byte
+    // aligned: they take the scalar path of the same kernel (the reference simply works there)
+    const int vec = (dsw_aligned16(c) && dsw_aligned16(r) && dsw_aligned16(y)) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == DSW_F32)
-        hipLaunchKernelGGL(rezero_fwd_kernel<false>, dim3(ew_blocks(n, 4)), dim3(EW_THREADS), 0, s, c, r, w, y, (long)n);
+        hipLaunchKernelGGL(rezero_fwd_kernel<false>, dim3(ew_blocks(n, vec ? 4 : 1)), dim3(EW_THREADS), 0, s, c, r, w, y,
+                           (long)n, vec);
     else if (dtype == DSW_BF16)
-        hipLaunchKernelGGL(rezero_fwd_kernel<true>, dim3(ew_blocks(n, 8)), dim3(EW_THREADS), 0, s, c, r, w, y, (long)n);
+        hipLaunchKernelGGL(rezero_fwd_kernel<true>, dim3(ew_blocks(n, vec ? 8 : 1)), dim3(EW_THREADS), 0, s, c, r, w, y,
+                           (long)n, vec);
     else
         return DSW_ERR_BAD_DTYPE;
     return dsw_check_launch();
@@ -148,16 +151,16 @@ int dsw_rezero_residual_bwd(const void* g, const void* c, const void* w, void* g
     if (n < 0) return DSW_ERR_BAD_ARG;
     if (!g || !c || !w || !grad_w) return DSW_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < dsw_rezero_residual_workspace_bytes()) return DSW_ERR_WORKSPACE;
-    if (!dsw_aligned16(g) || !dsw_aligned16(c) || (grad_c && !dsw_aligned16(grad_c))) return DSW_ERR_ALIGN;
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
+    const int vec = (dsw_aligned16(g) && dsw_aligned16(c) && (!grad_c || dsw_aligned16(grad_c))) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     float* partial = static_cast<float*>(workspace);
-    const int nb = ew_blocks(n, dtype == DSW_BF16 ? 8 : 4);
+    const int nb = ew_blocks(n, !vec ? 1 : dtype == DSW_BF16 ? 8 : 4);
     if (dtype == DSW_F32) {
-        hipLaunchKernelGGL(rezero_bwd_kernel<false>, dim3(nb), dim3(EW_THREADS), 0, s, g, c, w, grad_c, partial, (long)n);
+        hipLaunchKernelGGL(rezero_bwd_kernel<false>, dim3(nb), dim3(EW_THREADS), 0, s, g, c, w, grad_c, partial, (long)n, vec);
         hipLaunchKernelGGL(rezero_bwd_final_kernel<false>, dim3(1), dim3(256), 0, s, partial, nb, grad_w);
     } else {
-        hipLaunchKernelGGL(rezero_bwd_kernel<true>, dim3(nb), dim3(EW_THREADS), 0, s, g, c, w, grad_c, partial, (long)n);
+        hipLaunchKernelGGL(rezero_bwd_kernel<true>, dim3(nb), dim3(EW_THREADS), 0, s, g, c, w, grad_c, partial, (long)n, vec);
         hipLaunchKernelGGL(rezero_bwd_final_kernel<true>, dim3(1), dim3(256), 0, s, partial, nb, grad_w);
     }
     return dsw_check_launch();

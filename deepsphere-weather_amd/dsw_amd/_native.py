@@ -44,6 +44,11 @@ SIGNATURES = {
     "dsw_rezero_residual_workspace_bytes": (_i64, []),
     "dsw_rezero_residual_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _vp]),
     "dsw_rezero_residual_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _vp]),
+    "dsw_maxval_pool_fwd": (_int, [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _int, _vp]),
+    "dsw_maxval_pool_bwd": (_int, [_i32p, _i32p, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _int, _vp]),
+    "dsw_maxval_unpool_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "dsw_maxval_unpool_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _vp]),
+    "dsw_maxval_unpool_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp]),
     "dsw_cheb_fwd": (
         _int,
         [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp],

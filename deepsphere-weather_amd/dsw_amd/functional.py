@@ -20,6 +20,8 @@ __all__ = [
     "cheb_conv",
     "sparse_remap",
     "cheb_basis",
+    "maxval_pool",
+    "maxval_unpool",
     "set_test_backend",
 ]
 
@@ -44,7 +46,8 @@ class CsrOperator:
         self.shape = (int(shape[0]), int(shape[1]))
         self.nnz = int(colind.numel())
         self._t = None
-        self._plans = {}
+        self._plans = {}          # row_bytes -> device plan (or None)
+        self._plans_by_rows = {}  # tile_rows -> host plan (or None): built once per tile size, shared by every row size
 
     @classmethod
     def from_sparse_coo(cls, mat: torch.Tensor) -> "CsrOperator":
@@ -76,22 +79,30 @@ class CsrOperator:
         if row_bytes not in self._plans:
             from . import hop2
 
-            rp, ci, va = (t.cpu().numpy() for t in (self.rowptr, self.colind, self.values))
             import os
 
             plan = None
             forced = os.environ.get("DSW_HOP2_ROWS")   # diagnostics: force a tile size
+            host_csr = []
+
+            def host_plan(rows):
+                if rows not in self._plans_by_rows:
+                    if not host_csr:
+                        host_csr.extend(t.cpu().numpy() for t in (self.rowptr, self.colind, self.values))
+                    try:
+                        self._plans_by_rows[rows] = hop2.build_hop2_plan(*host_csr, rows)
+                    except ValueError:
+                        self._plans_by_rows[rows] = None
+                return self._plans_by_rows[rows]
+
             # largest tile whose workgroup still leaves room for >= 2 workgroups per CU (<= 80 KiB of
             # the 160 KiB LDS); a single resident workgroup (<= 156 KiB) is the last resort
             for budget in (80 * 1024, 156 * 1024):
                 for rows in ((int(forced),) if forced else (256, 128, 64)):
                     if rows > self.shape[0]:
                         continue
-                    try:
-                        cand = hop2.build_hop2_plan(rp, ci, va, rows)
-                    except ValueError:
-                        continue
-                    if cand.lds_bytes(row_bytes) <= budget:
+                    cand = host_plan(rows)
+                    if cand is not None and cand.lds_bytes(row_bytes) <= budget:
                         plan = cand
                         break
                 if plan is not None:
@@ -115,16 +126,44 @@ class CsrOperator:
                 t_rowptr, rows[order].to(torch.int32).contiguous(), self.values[order].contiguous(),
                 (ncol, nrow),
             )
-            t._t = self
-            self._t = t
+            # an exactly symmetric operator (content-equal to a live CSR, usually `self`) shares that object and
+            # with it the tile plans; anything else keeps its own transpose
+            shared = _dedup_by_content(t)
+            if shared is t:
+                t._t = self
+            self._t = shared
         return self._t
 
 
 _op_cache: dict = {}
+_content_cache: dict = {}   # (device, shape, nnz) -> [weakref(CsrOperator)]: operators with equal content share ONE object
+
+
+def _dedup_by_content(op: CsrOperator) -> CsrOperator:
+    """``model.to(device)`` gives every ConvCheb of a U-Net level its own copy of the same Laplacian (11 buffers,
+    3 distinct operators).  The derived CSR, its transpose and the host-built two-hop tile plans are keyed on the
+    CONTENT: a freshly derived CSR that equals a live one (exact comparison on the device, a few MB) is dropped in
+    favour of it, so transposes and plans are built once per distinct operator, not once per layer."""
+    key = (str(op.device), op.shape, op.nnz)
+    alive = []
+    hit = None
+    for ref in _content_cache.get(key, []):
+        cand = ref()
+        if cand is None:
+            continue
+        alive.append(ref)
+        if hit is None and torch.equal(cand.colind, op.colind) and torch.equal(cand.rowptr, op.rowptr) \
+                and torch.equal(cand.values, op.values):
+            hit = cand
+    if hit is None:
+        alive.append(weakref.ref(op))
+        hit = op
+    _content_cache[key] = alive
+    return hit
 
 
 def get_operator(mat: torch.Tensor) -> CsrOperator:
-    """CSR cache keyed on the sparse buffer's identity / version / device / dtype.
+    """CSR cache keyed on the sparse buffer's identity / version / device / dtype, de-duplicated by content.
 
     ``model.to(device)`` and dtype casts create new tensors (new id); ``load_state_dict`` copies
     in place and bumps ``_version`` - both invalidate the entry.
@@ -134,7 +173,7 @@ def get_operator(mat: torch.Tensor) -> CsrOperator:
     hit = _op_cache.get(key)
     if hit is not None and hit[0]() is mat and hit[1] == sig:
         return hit[2]
-    op = CsrOperator.from_sparse_coo(mat)
+    op = _dedup_by_content(CsrOperator.from_sparse_coo(mat))
 
     def _evict(_ref, key=key):
         _op_cache.pop(key, None)
@@ -277,6 +316,53 @@ class _HipBackend:
         return gc, gw
 
 
+    def maxval_pool_fwd(self, op, x):
+        lib = _native.load()
+        B, v_in, C = x.shape
+        y = torch.empty((B, op.shape[0], C), dtype=x.dtype, device=x.device)
+        sel = torch.empty((B, op.shape[0], C), dtype=torch.int32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.dsw_maxval_pool_fwd(op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), op.shape[0],
+                                         op.shape[1], x.data_ptr(), y.data_ptr(), sel.data_ptr(), B, C, _DTYPES[x.dtype],
+                                         _stream(x))
+        _native.check(rc, "dsw_maxval_pool_fwd")
+        return y, sel
+
+    def maxval_pool_bwd(self, op, dy, sel):
+        lib = _native.load()
+        B, v_out, C = dy.shape
+        opt = op.transpose()
+        dx = torch.empty((B, op.shape[1], C), dtype=dy.dtype, device=dy.device)
+        with torch.cuda.device(dy.device):
+            rc = lib.dsw_maxval_pool_bwd(opt.rowptr.data_ptr(), opt.colind.data_ptr(), op.shape[1], op.shape[0],
+                                         dy.data_ptr(), sel.data_ptr(), dx.data_ptr(), B, C, _DTYPES[dy.dtype], _stream(dy))
+        _native.check(rc, "dsw_maxval_pool_bwd")
+        return dx
+
+    def maxval_unpool_fwd(self, x, sel, v_fine):
+        lib = _native.load()
+        B, v_coarse, C = x.shape
+        y = torch.empty((B, v_fine, C), dtype=x.dtype, device=x.device)
+        nb = int(lib.dsw_maxval_unpool_workspace_bytes(B, v_fine, C))
+        ws = torch.empty((max(nb, 4),), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.dsw_maxval_unpool_fwd(sel.data_ptr(), x.data_ptr(), y.data_ptr(), ws.data_ptr(), nb, B, v_coarse,
+                                           v_fine, C, _DTYPES[x.dtype], _stream(x))
+        _native.check(rc, "dsw_maxval_unpool_fwd")
+        return y
+
+    def maxval_unpool_bwd(self, dy, sel):
+        lib = _native.load()
+        B, v_fine, C = dy.shape
+        v_coarse = sel.shape[1]
+        dx = torch.empty((B, v_coarse, C), dtype=dy.dtype, device=dy.device)
+        with torch.cuda.device(dy.device):
+            rc = lib.dsw_maxval_unpool_bwd(sel.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, v_coarse, v_fine, C,
+                                           _DTYPES[dy.dtype], _stream(dy))
+        _native.check(rc, "dsw_maxval_unpool_bwd")
+        return dx
+
+
 _HIP = _HipBackend()
 _test_backend = None
 
@@ -370,6 +456,71 @@ class _RemapFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         return ctx.be.spmm(ctx.op.transpose(), dy.contiguous()), None
+
+
+class _MaxValPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, op):
+        be = _backend_for(x)
+        y, sel = be.maxval_pool_fwd(op, x.contiguous())
+        ctx.op, ctx.be = op, be
+        ctx.save_for_backward(sel)
+        ctx.mark_non_differentiable(sel)
+        return y, sel
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy, _dsel):
+        (sel,) = ctx.saved_tensors
+        return ctx.be.maxval_pool_bwd(ctx.op, dy.contiguous(), sel), None
+
+
+class _MaxValUnpoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sel, v_fine):
+        be = _backend_for(x)
+        ctx.be = be
+        ctx.save_for_backward(sel)
+        return be.maxval_unpool_fwd(x.contiguous(), sel, v_fine)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        (sel,) = ctx.saved_tensors
+        return ctx.be.maxval_unpool_bwd(dy.contiguous(), sel), None, None
+
+
+def maxval_pool(op: CsrOperator, x: torch.Tensor):
+    """Max-value pooling (reference layers.py:1040-1079): per coarse cell the (unweighted) value of the fine cell whose
+    WEIGHTED value is largest.  Returns ``(y [B, Vd, F], sel int32 [B, Vd, F])`` with ``sel`` the chosen fine cell."""
+    if x.dim() != 3:
+        raise ValueError("expected input [B, V, F]")
+    assert x.shape[1] == op.shape[1], "remap_matrix.shape[1] != x.shape[1]"      # the reference's assert
+    _check_dtype(x)
+    return _MaxValPoolFn.apply(x, op)
+
+
+def maxval_unpool(x: torch.Tensor, sel: torch.Tensor, v_fine: int) -> torch.Tensor:
+    """Max-value unpooling (reference layers.py:1082-1103): every coarse value returns to the fine cell it was pooled
+    from, all other fine cells are zero.  ``sel``: int32 ``[B, Vc, F]`` as returned by :func:`maxval_pool`."""
+    if x.dim() != 3 or sel.shape != x.shape or sel.dtype != torch.int32:
+        raise ValueError("expected x [B, Vc, F] and an int32 selection of the same shape")
+    _check_dtype(x)
+    return _MaxValUnpoolFn.apply(x, sel.contiguous(), int(v_fine))
+
+
+def maxval_reference_index(sel: torch.Tensor) -> torch.Tensor:
+    """Compact selection ``[B, Vd, F]`` -> the reference's index tensor ``[2, F*B*Vd]`` int64 (layers.py:1069-1075):
+    row = chosen fine cell, column = f*B + b of the reference's internal ``[V, F*B]`` layout, listed column-major."""
+    B, D, F = sel.shape
+    row = sel.permute(2, 0, 1).reshape(-1).to(torch.int64)
+    col = torch.arange(F * B, device=sel.device, dtype=torch.int64).repeat_interleave(D)
+    return torch.stack([row, col])
+
+
+def maxval_compact_index(index: torch.Tensor, B: int, D: int, F: int) -> torch.Tensor:
+    """Inverse of :func:`maxval_reference_index`."""
+    return index[0].reshape(F, B, D).permute(1, 2, 0).to(torch.int32).contiguous()
 
 
 def cheb_conv(op: CsrOperator, x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:

@@ -17,6 +17,7 @@ this file                      reference ``modules/layers.py``
 ``RemapBlock``                 ``:948-968``
 ``GeneralAvgPool/Unpool``      ``:971-987``
 ``GeneralMaxAreaPool/Unpool``  ``:991-1036`` (same SpMM with a 0/1 matrix)
+``GeneralMaxValPool/Unpool``   ``:1040-1103`` (segmented arg-max / gather kernels, dsw_pool.hip)
 ``PoolUnpoolBlock``            ``:1139-1191``
 ``get_conv_fun``               ``:1198-1201``
 ``GeneralConvBlock``           ``:1204-1242``
@@ -24,8 +25,7 @@ this file                      reference ``modules/layers.py``
 
 The arithmetic (``torch.sparse.mm`` at ``:164,167,962`` and ``matmul`` at ``:177`` plus the layout
 copies around them) is replaced by ``dsw_amd.functional`` -> ``libdsw_hip.so``.  Everything that is
-not on that path (image convolutions, HEALPix/equiangular max/avg pooling, max-value pooling,
-cotan Laplacian) is out of scope and raises ``NotImplementedError`` with a pointer to DESIGN.md.
+not on that path (image convolutions, HEALPix/equiangular max/avg pooling, cotan Laplacian) is out of scope and raises ``NotImplementedError`` with a pointer to DESIGN.md.
 """
 import math
 from abc import ABC, abstractmethod
@@ -119,13 +119,37 @@ def conv_cheb(laplacian, inputs, weight):
     return _F.cheb_conv(op, inputs, weight)
 
 
-class ConvCheb(torch.nn.Module):
+class _Fp32OperatorMixin:
+    """Keeps the sparse operator buffers of a module at (at least) fp32 across ``.to(dtype)`` / ``.bfloat16()`` /
+    ``.half()`` casts.  The reference rounds the Laplacian / remap matrix to the activation dtype on such a cast
+    (its CPU path then also accumulates in bf16); here the kernels keep operator and accumulators in fp32 whatever
+    the activation storage type is, so rounding the buffer to an 8-bit mantissa would only lose accuracy (pooling rows
+    would no longer sum to 1, the Laplacian spectrum would move by ~4e-3 per hop).  Device moves and ``.double()``
+    behave as in the reference."""
+
+    _operator_buffers = ()
+
+    def _apply(self, fn, *args, **kwargs):
+        before = {n: self._buffers.get(n) for n in self._operator_buffers}
+        out = super()._apply(fn, *args, **kwargs)
+        for name, old in before.items():
+            new = self._buffers.get(name)
+            if old is None or new is None or new is old:
+                continue
+            if new.dtype in (torch.bfloat16, torch.float16) and old.dtype not in (torch.bfloat16, torch.float16):
+                self._buffers[name] = old.to(new.device)
+        return out
+
+
+class ConvCheb(_Fp32OperatorMixin, torch.nn.Module):
     """Graph convolution with Chebyshev polynomials of the rescaled Laplacian (Defferrard 2016).
 
     Input ``(sample, node, feature)``; parameters ``weight [in, kernel_size, out]``, ``bias [out]``
     (or ``None``); buffer ``laplacian`` (sparse COO, part of the state_dict).  ``kernel_size - 1`` is
     the polynomial order (1 = no neighbourhood, 2 = one hop, ...).
     """
+
+    _operator_buffers = ("laplacian",)
 
     def __init__(self, in_channels, out_channels, kernel_size, laplacian, bias=True, conv=conv_cheb, **kwargs):
         super().__init__()
@@ -228,13 +252,15 @@ def build_pooling_matrices(src_graph, dst_graph):
     return pool, unpool
 
 
-class RemapBlock(torch.nn.Module):
+class RemapBlock(_Fp32OperatorMixin, torch.nn.Module):
     """Mesh-based pooling / unpooling: ``y[b, d, f] = sum_v M[d, v] x[b, v, f]``.
 
     ``remap_matrix`` (sparse COO ``[V_dst, V_src]``) is a registered buffer as in the reference.
     The result is returned contiguous ``[B, V_dst, F]`` (the reference returns a permuted view with
     the same values).
     """
+
+    _operator_buffers = ("remap_matrix",)
 
     def __init__(self, remap_matrix):
         super().__init__()
@@ -294,6 +320,33 @@ class GeneralMaxAreaUnpool(RemapBlock):
         return _argmax_selector(mat, axis=0)
 
 
+class GeneralMaxValPool(RemapBlock):
+    """Max-value pooling: per coarse cell, sample and channel the value of the overlapping fine cell whose
+    area-WEIGHTED value is largest (reference ``layers.py:1040-1079``).
+
+    Returns ``(x_pooled [B, Vd, F], index)``.  ``index`` is the compact int32 ``[B, Vd, F]`` selection (the chosen fine
+    cell per output element) - the same information as the reference's ``[2, B*F*Vd]`` int64 tensor at a sixteenth of
+    the size; :meth:`reference_index` converts, and :class:`GeneralMaxValUnpool` accepts either form."""
+
+    def forward(self, x, *args, **kwargs):
+        return _F.maxval_pool(_F.get_operator(self.remap_matrix), x)
+
+    @staticmethod
+    def reference_index(index):
+        return _F.maxval_reference_index(index)
+
+
+class GeneralMaxValUnpool(RemapBlock):
+    """Max-value unpooling: coarse values go back to the fine cells they were pooled from, zeros elsewhere
+    (reference ``layers.py:1082-1103``; only the SHAPE of ``remap_matrix`` is used, as in the reference)."""
+
+    def forward(self, x, index, *args, **kwargs):
+        B, D, F_ = x.shape
+        if index.dim() == 2:   # the reference's [2, B*F*Vd] form
+            index = _F.maxval_compact_index(index, B, D, F_)
+        return _F.maxval_unpool(x, index, self.remap_matrix.shape[0])
+
+
 class PoolUnpoolBlock(torch.nn.Module):
     """Factories of (pooling, unpooling) layer pairs."""
 
@@ -317,7 +370,7 @@ class PoolUnpoolBlock(torch.nn.Module):
         if pool_method == "learn":
             raise NotImplementedError()
         if pool_method == "maxval":
-            raise NotImplementedError(_OUT_OF_SCOPE.format("GeneralMaxValPool/Unpool"))
+            return GeneralMaxValPool(pool_mat), GeneralMaxValUnpool(unpool_mat)
         raise ValueError(f"{pool_method} is not supoorted.")
 
 

@@ -140,7 +140,8 @@ int64_t dsw_cheb_bwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t 
  *     G_k = dY W[:,k,:]^T;  for j=K-1..1: G_{j-1} += (j>1 ? 2 : 1) L^T G_j - G_{j+1};  dX = G_0
  * rowptr_t/colind_t/vals_t describe the CSR of L^T (for a symmetric L pass L itself).
  * dX / dW / db may be NULL to skip them (db is only produced together with dW).
- * plan_t: optional two-hop plan of L^T (NULL = one launch per adjoint step). */
+ * plan_t: optional two-hop plan of L^T (NULL = one launch per adjoint step).
+ * B * V == 0 (an empty batch shard) writes dW = 0 and db = 0. */
 int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t,
                  int64_t V, int64_t nnz, const void* X, const void* T, const void* W,
                  const void* dY, void* dX, void* dW, void* db, void* workspace,
@@ -151,12 +152,39 @@ int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* 
  *   forward   y[i] = w * c[i] + r[i]        (w: ONE device scalar of the data dtype - the ReZero parameter)
  *   backward  grad_c[i] = w * g[i] (grad_c may be NULL),  grad_w = sum_i g[i] * c[i]   (deterministic two-stage sum);
  *             the gradient of r is g itself.
- * n elements, 16-byte aligned tensors; y may alias c or r.  workspace: dsw_rezero_residual_workspace_bytes(). */
+ * n elements; 16-byte aligned tensors take the 16 B/lane path, any other alignment a scalar path of the same kernel;
+ * y may alias c or r.  workspace: dsw_rezero_residual_workspace_bytes(). */
 int64_t dsw_rezero_residual_workspace_bytes(void);
 int dsw_rezero_residual_fwd(const void* c, const void* r, const void* w, void* y, int64_t n, int dtype,
                             dsw_stream_t stream);
 int dsw_rezero_residual_bwd(const void* g, const void* c, const void* w, void* grad_c, void* grad_w,
                             void* workspace, int64_t workspace_bytes, int64_t n, int dtype, dsw_stream_t stream);
+
+/* Max-value pooling over a sparse remap matrix (layers.py:1040-1079, GeneralMaxValPool.forward: the Python Counter
+ * loop + torch.gather / argmax per coarse row):  for every sample b, coarse row d, channel f
+ *     p* = argmax over the non-zeros p of row d of  vals[p] * X[b, colind[p], f]   (first maximum on ties)
+ *     Y[b,d,f] = X[b, colind[p*], f]  (unweighted),   sel[b,d,f] = colind[p*]      (-1 for an empty row, Y = 0)
+ * X: [B, v_in, C]; Y: [B, v_out, C]; sel: int32 [B, v_out, C] - the compact form of the reference's [2, B*C*v_out]
+ * int64 index tensor (row = sel, column = f*B + b, listed column-major; see GeneralMaxValPool.reference_index). */
+int dsw_maxval_pool_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t v_out, int64_t v_in,
+                        const void* X, void* Y, int32_t* sel, int64_t B, int64_t C, int dtype, dsw_stream_t stream);
+
+/* Its backward (autograd of the torch.gather at layers.py:1067):  dX[b,v,f] = sum over { d : sel[b,d,f] == v } dY[b,d,f],
+ * evaluated as a gather over the CSR of the TRANSPOSED matrix (rowptr_t [v_fine+1], colind_t): deterministic, no atomics. */
+int dsw_maxval_pool_bwd(const int32_t* rowptr_t, const int32_t* colind_t, int64_t v_fine, int64_t v_coarse,
+                        const void* dY, const int32_t* sel, void* dX, int64_t B, int64_t C, int dtype,
+                        dsw_stream_t stream);
+
+/* Max-value unpooling (layers.py:1082-1103, GeneralMaxValUnpool.forward: torch.index_put into zeros, no accumulate):
+ *     Y[b,v,f] = X[b,d,f] for the largest d with sel[b,d,f] == v, else 0      (last write wins, as on the CPU)
+ * X: [B, v_coarse, C]; Y: [B, v_fine, C]; workspace: dsw_maxval_unpool_workspace_bytes(B, v_fine, C) bytes. */
+int64_t dsw_maxval_unpool_workspace_bytes(int64_t B, int64_t v_fine, int64_t C);
+int dsw_maxval_unpool_fwd(const int32_t* sel, const void* X, void* Y, void* workspace, int64_t workspace_bytes,
+                          int64_t B, int64_t v_coarse, int64_t v_fine, int64_t C, int dtype, dsw_stream_t stream);
+
+/* Its backward (autograd of index_put):  dX[b,d,f] = dY[b, sel[b,d,f], f]. */
+int dsw_maxval_unpool_bwd(const int32_t* sel, const void* dY, void* dX, int64_t B, int64_t v_coarse, int64_t v_fine,
+                          int64_t C, int dtype, dsw_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -188,7 +188,7 @@ def cheb_backward_f64(rowptr, colind, values, x, weight, grad_out, has_bias=True
     dw = np.zeros((Fin, K, Fout), dtype=np.float64)
     G = []
     for k in range(K):
-        dw[:, k, :] = np.einsum("bvf,bvo->fo", T[k], gy)
+        dw[:, k, :] = T[k].reshape(B * V, Fin).T @ gy.reshape(B * V, Fout)   # = einsum("bvf,bvo->fo") via BLAS
         G.append(gy @ w[:, k, :].T)
 
     def apply_t(g):
@@ -234,3 +234,90 @@ def max_rel_err(a, ref):
     if denom == 0:
         return float(np.max(np.abs(a)))
     return float(np.max(np.abs(a - ref)) / denom)
+
+
+# --------------------------------------------------------------------------------------
+# Max-value pooling / unpooling  (reference: modules/layers.py:1040-1103)
+# --------------------------------------------------------------------------------------
+def maxval_pool_torch(matrix, x):
+    """``GeneralMaxValPool.forward`` (reference ``modules/layers.py:1043-1079``), same torch op sequence; the Python
+    ``Counter`` over the row indices (``:1056-1057``) is replaced by ``torch.bincount`` (same per-row counts).
+    Returns ``(x_pooled [B, Vd, F] (permuted view), nnz_ind [2, B*F*Vd])``."""
+    n_batch, n_nodes, n_val = x.shape
+    new_nodes, old_nodes = matrix.shape
+    assert n_nodes == old_nodes, "remap_matrix.shape[1] != x.shape[1]"
+    x = x.permute(1, 2, 0).reshape(n_nodes, n_batch * n_val)                       # :1049
+    row, col = matrix.indices()
+    weights = matrix.values()
+    counts = torch.bincount(row, minlength=new_nodes)
+    kernel_sizes = [int(c) for c in counts if int(c) > 0]                          # :1056-1057
+    col = col.repeat(n_batch * n_val, 1).T                                         # :1059
+    val = torch.gather(x, dim=0, index=col).detach()                               # :1061
+    weighted_val = weights.view(-1, 1) * val                                       # :1063
+    start_row, max_val_index = 0, []
+    for k in kernel_sizes:                                                         # :1065-1070
+        curr = weighted_val[start_row:start_row + k]
+        max_val_index.append(torch.argmax(curr, dim=0) + start_row)
+        start_row += k
+    max_val_index = torch.stack(max_val_index)
+    nnz_row = torch.gather(col, dim=0, index=max_val_index)                        # :1071
+    x_pooled = torch.gather(x, dim=0, index=nnz_row)                               # :1073
+    nnz_col = torch.arange(x_pooled.shape[1]).expand(x_pooled.shape[0], -1)        # np.indices(...)[1], :1075
+    nnz_ind = torch.stack([nnz_row, nnz_col], dim=2).permute(1, 0, 2).reshape(-1, 2).T   # :1077-1078
+    return x_pooled.reshape(new_nodes, n_val, n_batch).permute(2, 0, 1), nnz_ind
+
+
+def maxval_unpool_torch(new_nodes, x, index):
+    """``GeneralMaxValUnpool.forward`` (reference ``modules/layers.py:1085-1103``)."""
+    n_batch, _, n_val = x.shape
+    flat = x.permute(2, 0, 1).flatten()
+    out = torch.zeros([new_nodes, n_batch * n_val], dtype=x.dtype, device=x.device)
+    row, col = index
+    out = torch.index_put(out, (row, col), flat)
+    return out.reshape(new_nodes, n_val, n_batch).permute(2, 0, 1)
+
+
+def maxval_pool_np(rowptr, colind, values, x):
+    """Independent numpy statement of the same selection in the native ``[B, V, F]`` layout: returns
+    ``(y [B, Vd, F], sel int32 [B, Vd, F])`` - first maximum of ``w * x`` over the row's non-zeros."""
+    B, V, F = x.shape
+    D = len(rowptr) - 1
+    y = np.zeros((B, D, F), dtype=x.dtype)
+    sel = np.full((B, D, F), -1, dtype=np.int32)
+    for d in range(D):
+        cols = np.asarray(colind[rowptr[d]:rowptr[d + 1]])
+        if cols.size == 0:
+            continue
+        cand = x[:, cols, :]                                                      # [B, k, F]
+        score = cand.astype(np.float32) * np.asarray(values[rowptr[d]:rowptr[d + 1]], dtype=np.float32)[None, :, None]
+        arg = np.argmax(score, axis=1)                                            # first maximum
+        y[:, d, :] = np.take_along_axis(cand, arg[:, None, :], axis=1)[:, 0, :]
+        sel[:, d, :] = cols[arg]
+    return y, sel
+
+
+def maxval_pool_backward_np(sel, v_fine, gy):
+    """``dx[b, sel[b,d,f], f] += gy[b,d,f]`` (autograd of the gather)."""
+    B, D, F = gy.shape
+    dx = np.zeros((B, v_fine, F), dtype=np.float64)
+    b, f = np.meshgrid(np.arange(B), np.arange(F), indexing="ij")
+    for d in range(D):
+        np.add.at(dx, (b, sel[:, d, :], f), gy[:, d, :])
+    return dx
+
+
+def maxval_unpool_np(sel, v_fine, x):
+    """``y[b, sel[b,d,f], f] = x[b,d,f]``, increasing d (the last write wins), zeros elsewhere."""
+    B, D, F = x.shape
+    y = np.zeros((B, v_fine, F), dtype=x.dtype)
+    b, f = np.meshgrid(np.arange(B), np.arange(F), indexing="ij")
+    for d in range(D):
+        y[b, sel[:, d, :], f] = x[:, d, :]
+    return y
+
+
+def maxval_unpool_backward_np(sel, gy):
+    """``dx[b,d,f] = gy[b, sel[b,d,f], f]``."""
+    B, D, F = sel.shape
+    b, f = np.meshgrid(np.arange(B), np.arange(F), indexing="ij")
+    return np.stack([gy[b, sel[:, d, :], f] for d in range(D)], axis=1)

@@ -60,3 +60,17 @@ class OracleBackend:
         gc = (w.double() * g.double()).to(g.dtype) if need_c else None
         gw = (g.double() * c.double()).sum().reshape(w.shape).to(w.dtype)
         return gc, gw
+
+    def maxval_pool_fwd(self, op, x):
+        rp, ci, va = _csr_np(op)
+        y, sel = orc.maxval_pool_np(rp, ci, va, x.detach().float().numpy())
+        return torch.from_numpy(y).to(x.dtype), torch.from_numpy(sel)
+
+    def maxval_pool_bwd(self, op, dy, sel):
+        return torch.from_numpy(orc.maxval_pool_backward_np(sel.numpy(), op.shape[1], dy.detach().float().numpy())).to(dy.dtype)
+
+    def maxval_unpool_fwd(self, x, sel, v_fine):
+        return torch.from_numpy(orc.maxval_unpool_np(sel.numpy(), v_fine, x.detach().float().numpy())).to(x.dtype)
+
+    def maxval_unpool_bwd(self, dy, sel):
+        return torch.from_numpy(orc.maxval_unpool_backward_np(sel.numpy(), dy.detach().float().numpy())).to(dy.dtype)

@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Round-2 golden fixtures, produced by running the REFERENCE itself (build container only, like make_golden.py,
+whose import scaffolding - stubs for the absent xsphere / pygsp packages, reference-first sys.path - is reused):
+
+    python tests/golden/make_golden_r2.py
+
+G8  GeneralMaxValPool / GeneralMaxValUnpool (layers.py:1040-1103) and GeneralMaxAreaPool / GeneralMaxAreaUnpool
+    (layers.py:991-1036), 768 -> 192 -> 768, hierarchical and overlapping (k-NN interpolation) matrices: forward
+    values, the index tensor, and the gradients autograd derives.
+G9  one autoregressive optimisation run of the reference UNetSpherical (nside=8) with the reference WeightedMSELoss
+    (loss.py:118-156) and torch Adam(eps=1e-7) (train_predict_state.py:334-340): three steps of two forwards each.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402  (sets up the stubs and imports the reference's modules.layers / my_models_graph)
+
+ref_layers, ref_models, sphere, recipes, orc, save, csr_of = (mg.ref_layers, mg.ref_models, mg.sphere, mg.recipes,
+                                                              mg.orc, mg.save, mg.csr_of)
+
+
+def _import_ref_loss():
+    """modules/loss.py imports xarray, cartopy and matplotlib at module level (plotting helpers only): stub what is absent."""
+    for name in ("xarray", "cartopy", "cartopy.crs", "matplotlib", "matplotlib.pyplot"):
+        try:
+            __import__(name)
+        except Exception:
+            sys.modules[name] = types.ModuleType(name)
+    if not hasattr(sys.modules["cartopy"], "crs"):
+        sys.modules["cartopy"].crs = sys.modules["cartopy.crs"]
+    import modules.loss as ref_loss
+
+    assert ref_loss.__file__.startswith(mg.REF)
+    return ref_loss
+
+
+def g8():
+    gs, gd = sphere.SphereHealpix(8, nest=True, k=8), sphere.SphereHealpix(4, nest=True, k=8)
+    pool_h, unpool_h = sphere.healpix_pool_matrices(8, nest=True)
+    pool_i, unpool_i = sphere.knn_interp_pool_matrices(gs.coords, gd.coords, k=7)
+    arrays = {}
+    B, F = 2, 6
+    for tag, (pm, um) in {"hier": (pool_h, unpool_h), "interp": (pool_i, unpool_i)}.items():
+        # ---- max value ----
+        pool, unpool = ref_layers.GeneralMaxValPool(pm), ref_layers.GeneralMaxValUnpool(um)
+        x = torch.from_numpy(recipes.rand(800, (B, 768, F))).requires_grad_(True)
+        yp, idx = pool(x)
+        gyp = torch.from_numpy(recipes.rand(801, (B, 192, F)))
+        yp.backward(gyp)
+        xu = torch.from_numpy(recipes.rand(802, (B, 192, F))).requires_grad_(True)
+        yu = unpool(xu, idx)
+        gyu = torch.from_numpy(recipes.rand(803, (B, 768, F)))
+        yu.backward(gyu)
+        prp, pci, pva = csr_of(pool.remap_matrix)
+        urp, uci, uva = csr_of(unpool.remap_matrix)
+        arrays.update({
+            f"{tag}_pool_rowptr": prp, f"{tag}_pool_colind": pci, f"{tag}_pool_values": pva,
+            f"{tag}_unpool_rowptr": urp, f"{tag}_unpool_colind": uci, f"{tag}_unpool_values": uva,
+            f"{tag}_mv_x": x.detach().numpy(), f"{tag}_mv_yp": yp.detach().contiguous().numpy(),
+            f"{tag}_mv_index": idx.numpy().astype(np.int64), f"{tag}_mv_gyp": gyp.numpy(), f"{tag}_mv_dxp": x.grad.numpy(),
+            f"{tag}_mv_xu": xu.detach().numpy(), f"{tag}_mv_yu": yu.detach().contiguous().numpy(),
+            f"{tag}_mv_gyu": gyu.numpy(), f"{tag}_mv_dxu": xu.grad.numpy(),
+        })
+        # ---- max area ----
+        pool, unpool = ref_layers.GeneralMaxAreaPool(pm), ref_layers.GeneralMaxAreaUnpool(pm.T)
+        x = torch.from_numpy(recipes.rand(810, (B, 768, F))).requires_grad_(True)
+        yp, none_idx = pool(x)
+        assert none_idx is None
+        yp.backward(gyp)
+        xu = torch.from_numpy(recipes.rand(812, (B, 192, F))).requires_grad_(True)
+        yu = unpool(xu, None)
+        yu.backward(gyu)
+        arp, aci, ava = csr_of(pool.remap_matrix)
+        brp, bci, bva = csr_of(unpool.remap_matrix)
+        arrays.update({
+            f"{tag}_ma_pool_rowptr": arp, f"{tag}_ma_pool_colind": aci, f"{tag}_ma_pool_values": ava,
+            f"{tag}_ma_unpool_rowptr": brp, f"{tag}_ma_unpool_colind": bci, f"{tag}_ma_unpool_values": bva,
+            f"{tag}_ma_x": x.detach().numpy(), f"{tag}_ma_yp": yp.detach().contiguous().numpy(), f"{tag}_ma_dxp": x.grad.numpy(),
+            f"{tag}_ma_xu": xu.detach().numpy(), f"{tag}_ma_yu": yu.detach().contiguous().numpy(), f"{tag}_ma_dxu": xu.grad.numpy(),
+        })
+    save("G8_maxpool", **arrays)
+
+
+def g9():
+    ref_loss = _import_ref_loss()
+    ref_layers.build_pooling_matrices = sphere.build_pooling_matrices
+    V = 768
+    tensor_info = {
+        "dim_order": {"dynamic": ["sample", "time", "node", "feature"]},
+        "input_n_feature": 6, "output_n_feature": 2, "input_n_time": 3, "output_n_time": 1,
+        "input_shape_info": {"dynamic": {"node": V}}, "output_shape_info": {"dynamic": {"node": V}},
+    }
+    torch.manual_seed(10)
+    model = ref_models.UNetSpherical(
+        tensor_info, sampling="healpix", sampling_kwargs={"subdivisions": 8, "nest": True},
+        kernel_size_conv=3, conv_type="graph", graph_type="knn", knn=20, pool_method="interp",
+    )
+    names = sorted(n for n, _ in model.named_parameters())
+    params = dict(model.named_parameters())
+    with torch.no_grad():
+        for i, n in enumerate(names):
+            params[n].copy_(torch.from_numpy(recipes.unet_param_fill(i, n, tuple(params[n].shape))))
+    weights = torch.from_numpy(recipes.ar_area_weights(V))
+    criterion = ref_loss.WeightedMSELoss(weights=weights)                  # loss.py:118-156
+    dim_info = {"sample": 0, "time": 1, "node": 2, "feature": 3}
+    optimizer = torch.optim.Adam(model.parameters(), lr=0.007, eps=1e-7, weight_decay=0, amsgrad=False)
+    x0 = torch.from_numpy(recipes.rand(901, (2, 3, V, 6)))
+    targets = [torch.from_numpy(recipes.rand(902 + i, (2, 1, V, 2))) for i in range(2)]   # ar_iterations = 1
+    losses, grad_probes0, upd_l2, heads = [], None, None, None
+    before = {n: params[n].detach().clone() for n in names}
+    for step in range(3):
+        optimizer.zero_grad(set_to_none=True)
+        x, loss = x0, 0.0
+        for target in targets:        # the AR window of scripts_training/train_synthetic_state.py::ar_training_step
+            y = model(x)
+            yp, yo = ref_loss.reshape_tensors_4_loss(y, target, dim_info)  # loss.py:31-54
+            loss = loss + criterion(yp, yo)
+            nxt = x[:, -1:].clone()
+            nxt[..., -2:] = y[:, -1:]
+            x = torch.cat((x[:, 1:], nxt), dim=1)
+        loss.backward()
+        if step == 0:
+            grad_probes0 = np.stack([recipes.grad_probe(i, params[n].grad.numpy()) for i, n in enumerate(names)])
+        optimizer.step()
+        if step == 0:
+            upd_l2 = np.array([float((params[n].detach() - before[n]).double().norm()) for n in names])
+            heads = np.stack([np.resize(params[n].detach().numpy().ravel()[:32], 32) for n in names])
+        losses.append(loss.item())
+    arrays = {"losses": np.array(losses), "grad_probes0": grad_probes0, "update_l2": upd_l2, "param_heads1": heads,
+              "param_names": np.array(names), "weights": weights.numpy()}
+    for lvl, lap in enumerate(model.laplacians):
+        rp, ci, va = csr_of(lap)
+        arrays.update({f"lap{lvl}_rowptr": rp, f"lap{lvl}_colind": ci, f"lap{lvl}_values": va})
+    for nm in ("pool1", "unpool1", "pool2", "unpool2"):
+        m = getattr(model, nm).remap_matrix
+        rp, ci, va = csr_of(m)
+        arrays.update({f"{nm}_rowptr": rp, f"{nm}_colind": ci, f"{nm}_values": va, f"{nm}_shape": np.array(m.shape)})
+    save("G9_ar_steps", **arrays)
+    print("losses", losses)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    which = sys.argv[1:] or ["g8", "g9"]
+    if "g8" in which:
+        g8()
+    if "g9" in which:
+        g9()

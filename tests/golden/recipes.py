@@ -48,3 +48,9 @@ def irregular_operator(n, seed, min_deg=5, max_deg=200, symmetric=False):
         m.sort_indices()
         return m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.astype(np.float32)
     return rowptr.astype(np.int32), colind.astype(np.int32), vals
+
+
+def ar_area_weights(n):
+    """Seeded, non-uniform positive node weights summing to 1 (stand-in for loss.AreaWeights, which needs CDO)."""
+    w = 0.5 + np.random.default_rng(4242).random(n)
+    return (w / w.sum()).astype(np.float32)

@@ -614,3 +614,84 @@ def test_bench_contract_line():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("port", "reference")
+
+
+@pytest.mark.parametrize("tag", ["hier", "interp"])
+def test_max_pooling_golden_g8(tag):
+    """GeneralMaxValPool / Unpool (segmented arg-max + gather kernels) and GeneralMaxAreaPool / Unpool on the device
+    against the reference's own outputs (fixture G8): selection and values exact, gradients <= 1e-6."""
+    from test_host_logic import check_g8
+
+    check_g8(tag, device=DEV)
+
+
+@pytest.mark.parametrize("dt,C,B", [(torch.float32, 7, 3), (torch.float32, 64, 2), (torch.bfloat16, 40, 2), (torch.bfloat16, 5, 1)])
+def test_maxval_pool_vs_oracle_shapes(dt, C, B):
+    """Max-value pooling on an irregular rectangular matrix (rows of 1..9 entries, negative weights), odd channel
+    counts (scalar lanes) and both storage types, against the numpy statement of the reference's selection."""
+    from dsw_amd import functional as F_
+    from scipy import sparse
+
+    rng = np.random.default_rng(12)
+    vo, vi = 150, 400
+    rows = np.repeat(np.arange(vo), rng.integers(1, 10, size=vo))
+    cols = rng.integers(0, vi, size=rows.size)
+    m = sparse.csr_matrix((rng.standard_normal(rows.size).astype(np.float32), (rows, cols)), shape=(vo, vi))
+    m.sum_duplicates(); m.sort_indices()
+    op = F_.CsrOperator.from_sparse_coo(orc.coo_from_scipy(m).float().to(DEV))
+    x = torch.from_numpy(recipes.rand(21, (B, vi, C))).to(dt)
+    xd = x.to(DEV).requires_grad_(True)
+    y, sel = F_.maxval_pool(op, xd)
+    y_ref, sel_ref = orc.maxval_pool_np(m.indptr, m.indices, m.data, x.float().numpy())
+    assert torch.equal(sel.cpu(), torch.from_numpy(sel_ref))
+    assert torch.equal(y.float().cpu(), torch.from_numpy(y_ref))
+    gy = torch.from_numpy(recipes.rand(22, (B, vo, C))).to(dt)
+    y.backward(gy.to(DEV))
+    dx_ref = orc.maxval_pool_backward_np(sel_ref, vi, gy.float().numpy())
+    assert orc.max_rel_err(xd.grad.float(), dx_ref) <= (TOL_BF16 if dt == torch.bfloat16 else TOL_F64)
+    xu = torch.from_numpy(recipes.rand(23, (B, vo, C))).to(dt).to(DEV).requires_grad_(True)
+    yu = F_.maxval_unpool(xu, sel, vi)
+    assert torch.equal(yu.float().cpu(), torch.from_numpy(orc.maxval_unpool_np(sel_ref, vi, xu.detach().float().cpu().numpy())))
+    gyu = torch.from_numpy(recipes.rand(24, (B, vi, C))).to(dt)
+    yu.backward(gyu.to(DEV))
+    assert torch.equal(xu.grad.float().cpu(), torch.from_numpy(orc.maxval_unpool_backward_np(sel_ref, gyu.float().numpy())))
+
+
+def test_empty_shard_backward_writes_zero_parameter_gradients():
+    """A rank with no samples (B < world size) must contribute exact zeros to the gradient all-reduce - for both
+    evaluation orders of the layer (the mix-first branch used to leave dW / db unwritten)."""
+    from modules.layers import ConvCheb
+
+    (rp, ci, va), _, _, _, _ = _rand_case(192, 1, 8, 8, 3, seed=3)
+    lap = orc.coo_from_csr_arrays(rp, ci, va, (192, 192))
+    for fin, fout in ((32, 64), (64, 16)):       # basis-first, mix-first
+        layer = ConvCheb(fin, fout, 3, laplacian=lap).to(DEV)
+        x = torch.zeros(0, 192, fin, device=DEV, requires_grad=True)
+        for _ in range(2):                        # second pass: the caching allocator hands back dirty memory
+            junk = torch.full((fin * 3 * fout + fout + 64,), float("nan"), device=DEV)
+            del junk
+            layer.zero_grad(set_to_none=True)
+            y = layer(x)
+            y.backward(torch.zeros(0, 192, fout, device=DEV))
+            assert torch.count_nonzero(layer.weight.grad) == 0 and torch.count_nonzero(layer.bias.grad) == 0
+            assert torch.isfinite(layer.weight.grad).all() and torch.isfinite(layer.bias.grad).all()
+
+
+def test_rezero_residual_unaligned_views():
+    """Contiguous views with a storage offset that is not a multiple of 16 bytes (a batch slice of odd-sized rows)
+    take the scalar path instead of failing."""
+    from dsw_amd import functional as F_
+
+    torch.manual_seed(2)
+    base_c = torch.randn(3, 5, 7, device=DEV)
+    base_r = torch.randn(3, 5, 7, device=DEV)
+    c, r = base_c[1:], base_r[1:]                  # offset 35 floats = 140 bytes: not 16-byte aligned
+    assert c.is_contiguous() and c.data_ptr() % 16 != 0
+    c = c.detach().requires_grad_(True)
+    w = torch.tensor([0.3], device=DEV, requires_grad=True)
+    y = F_.rezero_residual(c, r, w)
+    g = torch.randn_like(y)[...]
+    y.backward(g)
+    assert orc.max_rel_err(y, (0.3 * c.detach().double() + r.double()).cpu().numpy()) <= TOL_F64
+    assert orc.max_rel_err(c.grad, (0.3 * g.double()).cpu().numpy()) <= TOL_F64
+    assert abs(float(w.grad) - float((g.double() * c.detach().double()).sum())) <= 1e-4

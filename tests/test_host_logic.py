@@ -332,3 +332,76 @@ def test_training_driver_config_and_ar_logic():
     assert torch.allclose(loss, expect)
     loss.backward()
     assert model.scale.grad is not None
+
+
+def _g8_layers(g, tag, kind):
+    """(pool, unpool) layers of the build on the fixture's matrices (kind: 'maxval' | 'maxarea')."""
+    from modules.layers import GeneralMaxAreaPool, GeneralMaxAreaUnpool, GeneralMaxValPool, GeneralMaxValUnpool
+
+    pm = sparse.csr_matrix((g[f"{tag}_pool_values"], g[f"{tag}_pool_colind"], g[f"{tag}_pool_rowptr"]), shape=(192, 768))
+    um = sparse.csr_matrix((g[f"{tag}_unpool_values"], g[f"{tag}_unpool_colind"], g[f"{tag}_unpool_rowptr"]), shape=(768, 192))
+    if kind == "maxval":
+        return GeneralMaxValPool(sparse.coo_matrix(pm)), GeneralMaxValUnpool(sparse.coo_matrix(um))
+    # max-area selection compares the matrix entries as given (fp64): rebuild the generator's matrices (the fixture
+    # stores the fp32 buffers, whose rounding can flip near-ties of the arg-max)
+    from dsw_amd import sphere
+
+    if tag == "hier":
+        pm64, _ = sphere.healpix_pool_matrices(8, nest=True)
+    else:
+        gs, gd = sphere.SphereHealpix(8, nest=True, k=8), sphere.SphereHealpix(4, nest=True, k=8)
+        pm64, _ = sphere.knn_interp_pool_matrices(gs.coords, gd.coords, k=7)
+    return GeneralMaxAreaPool(pm64), GeneralMaxAreaUnpool(pm64.T)
+
+
+def check_g8(tag, device="cpu", tol=1e-6):
+    """Max-value and max-area pooling layers against the reference's outputs (fixture G8), forward and backward."""
+    g = load_golden("G8_maxpool")
+    dev = lambda a: torch.from_numpy(a).to(device)
+    pool, unpool = (m.to(device) for m in _g8_layers(g, tag, "maxval"))
+    x = dev(g[f"{tag}_mv_x"]).requires_grad_(True)
+    yp, idx = pool(x)
+    assert idx.dtype == torch.int32 and idx.shape == yp.shape
+    assert torch.equal(pool.reference_index(idx).cpu(), torch.from_numpy(g[f"{tag}_mv_index"]))
+    assert torch.equal(yp.detach().cpu(), torch.from_numpy(g[f"{tag}_mv_yp"]))           # selection: exact
+    yp.backward(dev(g[f"{tag}_mv_gyp"]))
+    assert orc.max_rel_err(x.grad, g[f"{tag}_mv_dxp"]) <= tol
+    for index in (idx, dev(g[f"{tag}_mv_index"])):                                       # compact and reference form
+        xu = dev(g[f"{tag}_mv_xu"]).requires_grad_(True)
+        yu = unpool(xu, index)
+        assert torch.equal(yu.detach().cpu(), torch.from_numpy(g[f"{tag}_mv_yu"]))
+        yu.backward(dev(g[f"{tag}_mv_gyu"]))
+        assert torch.equal(xu.grad.cpu(), torch.from_numpy(g[f"{tag}_mv_dxu"]))
+    pool, unpool = (m.to(device) for m in _g8_layers(g, tag, "maxarea"))
+    x = dev(g[f"{tag}_ma_x"]).requires_grad_(True)
+    yp, none_idx = pool(x)
+    assert none_idx is None
+    yp.backward(dev(g[f"{tag}_mv_gyp"]))
+    assert orc.max_rel_err(yp, g[f"{tag}_ma_yp"]) <= tol and orc.max_rel_err(x.grad, g[f"{tag}_ma_dxp"]) <= tol
+    xu = dev(g[f"{tag}_ma_xu"]).requires_grad_(True)
+    yu = unpool(xu, None)
+    yu.backward(dev(g[f"{tag}_mv_gyu"]))
+    assert orc.max_rel_err(yu, g[f"{tag}_ma_yu"]) <= tol and orc.max_rel_err(xu.grad, g[f"{tag}_ma_dxu"]) <= tol
+    # the 0/1 matrices themselves equal the reference's
+    np.testing.assert_array_equal(orc.csr_arrays_from_coo(pool.remap_matrix.cpu())[1], g[f"{tag}_ma_pool_colind"])
+    np.testing.assert_array_equal(orc.csr_arrays_from_coo(unpool.remap_matrix.cpu())[1], g[f"{tag}_ma_unpool_colind"])
+
+
+@pytest.mark.parametrize("tag", ["hier", "interp"])
+def test_max_pooling_layers_match_reference_fixture_on_cpu_wiring(oracle_backend, tag):
+    check_g8(tag)
+
+
+def test_maxval_factory_and_unet_wiring(oracle_backend):
+    from dsw_amd import sphere
+    from modules.layers import GeneralMaxValPool, GeneralMaxValUnpool, PoolUnpoolBlock
+
+    gs, gd = sphere.SphereHealpix(4, nest=True, k=8), sphere.SphereHealpix(2, nest=True, k=8)
+    pool, unpool = PoolUnpoolBlock.getGeneralPoolUnpoolLayer(gs, gd, "maxval")
+    assert isinstance(pool, GeneralMaxValPool) and isinstance(unpool, GeneralMaxValUnpool)
+    x = torch.randn(2, 192, 5)
+    y, idx = pool(x)
+    back = unpool(y, idx)
+    # every coarse value lands on the fine cell it came from: pooling the unpooled field again is the identity
+    y2, _ = pool(back * 1e3 + torch.where(back != 0, 0.0, -1e9))
+    assert torch.equal(y2, y * 1e3) or orc.max_rel_err(y2, (y * 1e3).numpy()) < 1e-6

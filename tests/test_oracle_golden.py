@@ -124,3 +124,86 @@ def test_c_oracle_remap():
     rp, ci, va = (g[f"interp_pool_{k}"] for k in ("rowptr", "colind", "values"))
     y = c_oracle.remap(rp, ci, va, (192, 768), g["interp_x"])
     assert orc.max_rel_err(g["interp_yp"], y) <= TOL64
+
+
+# ---------------------------------------------------------------------------------------------
+# UNet-level restatement (oracle/unet_oracle.py) against fixture G5 (outputs of the reference model itself)
+# ---------------------------------------------------------------------------------------------
+def _g5_state(g):
+    """The reference model's state_dict of fixture G5, rebuilt from the fixture's operators and the seeded recipe."""
+    import recipes
+
+    names = [str(n) for n in g["param_names"]]
+    shapes = [eval(str(s)) for s in g["param_shapes"]]          # "(64, 3, 128)" strings written by make_golden.py
+    sd = {}
+    for i, (n, shp) in enumerate(zip(names, shapes)):
+        sd[n] = torch.from_numpy(recipes.unet_param_fill(i, n, tuple(shp))).requires_grad_(True)
+    laps = {}
+    for i in range(3):
+        rp = g[f"lap{i}_rowptr"]
+        laps[len(rp) - 1] = orc.coo_from_csr_arrays(rp, g[f"lap{i}_colind"], g[f"lap{i}_values"], (len(rp) - 1,) * 2)
+    level = {"conv1": 768, "conv2": 192, "conv3": 48, "uconv2": 192, "uconv1": 768, "uconv1_final": 768}
+    for key in (str(k) for k in g["state_keys"]):
+        if key.endswith("laplacian"):
+            sd[key] = laps[level[key.split(".")[0]]]
+        elif key.endswith("remap_matrix"):
+            nm = key.split(".")[0]
+            sd[key] = orc.coo_from_csr_arrays(g[f"{nm}_rowptr"], g[f"{nm}_colind"], g[f"{nm}_values"], tuple(g[f"{nm}_shape"]))
+    return sd, names
+
+
+def test_unet_oracle_matches_reference_fixture():
+    import recipes
+    from oracle import unet_oracle
+
+    g = load_golden("G5_unet_nside8")
+    sd, names = _g5_state(g)
+    x = torch.from_numpy(recipes.rand(501, (2, 3, 768, 6)))
+    target = torch.from_numpy(recipes.rand(502, (2, 1, 768, 2)))
+    y, loss, grads = unet_oracle.unet_fwd_bwd(sd, x, target)
+    assert orc.max_rel_err(y, g["y"]) <= TOL32
+    assert abs(loss - float(g["loss"][0])) <= TOL32 * max(1.0, float(g["loss"][0]))
+    probes = np.stack([recipes.grad_probe(i, grads[n].numpy()) for i, n in enumerate(names)])
+    ref = g["grad_probes"]
+    scale = np.abs(ref[:, :1]) + 1e-12
+    assert np.max(np.abs(probes[:, 0] - ref[:, 0]) / scale[:, 0]) <= 1e-4
+    assert np.max(np.abs(probes[:, 2:] - ref[:, 2:]) / scale) <= 1e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# max-value / max-area pooling restatements against fixture G8 (outputs of the reference's classes)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["hier", "interp"])
+def test_maxval_oracle_matches_reference_fixture(tag):
+    g = load_golden("G8_maxpool")
+    rp, ci, va = (g[f"{tag}_pool_{k}"] for k in ("rowptr", "colind", "values"))
+    m = orc.coo_from_csr_arrays(rp, ci, va, (192, 768))
+    x = torch.from_numpy(g[f"{tag}_mv_x"]).requires_grad_(True)
+    # restatement 1: the reference's torch op sequence
+    yp, idx = orc.maxval_pool_torch(m, x)
+    assert torch.equal(idx, torch.from_numpy(g[f"{tag}_mv_index"]))
+    assert torch.equal(yp.detach().contiguous(), torch.from_numpy(g[f"{tag}_mv_yp"]))
+    yp.backward(torch.from_numpy(g[f"{tag}_mv_gyp"]))
+    assert orc.max_rel_err(x.grad, g[f"{tag}_mv_dxp"]) <= 1e-6
+    xu = torch.from_numpy(g[f"{tag}_mv_xu"]).requires_grad_(True)
+    yu = orc.maxval_unpool_torch(768, xu, idx)
+    assert torch.equal(yu.detach().contiguous(), torch.from_numpy(g[f"{tag}_mv_yu"]))
+    yu.backward(torch.from_numpy(g[f"{tag}_mv_gyu"]))
+    assert torch.equal(xu.grad, torch.from_numpy(g[f"{tag}_mv_dxu"]))
+    # restatement 2: numpy, native layout, compact int32 selection; and the index conversion both ways
+    y2, sel = orc.maxval_pool_np(rp, ci, va, g[f"{tag}_mv_x"])
+    np.testing.assert_array_equal(y2, g[f"{tag}_mv_yp"])
+    B, D, F = sel.shape
+    ref_row = g[f"{tag}_mv_index"][0].reshape(F, B, D).transpose(1, 2, 0)       # column c = f*B + b, column-major list
+    np.testing.assert_array_equal(sel, ref_row)
+    np.testing.assert_array_equal(g[f"{tag}_mv_index"][1], np.repeat(np.arange(F * B), D))
+    assert orc.max_rel_err(orc.maxval_pool_backward_np(sel, 768, g[f"{tag}_mv_gyp"]), g[f"{tag}_mv_dxp"]) <= 1e-6
+    np.testing.assert_array_equal(orc.maxval_unpool_np(sel, 768, g[f"{tag}_mv_xu"]), g[f"{tag}_mv_yu"])
+    np.testing.assert_array_equal(orc.maxval_unpool_backward_np(sel, g[f"{tag}_mv_gyu"]), g[f"{tag}_mv_dxu"])
+    # max-area pooling is a remap with a 0/1 selection matrix
+    for which, xin, yout, dxout, gy, shape in (("pool", "x", "yp", "dxp", "gyp", (192, 768)),
+                                               ("unpool", "xu", "yu", "dxu", "gyu", (768, 192))):
+        arp, aci, ava = (g[f"{tag}_ma_{which}_{k}"] for k in ("rowptr", "colind", "values"))
+        assert set(np.unique(ava)) == {1.0}
+        assert orc.max_rel_err(g[f"{tag}_ma_{yout}"], orc.remap_f64(arp, aci, ava, shape, g[f"{tag}_ma_{xin}"])) <= 1e-6
+        assert orc.max_rel_err(g[f"{tag}_ma_{dxout}"], orc.remap_backward_f64(arp, aci, ava, shape, g[f"{tag}_mv_{gy}"])) <= 1e-6
