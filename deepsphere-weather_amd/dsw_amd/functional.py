@@ -162,6 +162,13 @@ def _dedup_by_content(op: CsrOperator) -> CsrOperator:
     return hit
 
 
+def invalidate_operator_caches():
+    """Forget every derived CSR / transpose / tile plan (after an in-place change of operator buffers that the
+    identity / version key cannot see, e.g. a broadcast into a sparse tensor's values)."""
+    _op_cache.clear()
+    _content_cache.clear()
+
+
 def get_operator(mat: torch.Tensor) -> CsrOperator:
     """CSR cache keyed on the sparse buffer's identity / version / device / dtype, de-duplicated by content.
 

@@ -46,6 +46,41 @@ def shard_batch(global_batch: int, rank: int, world: int):
     return start, start + base + (1 if rank < extra else 0)
 
 
+def broadcast_module_state(module, src: int = 0, group=None):
+    """Make every rank's parameters AND buffers bit-identical to rank ``src``'s.
+
+    Replicas must convolve with the same operator: ``prepare_torch_laplacian`` rescales by an ARPACK estimate of
+    lambda_max that differs by ~1e-3 between calls (random start vector), so Laplacians built independently on each
+    rank are NOT the same matrix.  Sparse buffers are broadcast as their (indices, values) pair; everything travels in
+    ONE flat bucket per dtype (a handful of collectives, not one per tensor).  No-op in a single-process world."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return module
+    dense = [p.data for p in module.parameters()]
+    for name, buf in module.named_buffers():
+        if buf is None:
+            continue
+        if buf.is_sparse:
+            if not buf.is_coalesced():
+                raise ValueError(f"sparse buffer '{name}' must be coalesced before it can be broadcast")
+            dense += [buf._indices(), buf._values()]
+        else:
+            dense.append(buf.data)
+    by_dtype = {}
+    for t in dense:
+        by_dtype.setdefault((t.dtype, t.device), []).append(t)
+    for (dtype, device), tensors in sorted(by_dtype.items(), key=lambda kv: str(kv[0])):
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for t in tensors:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+    from . import functional
+
+    functional.invalidate_operator_caches()   # derived CSR / plans of the pre-broadcast operators are stale
+    return module
+
+
 class FlatGradAllReduce:
     """Average the gradients of ``params`` across ranks with a single flat-bucket all-reduce."""
 

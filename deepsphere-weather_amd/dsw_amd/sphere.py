@@ -9,9 +9,10 @@ module provides self-contained stand-ins written from the public HEALPix geometr
 (Gorski et al. 2005) and a plain symmetrised k-NN Gaussian graph.
 
 PARITY UNPINNED: the edge weights are *not* claimed to equal pygsp's (which uses a
-per-(k, nside) optimal kernel width table) nor CDO's conservative remap weights.  Only
-the structure (k-NN stencil, symmetric normalized Laplacian, row-stochastic pooling
-matrices satisfying the invariants asserted at ``modules/layers.py:540-571``) matches.
+per-(k, nside) optimal kernel width table), and the conservative remap weights
+(``dsw_amd.conservative``: overlap areas of the spherical Voronoi meshes) are checked
+against the invariants the reference asserts on CDO's output (``modules/layers.py:540-571``),
+not against CDO's numbers (CDO is absent).
 Everything downstream (ConvCheb, RemapBlock) takes the operator as an input, so parity
 tests always feed the *same prepared operator* to reference and build.
 """
@@ -31,6 +32,8 @@ __all__ = [
     "healpix_pool_matrices",
     "equiangular_pool_matrices",
     "knn_interp_pool_matrices",
+    "conservative_pool_matrices",
+    "cell_areas",
     "build_pooling_matrices",
 ]
 
@@ -290,13 +293,42 @@ def _normalise_pool_unpool(weights):
     return sparse.coo_matrix(pool), sparse.coo_matrix(unpool)
 
 
-def build_pooling_matrices(src_graph, dst_graph):
-    """Build (pool, unpool) between two graphs of this module (src = finer)."""
-    if isinstance(src_graph, SphereHealpix) and isinstance(dst_graph, SphereHealpix):
-        if src_graph.subdivisions == 2 * dst_graph.subdivisions and src_graph.nest == dst_graph.nest:
-            return healpix_pool_matrices(src_graph.subdivisions, src_graph.nest)
-    if isinstance(src_graph, SphereEquiangular) and isinstance(dst_graph, SphereEquiangular):
-        c = src_graph.nlat // dst_graph.nlat
-        if c >= 1 and dst_graph.nlat * c == src_graph.nlat and dst_graph.nlon * c == src_graph.nlon:
-            return equiangular_pool_matrices(src_graph.nlat, src_graph.nlon, c)
-    return knn_interp_pool_matrices(src_graph.coords, dst_graph.coords)
+def cell_areas(graph) -> np.ndarray:
+    """Area of every node's cell (steradians): HEALPix pixels are equal-area by construction, any other sampling gets
+    the areas of its spherical Voronoi cells (what xsphere hands to CDO, loss.py:60-68)."""
+    if isinstance(graph, SphereHealpix):
+        return np.full(graph.n_vertices, 4.0 * np.pi / graph.n_vertices)
+    from . import conservative
+
+    return conservative.voronoi_cells(graph.coords)[2]
+
+
+def conservative_pool_matrices(src_coords, dst_coords):
+    """(pool, unpool) from first-order conservative remapping weights between the spherical Voronoi meshes of two
+    samplings - the construction of ``layers.py:529-581`` with xsphere + CDO replaced by ``dsw_amd.conservative``."""
+    from . import conservative
+
+    weights, _ = conservative.interpolation_matrix(src_coords, dst_coords)
+    return _normalise_pool_unpool(weights)
+
+
+def build_pooling_matrices(src_graph, dst_graph, method="auto"):
+    """Build (pool, unpool) between two graphs of this module (src = finer).
+
+    ``auto``: exact shortcuts where the two samplings nest (HEALPix parent / children, equiangular c x c blocks: the
+    conservative weights of the true pixels are known in closed form), otherwise conservative overlap areas of the
+    spherical Voronoi meshes (``conservative``), which is what the reference computes for every pair.
+    ``knn``: the cheap inverse-distance stand-in (not area-conserving; kept for huge irregular pairs)."""
+    if method not in ("auto", "conservative", "knn"):
+        raise ValueError("method must be 'auto', 'conservative' or 'knn'")
+    if method == "auto":
+        if isinstance(src_graph, SphereHealpix) and isinstance(dst_graph, SphereHealpix):
+            if src_graph.subdivisions == 2 * dst_graph.subdivisions and src_graph.nest == dst_graph.nest:
+                return healpix_pool_matrices(src_graph.subdivisions, src_graph.nest)
+        if isinstance(src_graph, SphereEquiangular) and isinstance(dst_graph, SphereEquiangular):
+            c = src_graph.nlat // dst_graph.nlat
+            if c >= 1 and dst_graph.nlat * c == src_graph.nlat and dst_graph.nlon * c == src_graph.nlon:
+                return equiangular_pool_matrices(src_graph.nlat, src_graph.nlon, c)
+    if method == "knn":
+        return knn_interp_pool_matrices(src_graph.coords, dst_graph.coords)
+    return conservative_pool_matrices(src_graph.coords, dst_graph.coords)

@@ -1,0 +1,75 @@
+"""Loss of the training harness: counterpart of the hot-path subset of ``/root/reference/modules/loss.py``.
+
+``reshape_tensors_4_loss`` (``:31-54``) and ``WeightedMSELoss`` (``:118-156``) keep the reference's names, signatures,
+reductions and error messages.  ``AreaWeights`` (``:60-68``) needs CDO in the reference; here the cell areas come from
+``dsw_amd.sphere`` (HEALPix pixels are equal-area by construction; other samplings use their Voronoi-cell areas).
+Plotting helpers are out of scope.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+
+def reshape_tensors_4_loss(Y_pred, Y_obs, dim_info_dynamic):
+    """``(data_points, node, feature)`` views of prediction and observation: every dimension other than ``node`` and
+    ``feature`` is flattened, in the tensors' own dimension order (``dim_info_dynamic``: name -> axis)."""
+    names = [k for k, _ in sorted(dim_info_dynamic.items(), key=lambda item: item[1])]
+    lead = [i for i, n in enumerate(names) if n not in ("node", "feature")]
+    order = lead + [names.index("node"), names.index("feature")]
+
+    def flat(t):
+        t = t.permute(*order)
+        return t.reshape(-1, t.shape[-2], t.shape[-1])
+
+    return flat(Y_pred), flat(Y_obs)
+
+
+def AreaWeights(graph):
+    """Per-node area fractions (sum to 1) as a float32 tensor."""
+    from dsw_amd import sphere
+
+    area = sphere.cell_areas(graph)
+    return torch.from_numpy((area / np.sum(area)).astype(np.float32))
+
+
+class WeightedMSELoss(nn.MSELoss):
+    """Squared error weighted per node.  ``pred`` / ``label``: ``(data_points, node, feature)``.
+
+    ``reduction='mean'``: ``sum(w * err^2) / sum(w) / n_data_points / n_feature``; ``'sum'``: ``sum(w * err^2) * n_node``;
+    ``'none'``: the weighted element-wise errors."""
+
+    def __init__(self, reduction="mean", weights=None):
+        super().__init__(reduction="none")
+        if not isinstance(reduction, str) or reduction not in ("mean", "sum", "none"):
+            raise ValueError("{} is not a valid value for reduction".format(reduction))
+        self.weighted_mse_reduction = reduction
+        if weights is not None:
+            self.check_weights(weights)
+        self.weights = weights
+
+    def forward(self, pred, label):
+        mse = super().forward(pred, label)
+        weights = self.weights
+        n_batch, num_nodes, n_val = mse.shape
+        if weights is None:
+            weights = torch.ones((num_nodes), dtype=mse.dtype, device=mse.device)
+        if num_nodes != len(weights):
+            raise ValueError(
+                "The number of weights does not match the the number of pixels. {} != {}".format(len(weights), num_nodes)
+            )
+        if weights.device != mse.device or weights.dtype != mse.dtype:
+            weights = weights.to(device=mse.device, dtype=mse.dtype)
+            if self.weights is not None:
+                self.weights = weights      # moved once: later calls (and HIP-graph captures) see a resident tensor
+        weighted_mse = mse * weights.view(1, -1, 1)
+        if self.weighted_mse_reduction == "sum":
+            return torch.sum(weighted_mse) * len(weights)
+        if self.weighted_mse_reduction == "mean":
+            return torch.sum(weighted_mse) / torch.sum(weights) / n_batch / n_val
+        return weighted_mse
+
+    def check_weights(self, weights):
+        if not isinstance(weights, torch.Tensor):
+            raise TypeError("Weights type is not a torch.Tensor. Got {}".format(type(weights)))
+        if len(weights.shape) != 1:
+            raise ValueError("Weights is a 1D vector. Got {}".format(weights.shape))

@@ -7,9 +7,13 @@ Counterpart of the harness that drives the hot path in the reference - ``main()`
 packages (xforecasting / xscaler / zarr data): JSON config (same ``model_settings`` / ``training_settings`` /
 ``ar_settings`` schema as ``configs/UNetSpherical/*/*.json``) -> model through the ``architecture_name`` +
 inspect-filtered kwargs convention -> ``.to(device)`` -> Adam(eps=1e-7) (``train_predict_state.py:334-340``)
--> autoregressive steps: ``ar_iterations`` forwards per optimisation step, the prediction replacing the most
-recent dynamic features of the input window (``stack_most_recent_prediction``), MSE summed over the
+-> ``WeightedMSELoss`` with the sampling's area weights (``:325-330``, ``modules/loss.py:118-156``) ->
+autoregressive steps: ``ar_iterations`` + 1 forwards per optimisation step, the prediction replacing the most
+recent dynamic features of the input window (``stack_most_recent_prediction``), the loss summed over the
 iterations, one backward, one flat-bucket gradient all-reduce when launched under torchrun, optimizer step.
+The whole step (~77 ConvCheb launches x 7 forwards at the default config) is captured once into a HIP graph and
+replayed; under torchrun parameters and operator buffers are broadcast from rank 0 first (ARPACK's lambda_max
+estimate is not deterministic, so independently built replicas would not share one operator).
 
     python scripts_training/train_synthetic_state.py --config_file configs/UNetSpherical/Healpix_400km/InterpPool-Graph_knn.synthetic.json --steps 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 scripts_training/train_synthetic_state.py ...
@@ -72,19 +76,142 @@ def get_pytorch_model(module, model_settings):
     return cls(**{k: v for k, v in model_settings.items() if k in accepted})
 
 
-def ar_training_step(model, x, targets, n_dyn, stack_most_recent_prediction=True):
-    """One autoregressive pass: ``len(targets)`` forwards; returns the summed MSE.
+def ar_training_step(model, x, targets, n_dyn, stack_most_recent_prediction=True, criterion=None, dim_info=None):
+    """One autoregressive pass: ``len(targets)`` forwards; returns the summed loss.
     x [B, T, V, F]; each target [B, 1, V, n_dyn]; the dynamic features are the LAST n_dyn features (the model's
-    increment path reads ``x[:, -1, :, -2:]``, my_models_graph.py:494)."""
+    increment path reads ``x[:, -1, :, -2:]``, my_models_graph.py:494).  ``criterion`` = a ``WeightedMSELoss`` applied
+    to ``reshape_tensors_4_loss`` views as in the reference's training loop (loss.py:31-54,118-156); None = plain MSE."""
     loss = x.new_zeros(())
     for target in targets:
         y = model(x)
-        loss = loss + torch.mean((y - target) ** 2)
+        if criterion is None:
+            loss = loss + torch.mean((y - target) ** 2)
+        else:
+            from modules.loss import reshape_tensors_4_loss
+
+            loss = loss + criterion(*reshape_tensors_4_loss(y, target, dim_info))
         if stack_most_recent_prediction and len(targets) > 1:
             nxt = x[:, -1:].clone()
             nxt[..., -n_dyn:] = y[:, -1:]
             x = torch.cat((x[:, 1:], nxt), dim=1)
     return loss
+
+
+class Trainer:
+    """model + WeightedMSELoss + Adam(eps=1e-7) + one flat-bucket gradient all-reduce, stepping on static
+    HBM-resident tensors.  ``step()`` launches the whole optimisation step - zero_grad, the AR forwards, backward,
+    optimizer update - as ONE HIP graph replay when ``use_graph`` (single process; with N > 1 ranks the graph ends after
+    the gradients are packed into the bucket, the RCCL all-reduce and the optimizer update follow eagerly)."""
+
+    def __init__(self, model, x, targets, n_dyn, lr, weights=None, stack=True, use_graph=True, dim_names=None):
+        from dsw_amd.parallel import FlatGradAllReduce
+        from modules.loss import WeightedMSELoss
+
+        self.model, self.x, self.targets, self.n_dyn, self.stack = model, x, targets, n_dyn, stack
+        dim_names = dim_names or ["sample", "time", "node", "feature"]
+        self.dim_info = {n: i for i, n in enumerate(dim_names)}
+        self.criterion = WeightedMSELoss(weights=None if weights is None else weights.to(x.device, x.dtype))
+        self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized() \
+            and torch.distributed.get_world_size() > 1
+        # capturable: the step counter lives on the device, so optimizer.step() can sit inside a HIP graph
+        self.optimizer = torch.optim.Adam(model.parameters(), lr=lr, eps=1e-7, weight_decay=0, amsgrad=False,
+                                          capturable=bool(use_graph and x.is_cuda))
+        self.sync_grads = FlatGradAllReduce(model.parameters())
+        self.loss = None
+        self.graph = None
+        self.launch = "eager"
+        if use_graph and x.is_cuda:
+            self._capture()
+
+    def _fwd_bwd(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = ar_training_step(self.model, self.x, self.targets, self.n_dyn, self.stack, self.criterion, self.dim_info)
+        loss.backward()
+        return loss.detach()
+
+    def _eager_step(self):
+        loss = self._fwd_bwd()
+        self.sync_grads()
+        self.optimizer.step()
+        return loss
+
+    def _capture(self):
+        # warm-up on a side stream (operator caches, tile plans, allocator pools, Adam state), then capture.  The
+        # warm-up steps must not count: parameters and optimizer state are restored afterwards.
+        saved = [p.detach().clone() for p in self.model.parameters()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.loss = self._fwd_bwd()
+                if not self.distributed:
+                    self.optimizer.step()
+            self.graph = g
+            self.launch = "hip graph: whole step" if not self.distributed else "hip graph: fwd+bwd, eager all-reduce + Adam"
+        except Exception as exc:  # noqa: BLE001 - capture not possible: stay eager
+            print("trainer: HIP graph capture unavailable (%s: %s); stepping eagerly" % (type(exc).__name__, exc),
+                  file=sys.stderr)
+            self.graph = None
+            torch.cuda.synchronize()
+        with torch.no_grad():
+            for p, v in zip(self.model.parameters(), saved):
+                p.copy_(v)
+            for st in self.optimizer.state.values():
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        v.zero_()
+
+    def step(self):
+        if self.graph is None:
+            return self._eager_step()
+        self.graph.replay()
+        if self.distributed:
+            self.sync_grads()
+            self.optimizer.step()
+        return self.loss
+
+
+def build_trainer(cfg, device, dtype=None, batch_size=None, ar_iterations=None, rank=0, use_graph=True, model=None,
+                  weights=None):
+    """config -> (Trainer, info dict): what ``main`` and the tests share."""
+    import modules.my_models_graph as my_architectures
+    from dsw_amd.parallel import broadcast_module_state
+    from modules.loss import AreaWeights
+
+    ms, ts, ar, syn = cfg["model_settings"], cfg["training_settings"], cfg["ar_settings"], cfg["synthetic_settings"]
+    dtype = dtype or _PRECISIONS.get(ts.get("numeric_precision", "float32"))
+    if dtype is None:
+        raise ValueError("numeric_precision: the HIP path implements 'float32' and 'bfloat16'")
+    ms = dict(ms)
+    ms["tensor_info"] = synthetic_tensor_info(cfg)
+    if model is None:
+        torch.manual_seed(ts.get("seed_model_weights", 10))
+        model = get_pytorch_model(my_architectures, ms)
+    model = model.to(device).to(dtype)
+    # replicas must share ONE set of operators and weights: lambda_max comes from ARPACK with a random start vector
+    broadcast_module_state(model, src=0)
+    if weights is None:
+        weights = AreaWeights(model.graphs[0])                      # train_predict_state.py:327
+    B = batch_size or ts.get("training_batch_size", 16)
+    info = ms["tensor_info"]
+    V, T, F = info["input_shape_info"]["dynamic"]["node"], info["input_n_time"], info["input_n_feature"]
+    n_dyn = info["output_n_feature"]
+    n_ar = (ar.get("ar_iterations", 0) if ar_iterations is None else ar_iterations) + 1
+    g = torch.Generator(device=device).manual_seed(syn.get("seed_data", 1234) + rank)
+    x = torch.randn(B, T, V, F, device=device, dtype=dtype, generator=g)
+    targets = [torch.randn(B, info["output_n_time"], V, n_dyn, device=device, dtype=dtype, generator=g)
+               for _ in range(n_ar)]
+    trainer = Trainer(model, x, targets, n_dyn, ts.get("learning_rate", 0.007), weights=weights,
+                      stack=ar.get("stack_most_recent_prediction", True), use_graph=use_graph,
+                      dim_names=info["dim_order"]["dynamic"])
+    return trainer, {"B": B, "V": V, "n_ar": n_ar, "architecture": ms["architecture_name"],
+                     "parameters": sum(p.numel() for p in model.parameters())}
 
 
 def main(argv=None):
@@ -94,14 +221,13 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch_size", type=int, default=None, help="per GPU; default training_batch_size of the config")
     ap.add_argument("--ar_iterations", type=int, default=None, help="override ar_settings.ar_iterations")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     args = ap.parse_args(argv)
 
-    import modules.my_models_graph as my_architectures
     from dsw_amd import _native
-    from dsw_amd.parallel import FlatGradAllReduce, init_from_env
+    from dsw_amd.parallel import init_from_env
 
     cfg = read_config(args.config_file)
-    ms, ts, ar, syn = cfg["model_settings"], cfg["training_settings"], cfg["ar_settings"], cfg["synthetic_settings"]
     rank, world, local = init_from_env()
     if not torch.cuda.is_available():
         raise RuntimeError("the ConvCheb hot path runs only on a ROCm device (no CPU fallback)")
@@ -109,54 +235,26 @@ def main(argv=None):
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    dtype = _PRECISIONS.get(ts.get("numeric_precision", "float32"))
-    if dtype is None:
-        raise ValueError("numeric_precision: the HIP path implements 'float32' and 'bfloat16'")
-
-    ms = dict(ms)
-    ms["tensor_info"] = synthetic_tensor_info(cfg)
-    torch.manual_seed(ts.get("seed_model_weights", 10))
-    model = get_pytorch_model(my_architectures, ms).to(device).to(dtype)
-    n_params = sum(p.numel() for p in model.parameters())
-    optimizer = torch.optim.Adam(model.parameters(), lr=ts.get("learning_rate", 0.007), eps=1e-7,
-                                 weight_decay=0, amsgrad=False)
-    sync_grads = FlatGradAllReduce(model.parameters())
-
-    B = args.batch_size or ts.get("training_batch_size", 16)
-    info = ms["tensor_info"]
-    V, T, F = info["input_shape_info"]["dynamic"]["node"], info["input_n_time"], info["input_n_feature"]
-    n_dyn = info["output_n_feature"]
-    n_ar = (ar.get("ar_iterations", 0) if args.ar_iterations is None else args.ar_iterations) + 1
-    g = torch.Generator(device=device).manual_seed(syn.get("seed_data", 1234) + rank)
-    x = torch.randn(B, T, V, F, device=device, dtype=dtype, generator=g)
-    targets = [torch.randn(B, info["output_n_time"], V, n_dyn, device=device, dtype=dtype, generator=g)
-               for _ in range(n_ar)]
+    trainer, info = build_trainer(cfg, device, batch_size=args.batch_size, ar_iterations=args.ar_iterations, rank=rank,
+                                  use_graph=not args.no_graph)
 
     losses = []
-
-    def step():
-        optimizer.zero_grad(set_to_none=True)
-        loss = ar_training_step(model, x, targets, n_dyn, ar.get("stack_most_recent_prediction", True))
-        loss.backward()
-        sync_grads()
-        optimizer.step()
-        return loss.detach()
-
     for _ in range(args.warmup):
-        losses.append(step())
+        losses.append(trainer.step().clone())
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses.append(step())
+        losses.append(trainer.step().clone())
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / max(args.steps, 1)
     losses = [float(v) for v in losses]
     if rank == 0:
         print(json.dumps({
-            "architecture": ms["architecture_name"], "parameters": n_params, "n_gpus": world,
-            "batch_per_gpu": B, "nodes": V, "forwards_per_step": n_ar, "ms_per_step": dt * 1e3,
-            "samples_per_s": B * world / dt, "loss_first": losses[0], "loss_last": losses[-1],
-            "dtype": str(dtype).replace("torch.", ""), "data": "synthetic",
+            "architecture": info["architecture"], "parameters": info["parameters"], "n_gpus": world,
+            "batch_per_gpu": info["B"], "nodes": info["V"], "forwards_per_step": info["n_ar"], "ms_per_step": dt * 1e3,
+            "samples_per_s": info["B"] * world / dt, "loss_first": losses[0], "loss_last": losses[-1],
+            "launch": trainer.launch, "loss": "WeightedMSELoss(area weights)",
+            "dtype": str(trainer.x.dtype).replace("torch.", ""), "data": "synthetic",
         }))
     return losses
 

@@ -10,6 +10,7 @@ G8  GeneralMaxValPool / GeneralMaxValUnpool (layers.py:1040-1103) and GeneralMax
 G9  one autoregressive optimisation run of the reference UNetSpherical (nside=8) with the reference WeightedMSELoss
     (loss.py:118-156) and torch Adam(eps=1e-7) (train_predict_state.py:334-340): three steps of two forwards each.
 """
+import importlib.machinery
 import os
 import sys
 import types
@@ -31,7 +32,9 @@ def _import_ref_loss():
         try:
             __import__(name)
         except Exception:
-            sys.modules[name] = types.ModuleType(name)
+            stub = types.ModuleType(name)
+            stub.__spec__ = importlib.machinery.ModuleSpec(name, loader=None)   # torch probes find_spec() of known names
+            sys.modules[name] = stub
     if not hasattr(sys.modules["cartopy"], "crs"):
         sys.modules["cartopy"].crs = sys.modules["cartopy.crs"]
     import modules.loss as ref_loss
@@ -87,6 +90,9 @@ def g8():
     save("G8_maxpool", **arrays)
 
 
+G9_LR = 2e-4   # Adam moves every parameter by ~lr per step: 0.007 (the config default) blows this random model up
+
+
 def g9():
     ref_loss = _import_ref_loss()
     ref_layers.build_pooling_matrices = sphere.build_pooling_matrices
@@ -109,7 +115,7 @@ def g9():
     weights = torch.from_numpy(recipes.ar_area_weights(V))
     criterion = ref_loss.WeightedMSELoss(weights=weights)                  # loss.py:118-156
     dim_info = {"sample": 0, "time": 1, "node": 2, "feature": 3}
-    optimizer = torch.optim.Adam(model.parameters(), lr=0.007, eps=1e-7, weight_decay=0, amsgrad=False)
+    optimizer = torch.optim.Adam(model.parameters(), lr=G9_LR, eps=1e-7, weight_decay=0, amsgrad=False)
     x0 = torch.from_numpy(recipes.rand(901, (2, 3, V, 6)))
     targets = [torch.from_numpy(recipes.rand(902 + i, (2, 1, V, 2))) for i in range(2)]   # ar_iterations = 1
     losses, grad_probes0, upd_l2, heads = [], None, None, None
@@ -133,7 +139,7 @@ def g9():
             heads = np.stack([np.resize(params[n].detach().numpy().ravel()[:32], 32) for n in names])
         losses.append(loss.item())
     arrays = {"losses": np.array(losses), "grad_probes0": grad_probes0, "update_l2": upd_l2, "param_heads1": heads,
-              "param_names": np.array(names), "weights": weights.numpy()}
+              "param_names": np.array(names), "weights": weights.numpy(), "lr": np.array([G9_LR])}
     for lvl, lap in enumerate(model.laplacians):
         rp, ci, va = csr_of(lap)
         arrays.update({f"lap{lvl}_rowptr": rp, f"lap{lvl}_colind": ci, f"lap{lvl}_values": va})

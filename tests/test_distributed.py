@@ -83,3 +83,43 @@ def test_shard_batch_covers_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _bcast_worker(rank, world, port, out):
+    for p in (os.path.join(REPO, "deepsphere-weather_amd"), REPO, os.path.join(REPO, "tests"), os.path.join(REPO, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from dsw_amd import sphere
+    from dsw_amd.parallel import broadcast_module_state, init_from_env
+    from modules.layers import ConvCheb, GeneralAvgPool, prepare_torch_laplacian
+
+    init_from_env("gloo")
+    g = sphere.SphereHealpix(4, nest=True, k=8)
+    # every rank prepares its OWN operator: the ARPACK estimate of lambda_max has a random start vector; pin the
+    # difference so that the test does not depend on luck
+    np.random.seed(100 + rank)
+    lap = prepare_torch_laplacian(g.L.copy(), lmax=1.93 + 1e-3 * rank)
+    torch.manual_seed(rank)                                   # and different initial weights
+    model = torch.nn.Sequential(ConvCheb(4, 8, 3, laplacian=lap), ConvCheb(8, 8, 2, laplacian=lap.clone()))
+    model.add_module("pool", GeneralAvgPool(sphere.healpix_pool_matrices(4, True)[0] * (1.0 + rank)))
+    before = model[0].laplacian._values().clone()
+    broadcast_module_state(model, src=0)
+    out[rank] = (before, model[0].laplacian._values().clone(), model[1].laplacian._values().clone(),
+                 model[0].weight.detach().clone(), model[1].bias.detach().clone(), model.pool.remap_matrix._values().clone(),
+                 model[0].laplacian._indices().clone())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_broadcast_makes_operators_and_parameters_identical():
+    """replicas must not convolve with differently scaled Laplacians."""
+    world = 2
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_bcast_worker, args=(world, port, out), nprocs=world, join=True)
+    assert not torch.equal(out[0][0], out[1][0])                 # the operators did differ before the broadcast
+    for k in range(1, 7):
+        assert torch.equal(out[0][k], out[1][k]), k
+    assert torch.equal(out[0][0], out[0][1])                     # rank 0's state is the one that survives

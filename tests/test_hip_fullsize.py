@@ -184,7 +184,7 @@ def test_unet_nside32_batch8_vs_cpu_restatement():
         y = m(x.to(dev))
         loss = ((y - target.to(dev)) ** 2).mean()
         loss.backward()
-        return y.detach().cpu(), float(loss), {n: p.grad.detach().cpu() for n, p in m.named_parameters()}
+        return y.detach().cpu(), loss.item(), {n: p.grad.detach().cpu() for n, p in m.named_parameters()}
 
     functional.set_test_backend(OracleBackend())
     try:
@@ -199,13 +199,22 @@ def test_unet_nside32_batch8_vs_cpu_restatement():
     sd = unet_oracle.leaf_state(model.state_dict())
     y_t, loss_t, g_t = unet_oracle.unet_fwd_bwd(sd, x, target)
     y_dev, loss_dev, g_dev = run(model.to(DEV), DEV)
+    # weight tensors [Fin, K, Fout] / [Fout, Fin] vs the 1-D ones (biases, ReZero scalars): the latter are plain sums of
+    # ~1e6 signed products whose fp32 evaluation cancels heavily - the reference's own fp32 CPU path is 1.2e-4 off fp64
+    # there (recorded as torch32_vs_f64_*), so they get the looser bound
+    mats = [n for n in names if g_ref[n].dim() >= 2]
+    vecs = [n for n in names if g_ref[n].dim() < 2]
+    worst = lambda pool, a, b: max(orc.max_rel_err(a[n], b[n]) for n in pool)
     errs = {"y": orc.max_rel_err(y_dev, y_ref), "loss": abs(loss_dev - loss_ref) / max(1.0, abs(loss_ref)),
-            "grad_max": max(orc.max_rel_err(g_dev[n], g_ref[n]) for n in names),
+            "grad_weights_max": worst(mats, g_dev, g_ref), "grad_bias_rezero_max": worst(vecs, g_dev, g_ref),
             "y_vs_torch32": orc.max_rel_err(y_dev, y_t),
-            "grad_max_vs_torch32": max(orc.max_rel_err(g_dev[n], g_t[n]) for n in names),
-            "torch32_vs_f64_grad_max": max(orc.max_rel_err(g_t[n], g_ref[n]) for n in names)}
+            "grad_weights_max_vs_torch32": worst(mats, g_dev, g_t), "grad_bias_rezero_max_vs_torch32": worst(vecs, g_dev, g_t),
+            "torch32_vs_f64_grad_weights_max": worst(mats, g_t, g_ref),
+            "torch32_vs_f64_grad_bias_rezero_max": worst(vecs, g_t, g_ref)}
     _record("unet_nside32_B8_fp32", errs)
-    worst = max(names, key=lambda n: orc.max_rel_err(g_dev[n], g_ref[n]))
+    worst_name = max(names, key=lambda n: orc.max_rel_err(g_dev[n], g_ref[n]))
+    print("worst gradient tensor:", worst_name, orc.max_rel_err(g_dev[worst_name], g_ref[worst_name]))
     assert errs["y"] <= 1e-5 and errs["loss"] <= 1e-5, errs
-    assert errs["grad_max"] <= 2e-5, (worst, errs)
-    assert errs["y_vs_torch32"] <= 1e-5 and errs["grad_max_vs_torch32"] <= 3e-4, errs
+    assert errs["grad_weights_max"] <= 1e-5, (worst_name, errs)
+    assert errs["grad_bias_rezero_max"] <= 1e-4, (worst_name, errs)
+    assert errs["y_vs_torch32"] <= 1e-5 and errs["grad_weights_max_vs_torch32"] <= 1e-4, errs

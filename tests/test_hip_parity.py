@@ -695,3 +695,17 @@ def test_rezero_residual_unaligned_views():
     assert orc.max_rel_err(y, (0.3 * c.detach().double() + r.double()).cpu().numpy()) <= TOL_F64
     assert orc.max_rel_err(c.grad, (0.3 * g.double()).cpu().numpy()) <= TOL_F64
     assert abs(float(w.grad) - float((g.double() * c.detach().double()).sum())) <= 1e-4
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_ar_training_steps_golden_g9(use_graph):
+    """Three autoregressive optimisation steps of the training driver (UNetSpherical nside=8, WeightedMSELoss, Adam
+    eps=1e-7; two forwards per step) against the reference run of fixture G9 - launched eagerly and as a replayed HIP
+    graph of the whole step (zero_grad + forwards + backward + Adam)."""
+    from test_host_logic import build_g9_trainer, check_g9
+
+    trainer, g, names = build_g9_trainer(DEV, use_graph=use_graph)
+    if use_graph:
+        assert trainer.graph is not None and trainer.launch.startswith("hip graph"), trainer.launch
+    losses = check_g9(trainer, g, names)
+    print("G9 losses", losses, "reference", g["losses"])
