@@ -228,9 +228,9 @@ int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* 
     const int64_t need = dsw_cheb_bwd_workspace_bytes(B, V, Fin, Fout, K, dtype);
     if (!workspace || workspace_bytes < need) return DSW_ERR_WORKSPACE;
     const bool mf = mix_first(Fin, Fout, K);
-    if (!dY || !X || !W || (K > 1 && !T && !mf)) return DSW_ERR_BAD_ARG;
     const int64_t N = B * V;
     hipStream_t s = (hipStream_t)stream;
+    if (N > 0 && (!dY || !X || !W || (K > 1 && !T && !mf))) return DSW_ERR_BAD_ARG;
     if (N == 0) {   // an empty batch shard (B < world size): the parameter gradients are exactly zero, not "unwritten"
         if (dW && hipMemsetAsync(dW, 0, (size_t)(Fin * K * Fout * elem_size(dtype)), s) != hipSuccess) return DSW_ERR_LAUNCH;
         if (db && hipMemsetAsync(db, 0, (size_t)(Fout * elem_size(dtype)), s) != hipSuccess) return DSW_ERR_LAUNCH;

@@ -86,6 +86,7 @@ struct Hop2Args {
     int n_chunks;               // batch chunks per tile (grid = n_tiles * n_chunks)
     int spc;                    // samples per chunk
     int ell_w;                  // ELL width in LDS: max row length of the plan rounded up to 4
+    int single_buf;             // 1: one input-row buffer (halves the staging LDS so that a second workgroup fits the CU)
 };
 
 
@@ -179,7 +180,8 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     // LDS carve-up (all offsets multiples of 16)
     unsigned char* bufX0 = lds;                                            // [max_n2][row_bytes], sample s
-    unsigned char* bufX1 = bufX0 + (size_t)P.max_n2 * P.row_bytes;         // [max_n2][row_bytes], sample s+1
+    // sample s+1 (aliases bufX0 when single-buffered: the loop then ends with a barrier so that nobody still reads it)
+    unsigned char* bufX1 = P.single_buf ? bufX0 : bufX0 + (size_t)P.max_n2 * P.row_bytes;
     unsigned char* bufT = bufX1 + (size_t)P.max_n2 * P.row_bytes;          // [max_n1][row_bytes]
     uint2* ell = reinterpret_cast<uint2*>(bufT + (size_t)P.max_n1 * P.row_bytes);   // [max_n1][W] {col, val}
     int* rows = reinterpret_cast<int*>(ell + (size_t)P.max_n1 * P.ell_w);  // [max_n2] global row ids
@@ -338,7 +340,8 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
                 *reinterpret_cast<uint4*>(P.Y2 + sample + (size_t)(r0 + i) * P.row_bytes + cb) = R::pack(o);
             }
         }
-        // no barrier here: the next iteration writes the OTHER bufX, and its barrier orders bufT reuse
+        // double-buffered: no barrier here - the next iteration writes the OTHER bufX, and its barrier orders bufT reuse
+        if (P.single_buf) __syncthreads();   // phase 2 still read this bufX (the b2 * U term)
     }
 }
 
@@ -349,8 +352,8 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
 // plan carries it in `reserved` (hop2.py); 0 = unknown -> not supported.
 static int hop2_ell_w(const dsw_hop2_plan* plan) { return (plan->reserved + 3) & ~3; }
 
-static size_t hop2_lds_bytes(const dsw_hop2_plan* plan, int row_bytes) {
-    size_t s = (size_t)(plan->max_n1 + 2 * (size_t)plan->max_n2) * row_bytes;   // bufT + double-buffered bufX
+static size_t hop2_lds_bytes(const dsw_hop2_plan* plan, int row_bytes, bool single_buf = false) {
+    size_t s = (size_t)(plan->max_n1 + (single_buf ? 1 : 2) * (size_t)plan->max_n2) * row_bytes;   // bufT + bufX (x2)
     s += (size_t)plan->max_n1 * hop2_ell_w(plan) * 8;
     s += (size_t)((plan->max_n2 + 3) & ~3) * 4 + 16;   // row ids + the tile's loop length
     return (s + 15) & ~(size_t)15;
@@ -364,7 +367,7 @@ int dsw_spmm2_supported(const dsw_hop2_plan* plan, int64_t C, int dtype) {
     if (row_bytes % 16 != 0 || row_bytes / 16 > NTHREADS) return 0;
     const int64_t rpp = NTHREADS / (row_bytes / 16);
     if ((plan->max_n2 + rpp - 1) / rpp > MAXST) return 0;   // register staging capacity
-    return hop2_lds_bytes(plan, (int)row_bytes) <= 160 * 1024 ? 1 : 0;
+    return hop2_lds_bytes(plan, (int)row_bytes, true) <= 160 * 1024 ? 1 : 0;
 }
 
 namespace {
@@ -412,7 +415,12 @@ int dsw_spmm2_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const 
     A.max_n1 = plan->max_n1; A.max_n2 = plan->max_n2; A.max_nnz = plan->max_nnz;
     A.row_bytes = (int)(C * es); A.lpr = A.row_bytes / 16; A.B = (int)B;
     A.ell_w = hop2_ell_w(plan);
-    const size_t lds = hop2_lds_bytes(plan, A.row_bytes);
+    // staging buffers: double-buffered input rows unless that costs the second resident workgroup (<= 80 KiB each) or
+    // does not fit at all - the k = 20 stencil's 2-ring is 4x the tile, and 8 waves per CU cannot hide the LDS latency
+    const size_t lds2 = hop2_lds_bytes(plan, A.row_bytes, false), lds1 = hop2_lds_bytes(plan, A.row_bytes, true);
+    A.single_buf = (lds2 <= 80 * 1024) ? 0 : (lds1 <= 80 * 1024) ? 1 : (lds2 <= 160 * 1024) ? 0 : 1;
+    { static const char* sb = getenv("DSW_H2_SINGLE"); if (sb) A.single_buf = (sb[0] == '1') && lds1 <= 160 * 1024 ? 1 : (lds2 <= 160 * 1024 ? 0 : 1); }   // diagnostics
+    const size_t lds = A.single_buf ? lds1 : lds2;
     // batch chunks.  A workgroup = (tile, chunk of the batch); the launch runs in ceil(n_tiles * chunks / slots) rounds
     // over the resident slots, each round costing the plan staging (about 1.5 samples' worth) plus the samples of a
     // chunk: pick the chunk count that minimises rounds * (1.5 + samples per chunk).  (NS: 768 tiles on 512 slots -> 2

@@ -97,12 +97,13 @@ class CsrOperator:
 
             # largest tile whose workgroup still leaves room for >= 2 workgroups per CU (<= 80 KiB of
             # the 160 KiB LDS); a single resident workgroup (<= 156 KiB) is the last resort
-            for budget in (80 * 1024, 156 * 1024):
+            # (the kernel drops to ONE input-row buffer when that is what lets a second workgroup share the CU)
+            for budget, single in ((80 * 1024, False), (80 * 1024, True), (156 * 1024, False), (156 * 1024, True)):
                 for rows in ((int(forced),) if forced else (256, 128, 64)):
                     if rows > self.shape[0]:
                         continue
                     cand = host_plan(rows)
-                    if cand is not None and cand.lds_bytes(row_bytes) <= budget:
+                    if cand is not None and cand.lds_bytes(row_bytes, single) <= budget:
                         plan = cand
                         break
                 if plan is not None:

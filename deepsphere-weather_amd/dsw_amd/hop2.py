@@ -60,11 +60,11 @@ class Hop2Plan:
         self._struct = None
         self._dev = None
 
-    def lds_bytes(self, row_bytes: int) -> int:
+    def lds_bytes(self, row_bytes: int, single_buf: bool = False) -> int:
         """LDS the kernel carves (must match hop2_lds_bytes in csrc/dsw_spmm2.hip): the input rows on
-        S2, the first-hop rows on S1, {col, val} pairs, local row pointers, the gather list."""
+        S2 (two buffers unless ``single_buf``), the first-hop rows on S1, {col, val} pairs, the gather list."""
         ell_w = (self.max_row_len + 3) & ~3
-        s = (self.max_n1 + 2 * self.max_n2) * row_bytes   # bufT + double-buffered input rows
+        s = (self.max_n1 + (1 if single_buf else 2) * self.max_n2) * row_bytes   # bufT + input rows
         s += self.max_n1 * ell_w * 8                      # ELL {col, val}
         s += ((self.max_n2 + 3) & ~3) * 4 + 16            # gather list + the tile's loop length
         return (s + 15) & ~15
