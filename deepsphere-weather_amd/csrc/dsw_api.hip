@@ -30,6 +30,9 @@ int dsw_bwd_gemm_fused_try(const void* X, const void* T, const void* W, const vo
                            hipStream_t stream, int* rc);
 int dsw_zmix_launch(const void* X, const void* W, const void* bias, void* Z0, void* Zrest, int64_t N, int64_t Fin,
                     int64_t Fout, int64_t K, int dtype, hipStream_t stream);
+int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X, const void* W, const void* bias, void* Y,
+                            void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
+                            int* rc);
 int dsw_zdgrad_launch(const void* dY, const void* D, const void* W, void* dX, int64_t N, int64_t Fin, int64_t Fout,
                       int64_t K, int dtype, hipStream_t stream);
 
@@ -194,6 +197,11 @@ int dsw_cheb_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals
         // the Clenshaw recurrence has exactly the form of the adjoint recurrence (with L instead of L^T)
         return dsw_cheb_basis_adj(rowptr, colind, vals, V, nnz, Y, T, B, Fout, K, dtype, stream, plan,
                                   K >= 4 ? spare : nullptr);
+    }
+    if (K == 3 && X && W && Y && rowptr && B >= 0 && V >= 0) {
+        // K = 3, 32 input channels, fp32: both hops AND the channel mix in one launch (dsw_fwd3.hip)
+        int rcf = DSW_OK;
+        if (dsw_cheb3_fwd_fused_try(plan, V, X, W, bias, Y, T, B, Fin, Fout, K, dtype, (hipStream_t)stream, &rcf)) return rcf;
     }
     if (K > 1) {
         rc = dsw_cheb_basis_fwd(rowptr, colind, vals, V, nnz, X, T, B, Fin, K, dtype, stream, plan);
