@@ -11,7 +11,8 @@ int dsw_spmm_launch(const int* rowptr, const int* colind, const float* vals, int
 // with non-temporal loads so they do not evict the gathered rows from L2 / Infinity Cache
 #define DSW_SPMM_HINT_COLD_Z 2
 int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* bias, void* Y, int64_t N,
-                       int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream);
+                       int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int relu = 0);
+int dsw_relu_inplace_launch(void* y, int64_t n, int dtype, hipStream_t s);
 int dsw_mix_dgrad_launch(const void* dY, const void* W, void* G0, void* Grest, int64_t N, int64_t Fin,
                          int64_t Fout, int64_t K, int dtype, hipStream_t stream);
 int64_t dsw_wgrad_slabs(int64_t N, int64_t Fin, int64_t Fout, int64_t K);
@@ -32,7 +33,7 @@ int dsw_zmix_launch(const void* X, const void* W, const void* bias, void* Z0, vo
                     int64_t Fout, int64_t K, int dtype, hipStream_t stream);
 int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X, const void* W, const void* bias, void* Y,
                             void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
-                            int* rc);
+                            int* rc, int relu);
 int dsw_zdgrad_launch(const void* dY, const void* D, const void* W, void* dX, int64_t N, int64_t Fin, int64_t Fout,
                       int64_t K, int dtype, hipStream_t stream);
 
@@ -179,10 +180,11 @@ int dsw_cheb_mix_fwd(const void* X, const void* T, const void* W, const void* bi
 
 int dsw_cheb_mix_first(int64_t Fin, int64_t Fout, int64_t K) { return mix_first(Fin, Fout, K) ? 1 : 0; }
 
-int dsw_cheb_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V, int64_t nnz,
-                 const void* X, const void* W, const void* bias, void* Y, void* T, int64_t B, int64_t Fin,
-                 int64_t Fout, int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan) {
-    if (K <= 0) return DSW_ERR_BAD_ARG;
+int dsw_cheb_fwd_act(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V, int64_t nnz,
+                     const void* X, const void* W, const void* bias, void* Y, void* T, int64_t B, int64_t Fin,
+                     int64_t Fout, int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan, int act) {
+    if (K <= 0 || (act != DSW_ACT_NONE && act != DSW_ACT_RELU)) return DSW_ERR_BAD_ARG;
+    const int relu = act == DSW_ACT_RELU;
     int rc = DSW_OK;
     if (mix_first(Fin, Fout, K)) {
         // T is scratch here: (K-1) planes of [N, Fin] hold the K-1 (+2 spare for K >= 4) planes of [N, Fout]
@@ -195,19 +197,32 @@ int dsw_cheb_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals
         if (rc != DSW_OK) return rc;
         char* spare = static_cast<char*>(T) + (K - 1) * N * Fout * elem_size(dtype);
         // the Clenshaw recurrence has exactly the form of the adjoint recurrence (with L instead of L^T)
-        return dsw_cheb_basis_adj(rowptr, colind, vals, V, nnz, Y, T, B, Fout, K, dtype, stream, plan,
-                                  K >= 4 ? spare : nullptr);
+        rc = dsw_cheb_basis_adj(rowptr, colind, vals, V, nnz, Y, T, B, Fout, K, dtype, stream, plan,
+                                K >= 4 ? spare : nullptr);
+        // the mix-first order ends in an SpMM: the activation is one in-place pass over the (Fout-channel) output
+        if (rc == DSW_OK && relu) rc = dsw_relu_inplace_launch(Y, N * Fout, dtype, (hipStream_t)stream);
+        return rc;
     }
     if (K == 3 && X && W && Y && rowptr && B >= 0 && V >= 0) {
         // K = 3, 32 input channels, fp32: both hops AND the channel mix in one launch (dsw_fwd3.hip)
         int rcf = DSW_OK;
-        if (dsw_cheb3_fwd_fused_try(plan, V, X, W, bias, Y, T, B, Fin, Fout, K, dtype, (hipStream_t)stream, &rcf)) return rcf;
+        if (dsw_cheb3_fwd_fused_try(plan, V, X, W, bias, Y, T, B, Fin, Fout, K, dtype, (hipStream_t)stream, &rcf, relu)) return rcf;
     }
     if (K > 1) {
         rc = dsw_cheb_basis_fwd(rowptr, colind, vals, V, nnz, X, T, B, Fin, K, dtype, stream, plan);
         if (rc != DSW_OK) return rc;
     }
-    return dsw_cheb_mix_fwd(X, T, W, bias, Y, B * V, Fin, Fout, K, dtype, stream);
+    if (B * V < 0 || Fin <= 0 || Fout <= 0) return DSW_ERR_BAD_ARG;
+    if (B * V == 0) return DSW_OK;
+    if (!X || !W || !Y || (K > 1 && !T)) return DSW_ERR_BAD_ARG;
+    return dsw_mix_fwd_launch(X, T, W, bias, Y, B * V, Fin, Fout, K, dtype, (hipStream_t)stream, relu);
+}
+
+int dsw_cheb_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V, int64_t nnz,
+                 const void* X, const void* W, const void* bias, void* Y, void* T, int64_t B, int64_t Fin,
+                 int64_t Fout, int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan) {
+    return dsw_cheb_fwd_act(rowptr, colind, vals, V, nnz, X, W, bias, Y, T, B, Fin, Fout, K, dtype, stream, plan,
+                            DSW_ACT_NONE);
 }
 
 int64_t dsw_cheb_bwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t Fout, int64_t K, int dtype) {

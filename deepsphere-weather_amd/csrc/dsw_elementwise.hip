@@ -113,6 +113,26 @@ __global__ __launch_bounds__(256) void rezero_bwd_final_kernel(const float* part
     if (threadIdx.x == 0) Ew<BF16>::store1(gw, 0, red[0]);
 }
 
+// y = relu(y) in place (the mix-first layers end in an SpMM, not in a GEMM epilogue);  g_out = y > 0 ? g : 0
+template <bool BF16, bool BWD>
+__global__ __launch_bounds__(EW_THREADS) void relu_kernel(const void* g, const void* y, void* out, long n, int vec) {
+    using E = Ew<BF16>;
+    constexpr int V = E::V;
+    const long nv = vec ? n / V : 0;
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < nv; i += (long)gridDim.x * EW_THREADS) {
+        float a[V], b[V], o[V];
+        E::load(y, (size_t)i * V, b);
+        if constexpr (BWD) E::load(g, (size_t)i * V, a);
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] = BWD ? (b[j] > 0.f ? a[j] : 0.f) : (b[j] < 0.f ? 0.f : b[j]);
+        E::store(out, (size_t)i * V, o);
+    }
+    for (long i = nv * V + (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * EW_THREADS) {
+        const float b = E::load1(y, i);
+        E::store1(out, i, BWD ? (b > 0.f ? E::load1(g, i) : 0.f) : (b < 0.f ? 0.f : b));
+    }
+}
+
 static int ew_blocks(long n, int v) {
     long b = ((n + v - 1) / v + EW_THREADS - 1) / EW_THREADS;
     if (b < 1) b = 1;
@@ -122,7 +142,32 @@ static int ew_blocks(long n, int v) {
 
 }  // namespace
 
+int dsw_relu_inplace_launch(void* y, int64_t n, int dtype, hipStream_t s) {
+    if (n <= 0) return DSW_OK;
+    const int vec = dsw_aligned16(y) ? 1 : 0;
+    if (dtype == DSW_F32)
+        hipLaunchKernelGGL((relu_kernel<false, false>), dim3(ew_blocks(n, vec ? 4 : 1)), dim3(EW_THREADS), 0, s, nullptr, y, y, (long)n, vec);
+    else
+        hipLaunchKernelGGL((relu_kernel<true, false>), dim3(ew_blocks(n, vec ? 8 : 1)), dim3(EW_THREADS), 0, s, nullptr, y, y, (long)n, vec);
+    return dsw_check_launch();
+}
+
 extern "C" {
+
+int dsw_relu_bwd(const void* dY, const void* Y, void* dYm, int64_t n, int dtype, dsw_stream_t stream) {
+    if (n < 0) return DSW_ERR_BAD_ARG;
+    if (n == 0) return DSW_OK;
+    if (!dY || !Y || !dYm) return DSW_ERR_BAD_ARG;
+    if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
+    const int vec = (dsw_aligned16(dY) && dsw_aligned16(Y) && dsw_aligned16(dYm)) ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DSW_F32)
+        hipLaunchKernelGGL((relu_kernel<false, true>), dim3(ew_blocks(n, vec ? 4 : 1)), dim3(EW_THREADS), 0, s, dY, Y, dYm, (long)n, vec);
+    else
+        hipLaunchKernelGGL((relu_kernel<true, true>), dim3(ew_blocks(n, vec ? 8 : 1)), dim3(EW_THREADS), 0, s, dY, Y, dYm, (long)n, vec);
+    return dsw_check_launch();
+}
+
 
 int64_t dsw_rezero_residual_workspace_bytes(void) { return (int64_t)EW_MAX_BLOCKS * 4; }
 

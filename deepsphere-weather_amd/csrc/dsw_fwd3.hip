@@ -57,6 +57,7 @@ struct Fwd3Args {
     int V, n_tiles, max_n1, max_n2;
     int B, n_chunks, spc, ell_w;
     int Fout;
+    int relu;            // ReLU after the bias (ConvBlock)
 };
 
 // byte offset of 16-byte chunk position (c ^ swizzle(row)) given c * 16 = cb: cb ^ swz(row)
@@ -264,6 +265,10 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
 #pragma unroll
         for (int r = 0; r < RBW; ++r) {   // lane: row 16 (rb0 + r) + l15, output channels 16 cbk + 4 kc .. + 3
             const int row = 16 * (rb0 + r) + l15;
+            if (P.relu) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[r][t] = acc[r][t] < 0.f ? 0.f : acc[r][t];   // NaN stays NaN (torch.relu)
+            }
             if (row < rt)
                 *reinterpret_cast<f32x4_t*>(P.Y + ((size_t)b * P.V + (size_t)(r0 + row)) * (size_t)P.Fout * 4 +
                                             (size_t)(16 * cbk + 4 * kc) * 4) = acc[r];
@@ -304,10 +309,10 @@ int launch_ncb(const Fwd3Args& A, long nwg, size_t lds, hipStream_t stream) {
 // 0 if the caller must use the generic sequence (basis launches + channel-mix GEMM).
 int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X, const void* W, const void* bias, void* Y,
                             void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
-                            int* rc) {
+                            int* rc, int relu) {
     static const char* env = getenv("DSW_FWD_FUSED");   // "0": generic sequence (diagnostics / A-B)
     if (env && env[0] == '0') return 0;
-    if (dtype != DSW_F32 || K != 3 || Fin != 32 || (Fout != 32 && Fout != 64 && Fout != 128)) return 0;
+    if (dtype != DSW_F32 || K != 3 || Fin != 32 || (Fout != 32 && Fout != 64)) return 0;   // (Fout = 128 compiles but spills)
     if (!plan || plan->tile_rows != 64 || !dsw_spmm2_supported(plan, Fin, dtype)) return 0;
     if (plan->max_n2 < 128) return 0;                       // T2 is parked in rows 64..127 of the input buffer
     if (!dsw_aligned16(X) || !dsw_aligned16(Y) || !dsw_aligned16(W) || (bias && !dsw_aligned16(bias)) ||
@@ -328,7 +333,7 @@ int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X,
     A.Y = static_cast<char*>(Y);
     A.W = static_cast<const float*>(W); A.bias = static_cast<const float*>(bias);
     A.V = (int)V; A.n_tiles = plan->n_tiles; A.max_n1 = plan->max_n1; A.max_n2 = plan->max_n2;
-    A.B = (int)B; A.ell_w = (plan->reserved + 3) & ~3; A.Fout = (int)Fout;
+    A.B = (int)B; A.ell_w = (plan->reserved + 3) & ~3; A.Fout = (int)Fout; A.relu = relu;
     // batch chunks: same cost model as the two-hop kernel (rounds x (staging + samples per chunk))
     const long slots = 256L * ((160 * 1024) / (long)lds > 0 ? (160 * 1024) / (long)lds : 1);
     long chunks = 1;

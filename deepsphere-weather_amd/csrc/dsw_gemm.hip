@@ -227,13 +227,13 @@ __global__ __launch_bounds__(256) void ts_gemm_kernel(const TsGemmParams P) {
                     if (jok) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i)
-                            st1<BF16>(C, (size_t)(rbase + (i & 3) + 8 * (i >> 2)) * P.ldc, acc[nt][i] + bias);
+                            st1<BF16>(C, (size_t)(rbase + (i & 3) + 8 * (i >> 2)) * P.ldc, epi_act(acc[nt][i] + bias, P.relu));
                     }
                 } else {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const long r = rbase + (i & 3) + 8 * (i >> 2);
-                        if (jok && r < P.M) st1<BF16>(C, (size_t)r * P.ldc, acc[nt][i] + bias);
+                        if (jok && r < P.M) st1<BF16>(C, (size_t)r * P.ldc, epi_act(acc[nt][i] + bias, P.relu));
                     }
                 }
 #pragma unroll
@@ -521,7 +521,7 @@ static int launch_ts_gemm(const TsGemmParams& P, hipStream_t stream) {
 }
 
 int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* bias, void* Y, int64_t N,
-                       int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream) {
+                       int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int relu) {
     if (N == 0) return DSW_OK;
     if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
     const int es = dtype == DSW_BF16 ? 2 : 4;
@@ -530,7 +530,7 @@ int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* 
     P.n_planes_a = (int)K; P.kd_per_plane = (int)Fin;
     P.Bsrc = W; P.b_sp = Fout; P.b_sq = 0; P.b_skd = K * Fout; P.b_sn = 1;
     P.C0 = Y; P.C1 = Y; P.c_plane_stride = 0; P.ldc = (int)Fout; P.n_planes_c = 1; P.n_per_plane = (int)Fout;
-    P.bias = bias; P.M = N;
+    P.bias = bias; P.M = N; P.relu = relu;
 #ifdef DSW_ABLATION   // build with -DDSW_ABLATION to enable the DSW_DBG ablation knobs (they produce wrong results by design)
     { static const char* d = getenv("DSW_DBG"); P.dbg = d ? atoi(d) : 0; }
 #endif

@@ -64,7 +64,11 @@ struct TsGemmParams {
     long M;
     int a_vec;              // 1 if float4/bf16x4 loads of A are legal
     int dbg;                // ablation builds only (-DDSW_ABLATION + DSW_DBG env): 1 = skip the epilogue stores, 2 = skip the MFMAs; else 0
+    int relu;               // 1: ReLU in the epilogue (ConvBlock: conv -> relu, my_models_graph.py:108-114), after the bias
 };
+
+// epilogue activation; NaN stays NaN like torch.relu (fmaxf would turn it into 0)
+static __device__ __forceinline__ float epi_act(const float v, const int relu) { return (relu && v < 0.f) ? 0.f : v; }
 
 
 // Position of a persistent workgroup in its (row tile, A plane, chunk) sequence, advanced incrementally: the

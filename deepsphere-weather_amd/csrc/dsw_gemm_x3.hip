@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3_kernel(const TsGemmParams
                     for (int i = 0; i < 16; ++i) {
                         typedef float f32x2 __attribute__((ext_vector_type(2)));
                         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-                        const f32x2 v = {acc[2 * h][i] + col_bias[2 * h], acc[2 * h + 1][i] + col_bias[2 * h + 1]};
+                        const f32x2 v = {epi_act(acc[2 * h][i] + col_bias[2 * h], P.relu), epi_act(acc[2 * h + 1][i] + col_bias[2 * h + 1], P.relu)};
                         const int rl = 4 * half + (i & 3) + 8 * (i >> 2);
                         *reinterpret_cast<uint32_t*>(wrows + rl * (LDA * 4) + 4 * l31) =
                             __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
@@ -264,13 +264,13 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3_kernel(const TsGemmParams
                     if (col_ok[nt]) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i)
-                            st1<BF16IO>(C, (size_t)(rbase + (i & 3) + 8 * (i >> 2)) * P.ldc, acc[nt][i] + bias);
+                            st1<BF16IO>(C, (size_t)(rbase + (i & 3) + 8 * (i >> 2)) * P.ldc, epi_act(acc[nt][i] + bias, P.relu));
                     }
                 } else {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const long r = rbase + (i & 3) + 8 * (i >> 2);
-                        if (col_ok[nt] && r < P.M) st1<BF16IO>(C, (size_t)r * P.ldc, acc[nt][i] + bias);
+                        if (col_ok[nt] && r < P.M) st1<BF16IO>(C, (size_t)r * P.ldc, epi_act(acc[nt][i] + bias, P.relu));
                     }
                 }
 #pragma unroll

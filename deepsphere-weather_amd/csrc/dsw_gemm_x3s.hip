@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const long r = rbase + (i & 3) + 8 * (i >> 2);
-                    if (col_ok[nt] && r < P.M) C[(size_t)r * P.ldc] = acc[nt][i] + bias;
+                    if (col_ok[nt] && r < P.M) C[(size_t)r * P.ldc] = epi_act(acc[nt][i] + bias, P.relu);
                     acc[nt][i] = 0.f;
                 }
             }

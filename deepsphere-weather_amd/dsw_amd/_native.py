@@ -53,6 +53,11 @@ SIGNATURES = {
         _int,
         [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp],
     ),
+    "dsw_cheb_fwd_act": (
+        _int,
+        [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int],
+    ),
+    "dsw_relu_bwd": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
     "dsw_cheb_bwd_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64, _i64, _int]),
     "dsw_cheb_bwd": (
         _int,

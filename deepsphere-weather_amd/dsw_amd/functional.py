@@ -251,7 +251,7 @@ class _HipBackend:
             _native.check(rc, "dsw_cheb_basis_fwd")
         return T
 
-    def cheb_fwd(self, op, x, w, bias):
+    def cheb_fwd(self, op, x, w, bias, relu=False):
         lib = _native.load()
         B, V, Fin = x.shape
         _, K, Fout = w.shape
@@ -265,12 +265,12 @@ class _HipBackend:
         csr = (None, None, None, V, 0) if op is None else (
             op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz)
         with torch.cuda.device(x.device):
-            rc = lib.dsw_cheb_fwd(
+            rc = lib.dsw_cheb_fwd_act(
                 *csr,
                 x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(T), B, Fin, Fout, K,
-                _DTYPES[x.dtype], _stream(x), pp,
+                _DTYPES[x.dtype], _stream(x), pp, 1 if relu else 0,
             )
-        _native.check(rc, "dsw_cheb_fwd")
+        _native.check(rc, "dsw_cheb_fwd_act")
         return y, (None if mix_first else T)
 
     def cheb_bwd(self, op, x, T, w, dy, need_dx, need_dw, need_db):
@@ -301,6 +301,14 @@ class _HipBackend:
         _native.check(rc, "dsw_cheb_bwd")
         return dx, (dw if need_dw else None), (db if need_db else None)
 
+
+    def relu_bwd(self, dy, y):
+        lib = _native.load()
+        out = torch.empty_like(dy)
+        with torch.cuda.device(dy.device):
+            rc = lib.dsw_relu_bwd(dy.data_ptr(), y.data_ptr(), out.data_ptr(), dy.numel(), _DTYPES[dy.dtype], _stream(dy))
+        _native.check(rc, "dsw_relu_bwd")
+        return out
 
     def rezero_fwd(self, c, r, w):
         lib = _native.load()
@@ -410,28 +418,34 @@ def _check_dtype(*tensors):
 # ----------------------------------------------------------------------------------------------
 class _ChebConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, op):
+    def forward(ctx, x, weight, bias, op, relu=False):
         be = _backend_for(x)
         xc = x.contiguous()
         wc = weight.contiguous()
         bc = None if bias is None else bias.contiguous()
-        y, T = be.cheb_fwd(op, xc, wc, bc)
-        # the output is NOT saved: callers modify it in place (layers.py:375, my_models_graph.py:213)
-        ctx.save_for_backward(xc, wc, T)
+        y, T = be.cheb_fwd(op, xc, wc, bc, relu) if relu else be.cheb_fwd(op, xc, wc, bc)
+        # the plain output is NOT saved: callers modify it in place (layers.py:375, my_models_graph.py:213).  With the
+        # fused activation the output IS the ReLU result, whose sign pattern backward needs (as F.relu saves its result);
+        # an in-place edit by the caller then trips autograd's version check instead of corrupting gradients.
+        ctx.save_for_backward(xc, wc, T, y if relu else None)
         ctx.op = op
         ctx.has_bias = bias is not None
         ctx.be = be
+        ctx.relu = relu
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
-        xc, wc, T = ctx.saved_tensors
+        xc, wc, T, y = ctx.saved_tensors
         need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], (
             ctx.has_bias and ctx.needs_input_grad[2]
         )
-        dx, dw, db = ctx.be.cheb_bwd(ctx.op, xc, T, wc, dy.contiguous(), need_dx, need_dw, need_db)
-        return dx, dw, db, None
+        dy = dy.contiguous()
+        if ctx.relu:
+            dy = ctx.be.relu_bwd(dy, y)
+        dx, dw, db = ctx.be.cheb_bwd(ctx.op, xc, T, wc, dy, need_dx, need_dw, need_db)
+        return dx, dw, db, None, None
 
 
 class _RezeroResidualFn(torch.autograd.Function):
@@ -531,8 +545,11 @@ def maxval_compact_index(index: torch.Tensor, B: int, D: int, F: int) -> torch.T
     return index[0].reshape(F, B, D).permute(1, 2, 0).to(torch.int32).contiguous()
 
 
-def cheb_conv(op: CsrOperator, x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
-    """``Y = sum_k T_k(L) x W_k (+ bias)`` for node-major ``x [B, V, Fin]``, ``weight [Fin, K, Fout]``."""
+def cheb_conv(op: CsrOperator, x: torch.Tensor, weight: torch.Tensor, bias=None, activation=None) -> torch.Tensor:
+    """``Y = act(sum_k T_k(L) x W_k (+ bias))`` for node-major ``x [B, V, Fin]``, ``weight [Fin, K, Fout]``;
+    ``activation``: None or "relu" (fused into the epilogue of the channel-mix GEMM)."""
+    if activation not in (None, "relu"):
+        raise ValueError("fused activation: None or 'relu'")
     if x.dim() != 3 or weight.dim() != 3:
         raise ValueError("expected inputs [B, V, Fin] and weight [Fin, K, Fout]")
     if x.shape[1] != op.shape[1] or op.shape[0] != op.shape[1]:
@@ -540,7 +557,7 @@ def cheb_conv(op: CsrOperator, x: torch.Tensor, weight: torch.Tensor, bias=None)
             f"operator shape {op.shape} does not match the {x.shape[1]} nodes of the input"
         )
     _check_dtype(x, weight, bias)
-    return _ChebConvFn.apply(x, weight, bias, op)
+    return _ChebConvFn.apply(x, weight, bias, op, activation == "relu")
 
 
 def dense_mix(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:

@@ -202,6 +202,14 @@ class ConvCheb(_Fp32OperatorMixin, torch.nn.Module):
             self.in_channels, self.out_channels, self.kernel_size, self.bias is not None
         )
 
+    def forward_activated(self, inputs, activation="relu"):
+        """``activation(forward(inputs))`` with the activation applied in the epilogue of the channel-mix kernel
+        (one pass less over the output than ``F.relu(conv(x))``, my_models_graph.py:108-114).  Only for the built-in
+        ``conv_cheb``; a custom ``conv=`` callable gets the plain two-step evaluation."""
+        if self._conv is conv_cheb and activation == "relu" and inputs.shape[2] == self.weight.shape[0]:
+            return _F.cheb_conv(_F.get_operator(self.laplacian), inputs, self.weight, self.bias, activation="relu")
+        return getattr(torch.nn.functional, activation)(self.forward(inputs))
+
     def forward(self, inputs):
         """``inputs``: n_signals x n_vertices x n_features."""
         # weight / bias / laplacian are read by attribute on every call (SWAG re-assigns them)

@@ -71,11 +71,15 @@ class ConvBlock(GeneralConvBlock):
         return self.bn(x.transpose(1, 2)).transpose(1, 2)  # BatchNorm1d wants (sample, channel, node)
 
     def forward(self, x):
-        x = self.conv(x)
-        if self.norm and self.bn_before_act:
-            x = self._normalise(x)
-        if self.act:
-            x = self.act_fun(x)
+        if self.act and self.act_fun is F.relu and not (self.norm and self.bn_before_act) \
+                and hasattr(self.conv, "forward_activated"):
+            x = self.conv.forward_activated(x, "relu")      # conv + bias + relu in one epilogue
+        else:
+            x = self.conv(x)
+            if self.norm and self.bn_before_act:
+                x = self._normalise(x)
+            if self.act:
+                x = self.act_fun(x)
         if self.norm and not self.bn_before_act:
             x = self._normalise(x)
         return x

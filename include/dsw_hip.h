@@ -131,6 +131,21 @@ int dsw_cheb_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals
                  void* Y, void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K,
                  int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan);
 
+/* ConvCheb.forward followed by the activation of the enclosing ConvBlock (my_models_graph.py:104-118: conv -> relu
+ * when batch norm does not sit in between): act = DSW_ACT_RELU applies max(., 0) in the epilogue of the channel-mix
+ * GEMM (after the bias; one in-place pass for mix-first layers, whose last stage is an SpMM) instead of a separate
+ * read + write of Y.  act = DSW_ACT_NONE is dsw_cheb_fwd. */
+#define DSW_ACT_NONE 0
+#define DSW_ACT_RELU 1
+int dsw_cheb_fwd_act(const int32_t* rowptr, const int32_t* colind, const float* vals,
+                     int64_t V, int64_t nnz, const void* X, const void* W, const void* bias,
+                     void* Y, void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K,
+                     int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan, int act);
+
+/* Backward of that activation (autograd of F.relu, what the reference's ConvBlock records):
+ *     dYm[i] = Y[i] > 0 ? dY[i] : 0          (Y = the layer's activated output; n elements; dYm may alias dY) */
+int dsw_relu_bwd(const void* dY, const void* Y, void* dYm, int64_t n, int dtype, dsw_stream_t stream);
+
 /* Scratch bytes dsw_cheb_bwd needs for this problem size. */
 int64_t dsw_cheb_bwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t Fout, int64_t K,
                                      int dtype);

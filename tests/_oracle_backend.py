@@ -31,12 +31,17 @@ class OracleBackend:
             return torch.empty((0,) + tuple(x.shape), dtype=x.dtype)
         return torch.from_numpy(np.stack(T[1:])).to(x.dtype)
 
-    def cheb_fwd(self, op, x, w, bias):
+    def relu_bwd(self, dy, y):
+        return torch.where(y > 0, dy, torch.zeros_like(dy))
+
+    def cheb_fwd(self, op, x, w, bias, relu=False):
         rp, ci, va = _csr_np(op, x.shape[1])
         y = orc.cheb_forward_f64(
             rp, ci, va, x.detach().float().numpy(), w.detach().float().numpy(),
             None if bias is None else bias.detach().float().numpy(),
         )
+        if relu:
+            y = np.maximum(y, 0.0)
         K = w.shape[1]
         T = self.cheb_basis(op, x, K) if K > 1 else None
         return torch.from_numpy(y).to(x.dtype), T

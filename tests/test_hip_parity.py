@@ -709,3 +709,45 @@ def test_ar_training_steps_golden_g9(use_graph):
         assert trainer.graph is not None and trainer.launch.startswith("hip graph"), trainer.launch
     losses = check_g9(trainer, g, names)
     print("G9 losses", losses, "reference", g["losses"])
+
+
+@pytest.mark.parametrize("V,B,Fin,Fout,K,dt", [
+    (768, 3, 32, 64, 3, torch.float32),     # whole-forward kernel (dsw_fwd3.hip)
+    (768, 2, 64, 128, 3, torch.float32),    # x3 GEMM epilogue
+    (192, 2, 512, 256, 3, torch.float32),   # mix-first: in-place pass after the Clenshaw recurrence
+    (192, 2, 256, 384, 2, torch.float32),   # streaming-W x3s GEMM epilogue
+    (192, 3, 18, 7, 3, torch.float32),      # exact-fp32 GEMM (unaligned shapes)
+    (768, 2, 64, 128, 3, torch.bfloat16),   # bf16 packed epilogue
+    (192, 2, 24, 40, 2, torch.bfloat16),
+])
+def test_convblock_fused_bias_relu_vs_oracle(V, B, Fin, Fout, K, dt):
+    """ConvBlock = conv + bias + ReLU (my_models_graph.py:104-118) with the activation in the kernel epilogue: forward,
+    and the backward through the ReLU mask (dX, dW, db), against the fp64 oracle of the same composition."""
+    import modules.my_models_graph as arch
+
+    (rp, ci, va), x, w, b, gy = _rand_case(V, B, Fin, Fout, K, seed=4000 + Fin + Fout, bias=True)
+    q = lambda a: torch.from_numpy(a).to(dt)
+    xq, wq, bq, gyq = q(x), q(w), q(b), q(gy)
+    lap = orc.coo_from_csr_arrays(rp, ci, va, (V, V))
+    blk = arch.ConvBlock(Fin, Fout, laplacian=lap, kernel_size=K, conv_type="graph", bias=True, activation=True,
+                         activation_fun="relu")
+    blk.conv.set_parameters(wq.float(), bq.float())
+    blk = blk.to(DEV).to(dt)
+    xd = xq.to(DEV).requires_grad_(True)
+    y = blk(xd)
+    assert (y >= 0).all()
+    y.backward(gyq.to(DEV))
+    f = lambda t: t.float().numpy()
+    z64 = orc.cheb_forward_f64(rp, ci, va, f(xq), f(wq), f(bq))
+    y64 = np.maximum(z64, 0.0)
+    # the mask is taken from the DEVICE output (an element within rounding of 0 may legitimately land on either side)
+    mask = (y.float().cpu().numpy() > 0)
+    dx64, dw64, db64 = orc.cheb_backward_f64(rp, ci, va, f(xq), f(wq), f(gyq) * mask, True)
+    tol = TOL_BF16 if dt == torch.bfloat16 else TOL_F64
+    assert orc.max_rel_err(y.float(), y64) <= tol
+    assert orc.max_rel_err(xd.grad.float(), dx64) <= tol
+    assert orc.max_rel_err(blk.conv.weight.grad.float(), dw64) <= 2 * tol
+    assert orc.max_rel_err(blk.conv.bias.grad.float(), db64) <= 2 * tol
+    # and the mask itself: only elements whose pre-activation is within rounding of zero may differ
+    flips = (mask != (z64 > 0))
+    assert np.abs(z64[flips]).max(initial=0.0) <= tol * np.abs(z64).max()
