@@ -741,7 +741,7 @@ def test_convblock_fused_bias_relu_vs_oracle(V, B, Fin, Fout, K, dt):
     z64 = orc.cheb_forward_f64(rp, ci, va, f(xq), f(wq), f(bq))
     y64 = np.maximum(z64, 0.0)
     # the mask is taken from the DEVICE output (an element within rounding of 0 may legitimately land on either side)
-    mask = (y.float().cpu().numpy() > 0)
+    mask = (y.detach().float().cpu().numpy() > 0)
     dx64, dw64, db64 = orc.cheb_backward_f64(rp, ci, va, f(xq), f(wq), f(gyq) * mask, True)
     tol = TOL_BF16 if dt == torch.bfloat16 else TOL_F64
     assert orc.max_rel_err(y.float(), y64) <= tol
