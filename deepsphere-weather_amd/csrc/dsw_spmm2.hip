@@ -90,73 +90,70 @@ struct Hop2Args {
 };
 
 
-// acc += sum_j val[j] * buf[off[j]] over the first W entries {byte offset, value} of one ELL row (W even, padded
-// with {own row, 0}); bufc = staging buffer + this lane's byte offset inside a row.
-// The chain entry -> address -> data -> fma is a sequence of dependent LDS round trips, so entries are
-// read two per ds_read_b128 and 8 (then 4) data rows are requested back to back: two LDS latencies per
-// batch instead of two per non-zero.
-template <bool BF16>
-static __device__ __forceinline__ void gather_ell(const uint2* __restrict__ row_ent, const int W,
+// acc += sum_j val[j] * buf[idx[j]] over the first W entries of one ELL row (W even, padded with {own row, 0}); the row
+// INDICES (position in the staged list, u16) and the VALUES (fp32) are two separate arrays: 6 bytes per entry instead
+// of 8 - what lets the k = 20 stencil (23 entries on 155 rows) keep two workgroups on a CU.  bufc = staging buffer +
+// this lane's byte offset inside a row.  The chain index -> address -> data -> fma is a sequence of dependent LDS
+// round trips, so 8 (then 4, then 2) entries are fetched per batch and their data rows requested back to back.
+// BYTEOFF: the u16 entries are BYTE offsets of the rows (list position x row bytes < 64 KiB: the add folds the 16-bit
+// select, v_add_u32_sdwa); otherwise they are list positions and the address costs a multiply-add.
+template <bool BF16, bool BYTEOFF>
+static __device__ __forceinline__ void gather_ell(const unsigned short* __restrict__ row_idx, const float* __restrict__ row_val,
+                                                  const int W, const unsigned row_bytes,
                                                   const unsigned char* __restrict__ bufc,
                                                   typename Row16<BF16>::V (&acc)[Row16<BF16>::N]) {
     using R = Row16<BF16>;
     using VT = typename R::V;
     constexpr int N = R::N;
-    const uint4* e4 = reinterpret_cast<const uint4*>(row_ent);   // {col0, val0, col1, val1}
     int j = 0;
     for (; j + 8 <= W; j += 8) {
-        uint4 e[4];
+        const uint2 i0 = *reinterpret_cast<const uint2*>(row_idx + j), i1 = *reinterpret_cast<const uint2*>(row_idx + j + 4);
+        const float4 v0 = *reinterpret_cast<const float4*>(row_val + j), v1 = *reinterpret_cast<const float4*>(row_val + j + 4);
+        const unsigned ix[8] = {i0.x & 0xffffu, i0.x >> 16, i0.y & 0xffffu, i0.y >> 16,
+                                i1.x & 0xffffu, i1.x >> 16, i1.y & 0xffffu, i1.y >> 16};
+        const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         uint4 d[8];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) e[t] = e4[(j >> 1) + t];
+        for (int t = 0; t < 8; ++t) d[t] = *reinterpret_cast<const uint4*>(bufc + (BYTEOFF ? ix[t] : ix[t] * row_bytes));
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            d[2 * t] = *reinterpret_cast<const uint4*>(bufc + e[t].x);
-            d[2 * t + 1] = *reinterpret_cast<const uint4*>(bufc + e[t].z);
-        }
+        for (int t = 0; t < 8; ++t) {
+            VT x[N];
+            R::unpack(d[t], x);
+            const VT v = R::splat(vv[t]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            VT x0[N], x1[N];
-            R::unpack(d[2 * t], x0);
-            R::unpack(d[2 * t + 1], x1);
-            const VT v0 = R::splat(__uint_as_float(e[t].y)), v1 = R::splat(__uint_as_float(e[t].w));
-#pragma unroll
-            for (int c = 0; c < N; ++c) {
-                acc[c] = fmav(v0, x0[c], acc[c]);
-                acc[c] = fmav(v1, x1[c], acc[c]);
-            }
+            for (int c = 0; c < N; ++c) acc[c] = fmav(v, x[c], acc[c]);
         }
     }
     if (j + 4 <= W) {
-        const uint4 ea = e4[j >> 1], eb = e4[(j >> 1) + 1];
-        const uint4 d0 = *reinterpret_cast<const uint4*>(bufc + ea.x);
-        const uint4 d1 = *reinterpret_cast<const uint4*>(bufc + ea.z);
-        const uint4 d2 = *reinterpret_cast<const uint4*>(bufc + eb.x);
-        const uint4 d3 = *reinterpret_cast<const uint4*>(bufc + eb.z);
-        VT x0[N], x1[N], x2[N], x3[N];
-        R::unpack(d0, x0); R::unpack(d1, x1); R::unpack(d2, x2); R::unpack(d3, x3);
-        const VT v0 = R::splat(__uint_as_float(ea.y)), v1 = R::splat(__uint_as_float(ea.w));
-        const VT v2 = R::splat(__uint_as_float(eb.y)), v3 = R::splat(__uint_as_float(eb.w));
+        const uint2 i0 = *reinterpret_cast<const uint2*>(row_idx + j);
+        const float4 v0 = *reinterpret_cast<const float4*>(row_val + j);
+        const unsigned ix[4] = {i0.x & 0xffffu, i0.x >> 16, i0.y & 0xffffu, i0.y >> 16};
+        const float vv[4] = {v0.x, v0.y, v0.z, v0.w};
+        uint4 d[4];
 #pragma unroll
-        for (int c = 0; c < N; ++c) {
-            acc[c] = fmav(v0, x0[c], acc[c]);
-            acc[c] = fmav(v1, x1[c], acc[c]);
-            acc[c] = fmav(v2, x2[c], acc[c]);
-            acc[c] = fmav(v3, x3[c], acc[c]);
+        for (int t = 0; t < 4; ++t) d[t] = *reinterpret_cast<const uint4*>(bufc + (BYTEOFF ? ix[t] : ix[t] * row_bytes));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            VT x[N];
+            R::unpack(d[t], x);
+            const VT v = R::splat(vv[t]);
+#pragma unroll
+            for (int c = 0; c < N; ++c) acc[c] = fmav(v, x[c], acc[c]);
         }
         j += 4;
     }
     if (j < W) {   // W is even: one last pair
-        const uint4 ea = e4[j >> 1];
-        const uint4 d0 = *reinterpret_cast<const uint4*>(bufc + ea.x);
-        const uint4 d1 = *reinterpret_cast<const uint4*>(bufc + ea.z);
+        const unsigned i0 = *reinterpret_cast<const unsigned*>(row_idx + j);
+        const float2 v0 = *reinterpret_cast<const float2*>(row_val + j);
+        const uint4 d0 = *reinterpret_cast<const uint4*>(bufc + (BYTEOFF ? (i0 & 0xffffu) : (i0 & 0xffffu) * row_bytes));
+        const uint4 d1 = *reinterpret_cast<const uint4*>(bufc + (BYTEOFF ? (i0 >> 16) : (i0 >> 16) * row_bytes));
         VT x0[N], x1[N];
         R::unpack(d0, x0); R::unpack(d1, x1);
-        const VT v0 = R::splat(__uint_as_float(ea.y)), v1 = R::splat(__uint_as_float(ea.w));
+        const VT va = R::splat(v0.x), vb = R::splat(v0.y);
 #pragma unroll
         for (int c = 0; c < N; ++c) {
-            acc[c] = fmav(v0, x0[c], acc[c]);
-            acc[c] = fmav(v1, x1[c], acc[c]);
+            acc[c] = fmav(va, x0[c], acc[c]);
+            acc[c] = fmav(vb, x1[c], acc[c]);
         }
     }
 }
@@ -172,7 +169,7 @@ constexpr int MAXST = 8;
 // barrier; vmcnt completes in order, so waiting for Z* (first use: end of the first phase-1 task) leaves
 // the U burst in flight under phases 1 and 2, and it lands in the other half of the double-buffered bufX
 // at the top of the next iteration.
-template <bool BF16, int NST, bool HZA, bool HZ2, int NS1 = NST, int NS2 = NST>
+template <bool BF16, int NST, bool HZA, bool HZ2, int NS1 = NST, int NS2 = NST, bool BYTEOFF = false>
 __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fused_kernel(const Hop2Args P) {
     using R = Row16<BF16>;
     using VT = typename R::V;
@@ -183,8 +180,9 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
     // sample s+1 (aliases bufX0 when single-buffered: the loop then ends with a barrier so that nobody still reads it)
     unsigned char* bufX1 = P.single_buf ? bufX0 : bufX0 + (size_t)P.max_n2 * P.row_bytes;
     unsigned char* bufT = bufX1 + (size_t)P.max_n2 * P.row_bytes;          // [max_n1][row_bytes]
-    uint2* ell = reinterpret_cast<uint2*>(bufT + (size_t)P.max_n1 * P.row_bytes);   // [max_n1][W] {col, val}
-    int* rows = reinterpret_cast<int*>(ell + (size_t)P.max_n1 * P.ell_w);  // [max_n2] global row ids
+    float* ell_val = reinterpret_cast<float*>(bufT + (size_t)P.max_n1 * P.row_bytes);           // [max_n1][W] values
+    unsigned short* ell_idx = reinterpret_cast<unsigned short*>(ell_val + (size_t)P.max_n1 * P.ell_w);   // [max_n1][W] list positions
+    int* rows = reinterpret_cast<int*>(ell_idx + (size_t)P.max_n1 * P.ell_w);                    // [max_n2] global row ids
     int* tile_w = rows + ((P.max_n2 + 3) & ~3);                            // longest local row of THIS tile
 
     // XCD-aware order: each XCD (hardware block id % 8) walks one contiguous range of (tile, batch chunk)
@@ -250,8 +248,10 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
             val = P.lval[nnz_off + p];
         }
         if (j == 0 && p1 - p0 > 2) atomicMax(tile_w, p1 - p0);
-        ell[t] = (p0 + j < p1) ? make_uint2(col * (unsigned)P.row_bytes, __float_as_uint(val))
-                               : make_uint2((unsigned)i * (unsigned)P.row_bytes, 0u);
+        const bool live = p0 + j < p1;
+        const unsigned pos = live ? col : (unsigned)i;
+        ell_idx[t] = (unsigned short)(BYTEOFF ? pos * (unsigned)P.row_bytes : pos);
+        ell_val[t] = live ? val : 0.f;
     }
     __syncthreads();   // ELL complete (and lrp in bufT dead) before the first phase 1
     const int Wt = (*tile_w + 1) & ~1;              // gather loop length of this tile (<= W, even)
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
                 VT acc[N];
 #pragma unroll
                 for (int j = 0; j < N; ++j) acc[j] = R::splat(0.f);
-                gather_ell<BF16>(ell + (size_t)i * W, Wt, bufX + cb, acc);
+                gather_ell<BF16, BYTEOFF>(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, (unsigned)P.row_bytes, bufX + cb, acc);
                 VT o[N];
 #pragma unroll
                 for (int j = 0; j < N; ++j) o[j] = R::splat(P.a1) * acc[j];
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
                 VT acc[N];
 #pragma unroll
                 for (int j = 0; j < N; ++j) acc[j] = R::splat(0.f);
-                gather_ell<BF16>(ell + (size_t)i * W, Wt, bufT + cb, acc);
+                gather_ell<BF16, BYTEOFF>(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, (unsigned)P.row_bytes, bufT + cb, acc);
                 VT u[N], o[N];
                 R::unpack(*reinterpret_cast<const uint4*>(bufX + (size_t)i * P.row_bytes + cb), u);
 #pragma unroll
@@ -354,7 +354,7 @@ static int hop2_ell_w(const dsw_hop2_plan* plan) { return (plan->reserved + 3) &
 
 static size_t hop2_lds_bytes(const dsw_hop2_plan* plan, int row_bytes, bool single_buf = false) {
     size_t s = (size_t)(plan->max_n1 + (single_buf ? 1 : 2) * (size_t)plan->max_n2) * row_bytes;   // bufT + bufX (x2)
-    s += (size_t)plan->max_n1 * hop2_ell_w(plan) * 8;
+    s += (size_t)plan->max_n1 * hop2_ell_w(plan) * 6;  // ELL: fp32 values + u16 list positions
     s += (size_t)((plan->max_n2 + 3) & ~3) * 4 + 16;   // row ids + the tile's loop length
     return (s + 15) & ~(size_t)15;
 }
@@ -371,16 +371,16 @@ int dsw_spmm2_supported(const dsw_hop2_plan* plan, int64_t C, int dtype) {
 }
 
 namespace {
-template <bool BF16, int NST, int NS1, int NS2>
+template <bool BF16, int NST, int NS1, int NS2, bool BYTEOFF = false>
 int launch_h2(const Hop2Args& A, long nwg, size_t lds, hipStream_t stream) {
     const int sel = ((A.Z1 || A.Z1b) ? 1 : 0) | (A.Z2 ? 2 : 0);
 #define DSW_H2_SEL(S, ZA_, Z2_)                                                                                  \
     case S: {                                                                                                    \
         if (lds > 64 * 1024 &&                                                                                   \
-            hipFuncSetAttribute((const void*)spmm2_fused_kernel<BF16, NST, ZA_, Z2_, NS1, NS2>,                  \
+            hipFuncSetAttribute((const void*)spmm2_fused_kernel<BF16, NST, ZA_, Z2_, NS1, NS2, BYTEOFF>,                  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
             return DSW_ERR_LAUNCH;                                                                               \
-        hipLaunchKernelGGL((spmm2_fused_kernel<BF16, NST, ZA_, Z2_, NS1, NS2>), dim3((unsigned)nwg),             \
+        hipLaunchKernelGGL((spmm2_fused_kernel<BF16, NST, ZA_, Z2_, NS1, NS2, BYTEOFF>), dim3((unsigned)nwg),             \
                            dim3(NTHREADS), lds, stream, A);                                                      \
         break;                                                                                                   \
     }
@@ -418,14 +418,19 @@ int dsw_spmm2_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const 
     // staging buffers: double-buffered input rows unless that costs the second resident workgroup (<= 80 KiB each) or
     // does not fit at all - the k = 20 stencil's 2-ring is 4x the tile, and 8 waves per CU cannot hide the LDS latency
     const size_t lds2 = hop2_lds_bytes(plan, A.row_bytes, false), lds1 = hop2_lds_bytes(plan, A.row_bytes, true);
-    A.single_buf = (lds2 <= 80 * 1024) ? 0 : (lds1 <= 80 * 1024) ? 1 : (lds2 <= 160 * 1024) ? 0 : 1;
+    const int rpp_ = NTHREADS / A.lpr;
+    const bool two_wg_regs = !((A.Z1 || A.Z1b) && (plan->max_n1 + rpp_ - 1) / rpp_ > 2);   // see __launch_bounds__
+    A.single_buf = (lds2 <= 80 * 1024) ? 0 : (lds1 <= 80 * 1024 && two_wg_regs) ? 1 : (lds2 <= 160 * 1024) ? 0 : 1;
     { static const char* sb = getenv("DSW_H2_SINGLE"); if (sb) A.single_buf = (sb[0] == '1') && lds1 <= 160 * 1024 ? 1 : (lds2 <= 160 * 1024 ? 0 : 1); }   // diagnostics
     const size_t lds = A.single_buf ? lds1 : lds2;
     // batch chunks.  A workgroup = (tile, chunk of the batch); the launch runs in ceil(n_tiles * chunks / slots) rounds
     // over the resident slots, each round costing the plan staging (about 1.5 samples' worth) plus the samples of a
     // chunk: pick the chunk count that minimises rounds * (1.5 + samples per chunk).  (NS: 768 tiles on 512 slots -> 2
     // chunks = exactly 3 rounds, 91 us; the former "about 4 rounds" rule gave 3 chunks = 4.5 rounds, 102 us.)
-    const long slots = 256L * ((160 * 1024) / (long)lds > 0 ? (160 * 1024) / (long)lds : 1);
+    long per_cu = (160 * 1024) / (long)lds > 0 ? (160 * 1024) / (long)lds : 1;
+    if (!two_wg_regs) per_cu = 1;
+    if (per_cu > 2) per_cu = 2;                              // 512-thread workgroups at <= 128 registers: two per CU
+    const long slots = 256L * per_cu;
     long chunks = 1;
     {
         double best = -1.0;
@@ -446,10 +451,14 @@ int dsw_spmm2_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const 
     const int nst = (plan->max_n2 + rpp - 1) / rpp;
     const int ns1 = (plan->max_n1 + rpp - 1) / rpp;
     const int ns2 = (plan->tile_rows + rpp - 1) / rpp;
-    // the common shape (64-row tiles, 8 lanes per row: 146 / 100 / 64 rows in 64-row passes) gets exact slot
-    // counts - 16 fewer live registers in the adjoint variants; everything else sizes all three by NST
-    if (nst == 3 && ns1 <= 2 && ns2 <= 1)
-        return dtype == DSW_BF16 ? launch_h2<true, 3, 2, 1>(A, nwg, lds, stream) : launch_h2<false, 3, 2, 1>(A, nwg, lds, stream);
+    // the common shapes (64-row tiles, 8 lanes per row) get exact slot counts - fewer live registers in the adjoint
+    // variants - and byte-offset ELL entries: k = 8 (158 / 108 / 64 rows = 3 / 2 / 1 passes of 64 rows) and k = 20
+    // (280 / 155 / 64 rows = 5 / 3 / 1); everything else sizes all three by NST
+    const bool byteoff = (long)plan->max_n2 * A.row_bytes <= 65535;
+    if (byteoff && nst == 3 && ns1 <= 2 && ns2 <= 1)
+        return dtype == DSW_BF16 ? launch_h2<true, 3, 2, 1, true>(A, nwg, lds, stream) : launch_h2<false, 3, 2, 1, true>(A, nwg, lds, stream);
+    if (byteoff && (nst == 4 || nst == 5) && ns1 <= 3 && ns2 <= 1)
+        return dtype == DSW_BF16 ? launch_h2<true, 5, 3, 1, true>(A, nwg, lds, stream) : launch_h2<false, 5, 3, 1, true>(A, nwg, lds, stream);
 #define DSW_H2_NST(N_)                                                                                     \
     case N_:                                                                                               \
         return dtype == DSW_BF16 ? launch_h2<true, N_, N_, N_>(A, nwg, lds, stream)                        \

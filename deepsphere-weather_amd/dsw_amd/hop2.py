@@ -65,7 +65,7 @@ class Hop2Plan:
         S2 (two buffers unless ``single_buf``), the first-hop rows on S1, {col, val} pairs, the gather list."""
         ell_w = (self.max_row_len + 3) & ~3
         s = (self.max_n1 + (1 if single_buf else 2) * self.max_n2) * row_bytes   # bufT + input rows
-        s += self.max_n1 * ell_w * 8                      # ELL {col, val}
+        s += self.max_n1 * ell_w * 6                      # ELL: fp32 values + u16 list positions
         s += ((self.max_n2 + 3) & ~3) * 4 + 16            # gather list + the tile's loop length
         return (s + 15) & ~15
 
