@@ -3,25 +3,30 @@
 //     T1 = L X,   T2 = 2 L T1 - X            (layers.py:163-169)
 //     Y  = [X | T1 | T2] W + bias            (layers.py:171-178, :375)
 //
-// The two-hop SpMM of dsw_spmm2.hip (same tile plan, same LDS staging of the tile's 2-ring, same prefetch scheme)
-// followed, per (tile, sample), by the channel mix on the matrix cores while X, T1 and T2 of the tile rows are still
-// in LDS.  The unfused sequence reads X, T1, T2 back from HBM in the mix kernel (3 of its 5 tensor passes); here the
-// launch moves X in, T1 / T2 out (once, for backward; not at all when the caller passes T = NULL) and Y out.
+// The two-hop SpMM of dsw_spmm2.hip (same tile plan, same LDS staging of the tile's 2-ring, same gather code) followed,
+// per (tile, sample), by the channel mix on the matrix cores while X, T1 and T2 of the tile rows are still on chip.
+// The unfused sequence reads X, T1, T2 back from HBM in the mix kernel (3 of its 5 tensor passes); here the launch moves
+// X in, T1 / T2 out (once, for backward) and Y out.
 //
-// Matrix part.  v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate: bitwise an fmaf chain, no operand splitting) in the
-// SWAPPED orientation  Y^T = W^T T^T :  the "A" operand is the W fragment (16 output channels of the wave's column
-// block), held in REGISTERS for the lifetime of the workgroup (3 planes x 8 k-steps = 24 VGPRs - no LDS for the
-// panel, so two workgroups still share a CU), the "B" operand is read from the staged rows (lane = row, 16 bytes per
-// read feed four k-steps), and the accumulator comes out as 4 CONSECUTIVE output channels of one row per lane:
-// 16-byte stores, 64 contiguous bytes per row and instruction.  The fp32 MFMA runs at 1/16 of the bf16 rate (61 us of
-// matrix-pipe time per launch at the north-star shape), but the pipe is otherwise idle in this latency-bound kernel
-// and the 3-way bf16 split of the first version cost more VALU issue time (every wave re-split the rows it shares
-// with the other column blocks: +32 M VALU instructions, 181 us) than the matrix time it saved.
-// LDS rows stay 128 bytes apart; the 16-byte chunk c of row r sits at chunk position c ^ ((r >> 1) & 7).  The row
-// gathers of the hops read all 8 chunks of a row (any order is as good as another; the ELL entry carries the row's
-// swizzle so that the address is ONE v_xad_u32), and the MFMA operand reads - 16 rows x one chunk column per lane
-// group, a 4-way bank conflict in the plain layout - become conflict-free.  T2 of the tile rows is parked in the dead
-// halo rows of the current input buffer, so the mix needs no LDS of its own and only ONE extra barrier per sample.
+// Matrix part: fp32 product on the bf16 pipe by exact 3-way operand splitting (x = h + m + l, 8 + 8 + 8 mantissa bits;
+// six MFMA terms, as ts_gemm_x3), v_mfma_f32_16x16x32_bf16 in the SWAPPED orientation  Y^T = W^T T^T :
+//   * the "A" operand is the W fragment (16 output channels of the wave's column block x one 32-channel plane), split
+//     once per workgroup and held in REGISTERS (3 planes x 3 terms x 4 VGPRs = 36) - no LDS for the panel, so two
+//     workgroups still share a CU;
+//   * the "B" operand are the tile rows.  Every row is split ONCE, by the thread that produces it (the staging thread
+//     for X, the phase-1 / phase-2 thread for T1 / T2: 5.5 VALU per element), into three bf16 images in LDS
+//     ([plane][term][64 rows][64 B], 36 KB), from which each wave reads ready-made fragments (one ds_read_b128 per
+//     term).  What this replaces, measured at the north-star shape: splitting on the fly in every wave that shares a
+//     row (4 column blocks): +32 M VALU instructions, 181 us; v_mfma_f32_16x16x4_f32 (no split): 165 us - the fp32
+//     MFMA issues at the VECTOR rate and did not overlap with the other workgroup's gather FMAs (removing the MFMAs
+//     gave back 47 of its 61 us);
+//   * the accumulator comes out as 4 CONSECUTIVE output channels of one row per lane: 16-byte stores, 64 contiguous
+//     bytes per row and instruction.  One 32-channel plane is exactly one MFMA k-step.
+// The 36 KB of split images are paid for by single-buffering the input rows: the next sample's rows (prefetched into
+// registers right after barrier A, as in dsw_spmm2.hip) are written to LDS after barrier C, when phase 2 - the last
+// reader of the input buffer - is over, and BEFORE the MFMA phase, which reads only the split images.  Three
+// workgroup barriers per sample.  16-byte chunk kc of row r of a split image sits at chunk kc ^ (2 * ((r >> 3) & 1)):
+// the fragment reads (16 rows x one chunk column per lane group) are bank-conflict free.
 #include <cstdlib>
 #include "dsw_common.h"
 #include "../../include/dsw_hip.h"
@@ -31,15 +36,11 @@ int dsw_spmm2_supported(const dsw_hop2_plan* plan, int64_t C, int dtype);
 namespace {
 
 constexpr int NTHREADS = 512;
-constexpr int RB = 128;    // bytes of one activation row in HBM (32 fp32 channels)
-constexpr int LS = 128;    // row stride in LDS (16-byte chunks XOR-swizzled by the row, see above)
-constexpr int LPR = 8;     // 16-byte lanes per row
-constexpr int RPP = 64;    // rows per pass of the 512 threads
-#ifndef DSW_FWD3_GB
-#define DSW_FWD3_GB 6
-#endif
-constexpr int GB = DSW_FWD3_GB;   // gathered rows in flight per thread
+constexpr int RB = 128;    // bytes of one activation row (32 fp32 channels), in HBM and in the LDS staging buffers
+constexpr int RPP = 64;    // rows per pass of the 512 threads (8 lanes of 16 bytes per row)
+constexpr int SPLIT_BYTES = 3 * 3 * 64 * 64;   // [plane][term][row][32 bf16]
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 struct Fwd3Args {
@@ -60,65 +61,91 @@ struct Fwd3Args {
     int relu;            // ReLU after the bias (ConvBlock)
 };
 
-// byte offset of 16-byte chunk position (c ^ swizzle(row)) given c * 16 = cb: cb ^ swz(row)
-static __device__ __forceinline__ unsigned swz(const int row) { return (unsigned)((row >> 1) & 7) << 4; }
+static __device__ __forceinline__ float trunc_bf16(float f) { return __uint_as_float(__float_as_uint(f) & 0xffff0000u); }
+// truncating fp32 -> bf16 of a pair: v_perm_b32 keeps the two high bytes of each value (lo in the low half)
+static __device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+// x = h + m + l exactly (8 + 8 + 8 mantissa bits by truncation; the residuals are exact in fp32)
+static __device__ __forceinline__ void split3x8(const float (&f)[8], bf16x8_t& h, bf16x8_t& m, bf16x8_t& l) {
+    float r1[8], r2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        r1[j] = f[j] - trunc_bf16(f[j]);
+        r2[j] = r1[j] - trunc_bf16(r1[j]);
+    }
+    uint4 uh = {pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7])};
+    uint4 um = {pack2(r1[0], r1[1]), pack2(r1[2], r1[3]), pack2(r1[4], r1[5]), pack2(r1[6], r1[7])};
+    uint4 ul = {pack2(r2[0], r2[1]), pack2(r2[2], r2[3]), pack2(r2[4], r2[5]), pack2(r2[6], r2[7])};
+    h = __builtin_bit_cast(bf16x8_t, uh); m = __builtin_bit_cast(bf16x8_t, um); l = __builtin_bit_cast(bf16x8_t, ul);
+}
+// the three bf16 images of 4 consecutive channels of one tile row -> LDS (8 bytes per term)
+static __device__ __forceinline__ void split_store(unsigned char* __restrict__ simg, const int plane, const int row,
+                                                   const unsigned c4, const float (&f)[4]) {
+    float r1[4], r2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r1[j] = f[j] - trunc_bf16(f[j]);
+        r2[j] = r1[j] - trunc_bf16(r1[j]);
+    }
+    // byte offset inside the 64-byte row: 16-byte chunk (c4 >> 1) swizzled by the row, 8-byte half (c4 & 1)
+    const unsigned off = (unsigned)row * 64u + ((((c4 >> 1) ^ (((unsigned)row >> 2) & 2u)) << 4) | ((c4 & 1u) << 3));
+    unsigned char* base = simg + (size_t)plane * (3 * 64 * 64) + off;
+    *reinterpret_cast<uint2*>(base) = make_uint2(pack2(f[0], f[1]), pack2(f[2], f[3]));
+    *reinterpret_cast<uint2*>(base + 64 * 64) = make_uint2(pack2(r1[0], r1[1]), pack2(r1[2], r1[3]));
+    *reinterpret_cast<uint2*>(base + 2 * 64 * 64) = make_uint2(pack2(r2[0], r2[1]), pack2(r2[2], r2[3]));
+}
 
-// acc += sum_j val[j] * buf[off[j]] over the first W entries {byte offset, value} of one ELL row (see dsw_spmm2.hip)
-// entries carry  row * 128 + swizzle(row);  the lane's chunk of that row is at  buf + (entry ^ cb)
-static __device__ __forceinline__ void gather_ell(const uint2* __restrict__ row_ent, const int W,
-                                                  const unsigned char* __restrict__ buf, const unsigned cb,
-                                                  float (&acc)[4]) {
-    const uint4* e4 = reinterpret_cast<const uint4*>(row_ent);   // {off0, val0, off1, val1}
+// acc += sum_j val[j] * buf[pos[j]] over the first W entries of one ELL row: fp32 values + u8 list POSITIONS of the rows
+// in the staging buffer (W % 4 == 0 storage, W even in use, padded with {own row, 0}); bufc = staging buffer + this
+// lane's byte offset in a row.  One byte per index (the 2-ring of a 64-row tile has < 256 rows) is what keeps the
+// workgroup under 80 KB at nside = 64 (115 / 175 rows in the fattest tile).
+// 4 rows in flight per batch (the two-hop kernel takes 8): 36 registers hold the W fragments for the whole workgroup,
+// and a spill costs a scratch access + s_waitcnt vmcnt(0) in the middle of the prefetch window.
+static __device__ __forceinline__ void gather_ell(const unsigned char* __restrict__ row_idx, const float* __restrict__ row_val,
+                                                  const int W, const unsigned char* __restrict__ bufc, float (&acc)[4]) {
     int j = 0;
-    // 4 rows per batch (the two-hop kernel takes 8): the W fragments of the mix live in registers for the whole
-    // workgroup, and a spilled address costs a scratch load + vmcnt(0) in the middle of the prefetch window
-    for (; j + GB <= W; j += GB) {
-        uint4 e[GB / 2], d[GB];
+    for (; j + 4 <= W; j += 4) {
+        const unsigned w = *reinterpret_cast<const unsigned*>(row_idx + j);
+        const float4 v0 = *reinterpret_cast<const float4*>(row_val + j);
+        const unsigned ix[4] = {(w & 0xffu) << 7, ((w >> 8) & 0xffu) << 7, ((w >> 16) & 0xffu) << 7, (w >> 24) << 7};
+        const float vv[4] = {v0.x, v0.y, v0.z, v0.w};
+        float4 d[4];
 #pragma unroll
-        for (int t = 0; t < GB / 2; ++t) e[t] = e4[(j >> 1) + t];
+        for (int t = 0; t < 4; ++t) d[t] = *reinterpret_cast<const float4*>(bufc + ix[t]);
 #pragma unroll
-        for (int t = 0; t < GB / 2; ++t) {
-            d[2 * t] = *reinterpret_cast<const uint4*>(buf + (e[t].x ^ cb));
-            d[2 * t + 1] = *reinterpret_cast<const uint4*>(buf + (e[t].z ^ cb));
-        }
-#pragma unroll
-        for (int t = 0; t < GB / 2; ++t) {
-            const float v0 = __uint_as_float(e[t].y), v1 = __uint_as_float(e[t].w);
-            const uint32_t a[4] = {d[2 * t].x, d[2 * t].y, d[2 * t].z, d[2 * t].w};
-            const uint32_t b[4] = {d[2 * t + 1].x, d[2 * t + 1].y, d[2 * t + 1].z, d[2 * t + 1].w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                acc[c] = fmaf(v0, __uint_as_float(a[c]), acc[c]);
-                acc[c] = fmaf(v1, __uint_as_float(b[c]), acc[c]);
-            }
+        for (int t = 0; t < 4; ++t) {
+            acc[0] = fmaf(vv[t], d[t].x, acc[0]); acc[1] = fmaf(vv[t], d[t].y, acc[1]);
+            acc[2] = fmaf(vv[t], d[t].z, acc[2]); acc[3] = fmaf(vv[t], d[t].w, acc[3]);
         }
     }
-    for (; j + 2 <= W; j += 2) {   // W is even
-        const uint4 ea = e4[j >> 1];
-        const uint4 d0 = *reinterpret_cast<const uint4*>(buf + (ea.x ^ cb));
-        const uint4 d1 = *reinterpret_cast<const uint4*>(buf + (ea.z ^ cb));
-        const float v0 = __uint_as_float(ea.y), v1 = __uint_as_float(ea.w);
-        const uint32_t a[4] = {d0.x, d0.y, d0.z, d0.w}, b[4] = {d1.x, d1.y, d1.z, d1.w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            acc[c] = fmaf(v0, __uint_as_float(a[c]), acc[c]);
-            acc[c] = fmaf(v1, __uint_as_float(b[c]), acc[c]);
-        }
+    if (j < W) {   // W is even: one last pair
+        const unsigned w = *reinterpret_cast<const unsigned short*>(row_idx + j);
+        const float2 v0 = *reinterpret_cast<const float2*>(row_val + j);
+        const float4 d0 = *reinterpret_cast<const float4*>(bufc + ((w & 0xffu) << 7));
+        const float4 d1 = *reinterpret_cast<const float4*>(bufc + ((w >> 8) << 7));
+        acc[0] = fmaf(v0.x, d0.x, acc[0]); acc[1] = fmaf(v0.x, d0.y, acc[1]);
+        acc[2] = fmaf(v0.x, d0.z, acc[2]); acc[3] = fmaf(v0.x, d0.w, acc[3]);
+        acc[0] = fmaf(v0.y, d1.x, acc[0]); acc[1] = fmaf(v0.y, d1.y, acc[1]);
+        acc[2] = fmaf(v0.y, d1.z, acc[2]); acc[3] = fmaf(v0.y, d1.w, acc[3]);
     }
 }
 
 // NST / NS1: register-stage slots per thread for the gather list (ceil(max_n2 / 64)) and for S1 (ceil(max_n1 / 64));
-// the tile is 64 rows = one slot.  NCB = Fout / 16 column blocks; a wave owns ONE column block (its W fragments stay in
+// the tile is 64 rows = slot 0.  NCB = Fout / 16 column blocks; a wave owns ONE column block (its W fragments stay in
 // registers) and RBW = NCB / 2 of the four 16-row blocks of the tile.
-template <int NST, int NS1, int NCB>
+// FULL: every tile has 64 rows (V % 64 == 0) and the basis is kept (T != NULL): no store of the loop sits under a
+// condition, so the compiler can count the VMEM operations behind the prefetch loads (s_waitcnt vmcnt(n), n > 0).
+template <int NST, int NS1, int NCB, bool FULL>
 __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3Args P) {
     constexpr int RBW = NCB / 2;
-    extern __shared__ __attribute__((aligned(128))) unsigned char lds[];
-    unsigned char* bufX0 = lds;                                             // [max_n2][LS]
-    unsigned char* bufX1 = bufX0 + (size_t)P.max_n2 * LS;                   // [max_n2][LS]
-    unsigned char* bufT = bufX1 + (size_t)P.max_n2 * LS;                    // [max_n1][LS]
-    uint2* ell = reinterpret_cast<uint2*>(bufT + (size_t)P.max_n1 * LS);    // [max_n1][W] {byte offset, value}
-    int* rows = reinterpret_cast<int*>(ell + (size_t)P.max_n1 * P.ell_w);   // [max_n2] global row ids
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* bufX = lds;                                              // [max_n2][128] input rows of the 2-ring
+    unsigned char* bufT = bufX + (size_t)P.max_n2 * RB;                     // [max_n1][128] T1 on the 1-ring
+    unsigned char* simg = bufT + (size_t)P.max_n1 * RB;                     // split images of the tile rows (36 KB)
+    float* ell_val = reinterpret_cast<float*>(simg + SPLIT_BYTES);          // [max_n1][W]
+    unsigned char* ell_idx = reinterpret_cast<unsigned char*>(ell_val + (size_t)P.max_n1 * P.ell_w);     // [max_n1][W] u8
+    int* rows = reinterpret_cast<int*>(ell_idx + (((size_t)P.max_n1 * P.ell_w + 3) & ~(size_t)3));   // [max_n2] global row ids
     int* tile_w = rows + ((P.max_n2 + 3) & ~3);
 
     const long nwg = gridDim.x, orig = blockIdx.x;                          // XCD-aware order (see dsw_spmm2.hip)
@@ -143,16 +170,20 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
     __syncthreads();
 
     const int grp = tid >> 3;                       // row of a 64-row pass
-    const unsigned cb = (unsigned)(tid & 7) * 16;   // byte offset of this lane inside a row
-    unsigned offU[NST];
-#pragma unroll
-    for (int k = 0; k < NST; ++k) offU[k] = (unsigned)rows[min(grp + k * RPP, n2 - 1)] * (unsigned)RB + cb;
+    const unsigned c4 = (unsigned)(tid & 7);        // 16-byte chunk (4 channels) of this lane inside a row
+    const unsigned cb = c4 * 16;
+    const unsigned tile_off = (unsigned)(r0 + grp) * (unsigned)RB + cb;    // this thread's tile row (slot 0), sample-relative
+    // byte offset (sample-relative) of list position grp + k * 64, index-clamped so that every load is legal and
+    // unconditional; re-read from LDS where needed instead of kept in registers (the W fragments need those)
+    auto offU = [&](const int k) __attribute__((always_inline)) {
+        return (unsigned)rows[min(grp + k * RPP, n2 - 1)] * (unsigned)RB + cb;
+    };
 
     u32x4 su[NST];
     if (b_begin < b_end) {
         const size_t sb = (size_t)b_begin * sample_bytes;
 #pragma unroll
-        for (int k = 0; k < NST; ++k) su[k] = *reinterpret_cast<const u32x4*>(P.X + sb + offU[k]);
+        for (int k = 0; k < NST; ++k) su[k] = *reinterpret_cast<const u32x4*>(P.X + sb + offU(k));
     }
     const int tile_nnz = lrp[n1];
     for (int t = tid; t < n1 * W; t += NTHREADS) {
@@ -166,8 +197,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
             val = P.lval[nnz_off + p];
         }
         if (j == 0 && p1 - p0 > 2) atomicMax(tile_w, p1 - p0);
-        ell[t] = (p0 + j < p1) ? make_uint2(col * (unsigned)LS + swz((int)col), __float_as_uint(val))
-                               : make_uint2((unsigned)i * (unsigned)LS + swz(i), 0u);
+        const bool live = p0 + j < p1;
+        ell_idx[t] = (unsigned char)(live ? col : (unsigned)i);
+        ell_val[t] = live ? val : 0.f;
     }
 
     // ---- W fragments of this wave's column block, split once: lane l holds W[f = 8 (l >> 4) + j][plane][n = 16 cbk + (l & 15)]
@@ -175,92 +207,109 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
     const int cbk = wave % NCB;
     const int rb0 = (wave / NCB) * RBW;
     const int l15 = lane & 15, kc = lane >> 4;
-    // k-step (s, q, t) contracts channel 16 q + 4 (lane >> 4) + t of plane s: a lane's 16-byte operand read feeds 4 steps
-    float wreg[3][2][4];
+    bf16x8_t wh[3], wm[3], wl[3];
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < 3; ++s) {
+        float f[8];
 #pragma unroll
-        for (int q2 = 0; q2 < 2; ++q2)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                wreg[s][q2][t] = P.W[((size_t)(16 * q2 + 4 * kc + t) * 3 + s) * P.Fout + 16 * cbk + l15];
+        for (int j = 0; j < 8; ++j) f[j] = P.W[((size_t)(8 * kc + j) * 3 + s) * P.Fout + 16 * cbk + l15];
+        split3x8(f, wh[s], wm[s], wl[s]);
+    }
     f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
     if (P.bias != nullptr) bias4 = *reinterpret_cast<const f32x4_t*>(P.bias + 16 * cbk + 4 * kc);
 
     __syncthreads();   // ELL complete (and lrp in bufT dead)
     const int Wt = (*tile_w + 1) & ~1;
+    // the first sample's rows (the loop writes the NEXT sample's rows after its barrier C)
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int i = grp + k * RPP;
+        if (i < n2) *reinterpret_cast<u32x4*>(bufX + (size_t)i * RB + cb) = su[k];
+    }
 
     for (int b = b_begin; b < b_end; ++b) {
-        unsigned char* bufX = ((b - b_begin) & 1) ? bufX1 : bufX0;
-#pragma unroll
-        for (int k = 0; k < NST; ++k) {
-            const int i = grp + k * RPP;
-            if (i < n2) *reinterpret_cast<u32x4*>(bufX + (size_t)i * LS + (cb ^ swz(i))) = su[k];
-        }
-        __syncthreads();   // A: bufX(b) complete; everybody is past the mix of sample b-1 (bufT reusable)
+        __syncthreads();   // A: bufX(b) complete; everybody is past the MFMA phase of sample b-1 (split images, bufT free)
         const size_t sample = (size_t)b * sample_bytes;
-        {   // next sample's input rows: in flight under all three phases
+        {   // next sample's input rows: in flight under phases 1 and 2
             const size_t sb = (size_t)(b + 1 < b_end ? b + 1 : b) * sample_bytes;
 #pragma unroll
-            for (int k = 0; k < NST; ++k) su[k] = *reinterpret_cast<const u32x4*>(P.X + sb + offU[k]);
+            for (int k = 0; k < NST; ++k) su[k] = *reinterpret_cast<const u32x4*>(P.X + sb + offU(k));
         }
-        // ---- phase 1: T1 = L X on S1
+        // ---- phase 1: T1 = L X on S1; the tile rows (slot 0) also leave their split images of X and T1
 #pragma unroll
         for (int k = 0; k < NS1; ++k) {
             const int i = grp + k * RPP;
-            if (i < n1) {
+            if (k == 0 || i < n1) {               // slot 0 = the tile rows (64 <= n1 whenever the tile is full)
                 float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                gather_ell(ell + (size_t)i * W, Wt, bufX, cb, acc);
+                gather_ell(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, bufX + cb, acc);
                 const uint4 packed = make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]),
                                                 __float_as_uint(acc[3]));
-                *reinterpret_cast<uint4*>(bufT + (size_t)i * LS + (cb ^ swz(i))) = packed;
-                if (P.T1 != nullptr && i < rt)
-                    *reinterpret_cast<uint4*>(P.T1 + sample + (size_t)(r0 + i) * RB + cb) = packed;
+                *reinterpret_cast<uint4*>(bufT + (size_t)i * RB + cb) = packed;
+                if (k == 0) {
+                    // uniform 64-bit base + 32-bit lane offset: the store takes its address from an SGPR pair + one VGPR
+                    if constexpr (FULL) *reinterpret_cast<uint4*>(P.T1 + sample + tile_off) = packed;
+                    else if (P.T1 != nullptr && i < rt) *reinterpret_cast<uint4*>(P.T1 + sample + tile_off) = packed;
+                    split_store(simg, 1, i, c4, acc);
+                    const float4 xr = *reinterpret_cast<const float4*>(bufX + (size_t)i * RB + cb);
+                    const float xf[4] = {xr.x, xr.y, xr.z, xr.w};
+                    split_store(simg, 0, i, c4, xf);
+                }
             }
         }
         __syncthreads();   // B
-        // ---- phase 2: T2 = 2 L T1 - X on the tile rows; parked in rows 64.. of bufX (halo rows, dead after phase 1)
+        // ---- phase 2: T2 = 2 L T1 - X on the tile rows -> HBM and split images
         {
             const int i = grp;
-            if (i < rt) {
+            if (FULL || i < rt) {
                 float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                gather_ell(ell + (size_t)i * W, Wt, bufT, cb, acc);
-                const uint4 u = *reinterpret_cast<const uint4*>(bufX + (size_t)i * LS + (cb ^ swz(i)));
-                const uint4 packed = make_uint4(__float_as_uint(fmaf(2.f, acc[0], -__uint_as_float(u.x))),
-                                                __float_as_uint(fmaf(2.f, acc[1], -__uint_as_float(u.y))),
-                                                __float_as_uint(fmaf(2.f, acc[2], -__uint_as_float(u.z))),
-                                                __float_as_uint(fmaf(2.f, acc[3], -__uint_as_float(u.w))));
-                *reinterpret_cast<uint4*>(bufX + (size_t)(64 + i) * LS + (cb ^ swz(i))) = packed;   // swz(64 + i) == swz(i)
-                if (P.T2 != nullptr)
-                    *reinterpret_cast<uint4*>(P.T2 + sample + (size_t)(r0 + i) * RB + cb) = packed;
+                gather_ell(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, bufT + cb, acc);
+                const float4 u = *reinterpret_cast<const float4*>(bufX + (size_t)i * RB + cb);
+                const float t2[4] = {fmaf(2.f, acc[0], -u.x), fmaf(2.f, acc[1], -u.y), fmaf(2.f, acc[2], -u.z), fmaf(2.f, acc[3], -u.w)};
+                if (FULL || P.T2 != nullptr)
+                    *reinterpret_cast<uint4*>(P.T2 + sample + tile_off) =
+                        make_uint4(__float_as_uint(t2[0]), __float_as_uint(t2[1]), __float_as_uint(t2[2]), __float_as_uint(t2[3]));
+                split_store(simg, 2, i, c4, t2);
             }
         }
-        __syncthreads();   // C
-        // ---- phase 3: Y[tile rows, 16 cbk ..+16] = [X | T1 | T2] W + bias on the matrix cores
-        const unsigned char* plane[3] = {bufX, bufT, bufX + (size_t)64 * LS};
+        __syncthreads();   // C: nobody reads bufX / bufT of this sample any more; split images complete
+        // next sample's rows -> the (single) input buffer
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int i = grp + k * RPP;
+            if (i < n2) *reinterpret_cast<u32x4*>(bufX + (size_t)i * RB + cb) = su[k];
+        }
+        // ---- phase 3: Y[tile rows, 16 cbk ..+16] = [X | T1 | T2] W + bias on the matrix cores, from the split images
         f32x4_t acc[RBW];
-        unsigned rowoff[RBW], rswz[RBW];
+        unsigned fro[RBW];
 #pragma unroll
         for (int r = 0; r < RBW; ++r) {
-            const int row = 16 * (rb0 + r) + l15;
+            const unsigned row = 16u * (rb0 + r) + l15;
             acc[r] = bias4;
-            rowoff[r] = (unsigned)row * LS;
-            rswz[r] = swz(row);
+            fro[r] = row * 64u + (((unsigned)kc ^ ((row >> 2) & 2u)) << 4);
         }
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
+            bf16x8_t th[RBW], tm[RBW], tl[RBW];
 #pragma unroll
-            for (int q2 = 0; q2 < 2; ++q2) {
-                f32x4_t x[RBW];
-#pragma unroll
-                for (int r = 0; r < RBW; ++r)
-                    x[r] = *reinterpret_cast<const f32x4_t*>(plane[s] + rowoff[r] + (((unsigned)(4 * q2 + kc) << 4) ^ rswz[r]));
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int r = 0; r < RBW; ++r)   // independent accumulators interleaved: no dependent-MFMA stall
-                        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s][q2][t], x[r][t], acc[r], 0, 0, 0);
+            for (int r = 0; r < RBW; ++r) {
+                const unsigned char* pb = simg + (size_t)s * (3 * 64 * 64) + fro[r];
+                th[r] = *reinterpret_cast<const bf16x8_t*>(pb);
+                tm[r] = *reinterpret_cast<const bf16x8_t*>(pb + 64 * 64);
+                tl[r] = *reinterpret_cast<const bf16x8_t*>(pb + 2 * 64 * 64);
             }
+            // six leading terms, smallest first; the RBW independent accumulators are interleaved
+#pragma unroll
+            for (int r = 0; r < RBW; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], th[r], acc[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RBW; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], tl[r], acc[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RBW; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[s], tm[r], acc[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RBW; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[s], th[r], acc[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RBW; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], tm[r], acc[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RBW; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], th[r], acc[r], 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < RBW; ++r) {   // lane: row 16 (rb0 + r) + l15, output channels 16 cbk + 4 kc .. + 3
@@ -269,34 +318,33 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[r][t] = acc[r][t] < 0.f ? 0.f : acc[r][t];   // NaN stays NaN (torch.relu)
             }
-            if (row < rt)
-                *reinterpret_cast<f32x4_t*>(P.Y + ((size_t)b * P.V + (size_t)(r0 + row)) * (size_t)P.Fout * 4 +
-                                            (size_t)(16 * cbk + 4 * kc) * 4) = acc[r];
+            if (FULL || row < rt)
+                *reinterpret_cast<f32x4_t*>(P.Y + (size_t)b * ((size_t)P.V * P.Fout * 4) +
+                                            (unsigned)((r0 + row) * P.Fout * 4 + (16 * cbk + 4 * kc) * 4)) = acc[r];
         }
-        // no barrier: the next iteration fills the OTHER input buffer, and its barrier A orders the reuse of bufT
     }
 }
 
 size_t fwd3_lds_bytes(const dsw_hop2_plan* plan) {
     const int ell_w = (plan->reserved + 3) & ~3;
-    size_t s = (size_t)(plan->max_n1 + 2 * (size_t)plan->max_n2) * LS;
-    s += (size_t)plan->max_n1 * ell_w * 8;
+    size_t s = (size_t)(plan->max_n1 + (size_t)plan->max_n2) * RB + SPLIT_BYTES;
+    s += (size_t)plan->max_n1 * ell_w * 4 + (((size_t)plan->max_n1 * ell_w + 3) & ~(size_t)3);   // fp32 values + u8 positions
     s += (size_t)((plan->max_n2 + 3) & ~3) * 4 + 16;
     return (s + 15) & ~(size_t)15;
 }
 
-template <int NST, int NS1>
+template <int NST, int NS1, bool FULL>
 int launch_ncb(const Fwd3Args& A, long nwg, size_t lds, hipStream_t stream) {
 #define DSW_F3(N_)                                                                                                      \
     case N_: {                                                                                                          \
-        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)cheb3_fwd_fused_kernel<NST, NS1, N_>,                   \
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)cheb3_fwd_fused_kernel<NST, NS1, N_, FULL>,             \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
             return DSW_ERR_LAUNCH;                                                                                      \
-        hipLaunchKernelGGL((cheb3_fwd_fused_kernel<NST, NS1, N_>), dim3((unsigned)nwg), dim3(NTHREADS), lds, stream, A); \
+        hipLaunchKernelGGL((cheb3_fwd_fused_kernel<NST, NS1, N_, FULL>), dim3((unsigned)nwg), dim3(NTHREADS), lds, stream, A); \
         break;                                                                                                          \
     }
     switch (A.Fout / 16) {
-        DSW_F3(2) DSW_F3(4) DSW_F3(8)
+        DSW_F3(2) DSW_F3(4)
         default: return DSW_ERR_BAD_ARG;
     }
 #undef DSW_F3
@@ -314,7 +362,7 @@ int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X,
     if (env && env[0] == '0') return 0;
     if (dtype != DSW_F32 || K != 3 || Fin != 32 || (Fout != 32 && Fout != 64)) return 0;   // (Fout = 128 compiles but spills)
     if (!plan || plan->tile_rows != 64 || !dsw_spmm2_supported(plan, Fin, dtype)) return 0;
-    if (plan->max_n2 < 128) return 0;                       // T2 is parked in rows 64..127 of the input buffer
+    if (plan->max_n2 > 255) return 0;                       // u8 list positions in the ELL
     if (!dsw_aligned16(X) || !dsw_aligned16(Y) || !dsw_aligned16(W) || (bias && !dsw_aligned16(bias)) ||
         (T && !dsw_aligned16(T)))
         return 0;
@@ -334,6 +382,7 @@ int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X,
     A.W = static_cast<const float*>(W); A.bias = static_cast<const float*>(bias);
     A.V = (int)V; A.n_tiles = plan->n_tiles; A.max_n1 = plan->max_n1; A.max_n2 = plan->max_n2;
     A.B = (int)B; A.ell_w = (plan->reserved + 3) & ~3; A.Fout = (int)Fout; A.relu = relu;
+
     // batch chunks: same cost model as the two-hop kernel (rounds x (staging + samples per chunk))
     const long slots = 256L * ((160 * 1024) / (long)lds > 0 ? (160 * 1024) / (long)lds : 1);
     long chunks = 1;
@@ -351,10 +400,11 @@ int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X,
     const long nwg = (long)plan->n_tiles * A.n_chunks;
     if (nwg > 2147483647L) return 0;
     int r;
-    if (nst == 3 && ns1 == 2) r = launch_ncb<3, 2>(A, nwg, lds, stream);
-    else if (nst == 2 && ns1 <= 2) r = launch_ncb<2, 2>(A, nwg, lds, stream);
-    else if (nst == 3) r = launch_ncb<3, 3>(A, nwg, lds, stream);
-    else r = launch_ncb<4, 4>(A, nwg, lds, stream);
+    const bool full = (V % 64 == 0) && T != nullptr;
+    if (nst == 3 && ns1 == 2) r = full ? launch_ncb<3, 2, true>(A, nwg, lds, stream) : launch_ncb<3, 2, false>(A, nwg, lds, stream);
+    else if (nst == 2 && ns1 <= 2) r = full ? launch_ncb<2, 2, true>(A, nwg, lds, stream) : launch_ncb<2, 2, false>(A, nwg, lds, stream);
+    else if (nst == 3) r = full ? launch_ncb<3, 3, true>(A, nwg, lds, stream) : launch_ncb<3, 3, false>(A, nwg, lds, stream);
+    else r = full ? launch_ncb<4, 4, true>(A, nwg, lds, stream) : launch_ncb<4, 4, false>(A, nwg, lds, stream);
     *rc = r;
     return 1;
 }
