@@ -196,6 +196,35 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None):
         except Exception:
             traffic = None
     out_mfma = mfma_leg(layer, x, T, steps)
+    # whole forward through the C ABI (dsw_cheb_fwd): at the north-star shape ONE launch (two hops + channel mix,
+    # dsw_fwd3.hip); its algorithmic bytes = the forward recurrence (5E + 2Lb for K = 3) + the mix (K E in, N Fout s out)
+    Fout = layer.out_channels
+    yb = torch.empty((B, V, Fout), dtype=x.dtype, device=x.device)
+    bias = layer.bias
+    mf = bool(lib.dsw_cheb_mix_first(C, Fout, K))
+    ppf, _k3 = F_._plan_ptr(op, x, Fout if mf else C) if K > 2 else (None, None)
+
+    def whole_fwd():
+        rc = lib.dsw_cheb_fwd(op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz, x.data_ptr(),
+                              layer.weight.data_ptr(), None if bias is None else bias.data_ptr(), yb.data_ptr(),
+                              T.data_ptr(), B, C, Fout, K, dcode, st, ppf)
+        assert rc == 0
+
+    for _ in range(3):
+        whole_fwd()
+    torch.cuda.synchronize()
+    t0.record(stream)
+    for _ in range(steps):
+        whole_fwd()
+    t1.record(stream)
+    torch.cuda.synchronize()
+    wf_s = t0.elapsed_time(t1) * 1e-3 / steps
+    wf_bytes = fwd_b + (K * E + B * V * Fout * es)
+    out_fwd = {"what": "dsw_cheb_fwd (recurrence + channel mix + bias), HIP events", "avg_us": round(wf_s * 1e6, 2),
+               "algorithmic_bytes": int(wf_bytes), "achieved_GBs": round(wf_bytes / wf_s / 1e9, 1),
+               "frac": round(wf_bytes / wf_s / 1e9 / HBM_PEAK_GBS, 4),
+               "compulsory_bytes": int(E + (K - 1) * E + B * V * Fout * es),
+               "note": "algorithmic = unfused pass count (SURVEY 8d); compulsory = X in, T_1.. out (kept for backward), Y out"}
     return {
         "bound": "hbm",
         "kernel": ("SpMM recurrence: forward %s + adjoint %s, %d launches/step" % (
@@ -211,6 +240,7 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None):
         "fwd_recurrence_us": round(fwd_s * 1e6, 2),
         "fwd_recurrence_frac": round(fwd_b / fwd_s / 1e9 / HBM_PEAK_GBS, 4),
         "mfma": out_mfma,
+        "whole_forward": out_fwd,
     }
 
 

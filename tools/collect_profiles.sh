@@ -1,0 +1,26 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): tools/collect_profiles.sh <round tag, e.g. r02>
+# Everything the DESIGN.md tables quote, into gpurun_out/profiles_<tag>/ (copy what should be judged into profiles/):
+#   bench lines of every workload, rocprofv3 kernel stats of the default bench command / unet / c3 / k=20,
+#   PMC passes (HBM traffic, MFMA busy, LDS) of the ns / c3 / k=20 workloads.
+tag=${1:-rXX}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out/profiles_$tag
+mkdir -p $out
+cd $root
+python bench.py > $out/${tag}_bench_ns_default.json 2> $out/bench.err
+python bench.py --knn 20 > $out/${tag}_bench_ns_k20.json 2>> $out/bench.err
+python bench.py --workload c3 > $out/${tag}_bench_c3.json 2>> $out/bench.err
+python bench.py --workload unet > $out/${tag}_bench_unet.json 2>> $out/bench.err
+python bench.py --workload c5 > $out/${tag}_bench_c5.json 2>> $out/bench.err
+bash tools/prof_stats.sh ${tag}_default > $out/stats_default.txt 2>&1
+bash tools/prof_stats.sh ${tag}_unet --workload unet --no-cpu-baseline --no-roofline --steps 10 > $out/stats_unet.txt 2>&1
+bash tools/prof_stats.sh ${tag}_c3 --workload c3 --no-cpu-baseline --steps 20 > $out/stats_c3.txt 2>&1
+bash tools/prof_stats.sh ${tag}_k20 --knn 20 --no-cpu-baseline --steps 20 > $out/stats_k20.txt 2>&1
+for t in default unet c3 k20; do cp $root/gpurun_out/prof_${tag}_$t/${tag}_${t}_kernel_stats.csv $out/${tag}_${t}_kernel_stats.csv 2>/dev/null; done
+bash tools/prof_pmc.sh ${tag}_ns > $out/${tag}_ns_pmc_summary.txt 2>&1
+BENCH_ARGS="--workload c3 --steps 10 --warmup 3 --no-cpu-baseline" bash tools/prof_pmc.sh ${tag}_c3 > $out/${tag}_c3_pmc_summary.txt 2>&1
+BENCH_ARGS="--knn 20 --steps 10 --warmup 3 --no-cpu-baseline" bash tools/prof_pmc.sh ${tag}_k20 > $out/${tag}_k20_pmc_summary.txt 2>&1
+python tools/make_traffic_json.py ns ${tag}_ns c3 ${tag}_c3 ns_k20 ${tag}_k20 > $out/traffic.log 2>&1
+cp profiles/spmm_traffic.json $out/spmm_traffic.json
+ls -la $out

@@ -24,7 +24,7 @@ for key, tag in zip(args[0::2], args[1::2]):
     vals = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(f"{ROOT}/gpurun_out/pmc_{tag}_[AB]/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            m = re.search(r"(spmm2_fused_kernel<[^>]*>|spmm_csr_rowsplit<[^>]*>)", r["Kernel_Name"])
+            m = re.search(r"(spmm2_fused_kernel<[^>]*>|spmm_csr_rowsplit<[^>]*>|cheb3_fwd_fused_kernel<[^>]*>|cheb_wgrad_x3_kernel<[^>]*>|ts_gemm_x3_kernel<[^>]*>)", r["Kernel_Name"])
             if m and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
                 vals[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
     kernels, total, launches = {}, 0.0, 0
@@ -35,6 +35,8 @@ for key, tag in zip(args[0::2], args[1::2]):
         wr = 1024.0 * sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
         n = len(d["WRITE_SIZE"])
         kernels[name] = {"read": round(rd), "write": round(wr), "dispatches_sampled": n}
+        if not name.startswith("spmm"):      # other kernels of the step: listed, not part of the SpMM mean
+            continue
         total += (rd + wr) * n
         launches += n
     if launches:
