@@ -580,7 +580,8 @@ def main():
             rl_layer, rl_what, rl_x = model, None, x.detach()
         if not args.no_roofline:
             out["roofline"] = roofline_leg(rl_layer, rl_x, max(10, args.steps), 5,
-                                           traffic_key=args.workload if (args.knn == 8 and rl_what is None) else None)
+                                           traffic_key=(None if rl_what is not None else args.workload if args.knn == 8
+                                                        else "ns_k20" if (args.workload == "ns" and args.knn == 20) else None))
             if rl_what is not None:
                 out["roofline"]["kernel"] += "; layer " + rl_what
         if not args.no_cpu_baseline:

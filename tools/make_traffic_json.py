@@ -27,20 +27,29 @@ for key, tag in zip(args[0::2], args[1::2]):
             m = re.search(r"(spmm2_fused_kernel<[^>]*>|spmm_csr_rowsplit<[^>]*>|cheb3_fwd_fused_kernel<[^>]*>|cheb_wgrad_x3_kernel<[^>]*>|ts_gemm_x3_kernel<[^>]*>)", r["Kernel_Name"])
             if m and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
                 vals[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    kernels, total, launches = {}, 0.0, 0
+    kernels, per_kernel = {}, {}
     for name, d in sorted(vals.items()):
         if not d["FETCH_SIZE"] or not d["WRITE_SIZE"]:
             continue
         rd = 2.0 * 1024 * sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"])
         wr = 1024.0 * sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
-        n = len(d["WRITE_SIZE"])
-        kernels[name] = {"read": round(rd), "write": round(wr), "dispatches_sampled": n}
-        if not name.startswith("spmm"):      # other kernels of the step: listed, not part of the SpMM mean
-            continue
-        total += (rd + wr) * n
-        launches += n
+        kernels[name] = {"read": round(rd), "write": round(wr), "dispatches_sampled": len(d["WRITE_SIZE"])}
+        if name.startswith("spmm"):          # other kernels of the step are listed, not part of the SpMM mean
+            per_kernel[name] = rd + wr
+    # launches of ONE step's recurrences (what bench.py's roofline leg times): every forward variant once (first pair
+    # without epilogue operands, later pairs with Z1), the adjoint variant (Z1 and Z2) as often as there are forward
+    # launches - independent of how many dispatches of each the profiled command happened to contain
+    is_adj = lambda n: bool(re.search(r"<(true|false), \d+, true, true", n))
+    fwd = [n for n in per_kernel if not is_adj(n)]
+    adj = [n for n in per_kernel if is_adj(n)]
+    total, launches = 0.0, 0
+    for n in fwd:
+        total += per_kernel[n]; launches += 1
+    for n in adj:
+        w = max(1, len(fwd)) / max(1, len(adj))
+        total += per_kernel[n] * w; launches += w
     if launches:
         result[key] = {"hbm_bytes_per_launch": round(total / launches), "kernels": kernels,
-                       "source": f"tools/prof_pmc.sh {tag} (passes A: FETCH_SIZE x2, B: WRITE_SIZE), dispatch-weighted mean"}
+                       "source": f"tools/prof_pmc.sh {tag} (passes A: FETCH_SIZE x2, B: WRITE_SIZE), mean over the SpMM launches of one step"}
 json.dump(result, open(out_path, "w"), indent=1)
 print(json.dumps(result, indent=1))
