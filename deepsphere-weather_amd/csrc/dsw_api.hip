@@ -48,7 +48,7 @@ static inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * 
 // UNet, 64 -> 2 output layer) take the mix-first order.  Its backward is the dual: Chebyshev basis of dY under L^T,
 // dX = sum_k D_k W_k^T, dW_k = X^T D_k - and needs nothing saved from the forward except X.
 static bool mix_first(int64_t Fin, int64_t Fout, int64_t K) {
-    static const char* env = getenv("DSW_MIX_FIRST");   // "0": always basis-first (diagnostics / A-B)
+    static const char* env = dsw_diag_env("DSW_MIX_FIRST");   // "0": always basis-first (diagnostics / A-B)
     if (env && env[0] == '0') return false;
     return K >= 2 && 2 * Fout <= Fin;
 }
@@ -102,7 +102,7 @@ int dsw_cheb_basis_fwd(const int32_t* rowptr, const int32_t* colind, const float
     hipStream_t s = (hipStream_t)stream;
     auto Tk = [&](int64_t k) -> const void* { return k == 0 ? X : static_cast<const void*>(t + (k - 1) * plane); };
     // hop pairs run fused whenever a supported plan is given (DSW_HOP2_FWD=0 forces one launch per hop)
-    static const char* fwd_env = getenv("DSW_HOP2_FWD");
+    static const char* fwd_env = dsw_diag_env("DSW_HOP2_FWD");
     const bool fused = plan != nullptr && !(fwd_env != nullptr && fwd_env[0] == '0') && dsw_spmm2_supported(plan, C, dtype);
     int rc = DSW_OK;
     int64_t k = 1;   // next basis index to produce

@@ -30,6 +30,16 @@ static __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
     return (uint16_t)(u >> 16);
 }
 
+// Diagnostic switches (A/B runs, ablations, kernel-selection overrides) exist only in builds made with -DDSW_DIAG
+// (`DSW_BUILD_DIAG=1 python -m dsw_amd.build`): the product library reads NO environment variable - a process-wide,
+// read-once switch that silently changes the evaluation order has no place in it.
+#ifdef DSW_DIAG
+#include <cstdlib>
+static inline const char* dsw_diag_env(const char* name) { return getenv(name); }
+#else
+static inline const char* dsw_diag_env(const char*) { return nullptr; }
+#endif
+
 static inline int dsw_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? DSW_OK : DSW_ERR_LAUNCH;

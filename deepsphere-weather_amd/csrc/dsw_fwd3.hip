@@ -358,7 +358,7 @@ int launch_ncb(const Fwd3Args& A, long nwg, size_t lds, hipStream_t stream) {
 int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X, const void* W, const void* bias, void* Y,
                             void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
                             int* rc, int relu) {
-    static const char* env = getenv("DSW_FWD_FUSED");   // "0": generic sequence (diagnostics / A-B)
+    static const char* env = dsw_diag_env("DSW_FWD_FUSED");   // "0": generic sequence (diagnostics / A-B)
     if (env && env[0] == '0') return 0;
     if (dtype != DSW_F32 || K != 3 || Fin != 32 || (Fout != 32 && Fout != 64)) return 0;   // (Fout = 128 compiles but spills)
     if (!plan || plan->tile_rows != 64 || !dsw_spmm2_supported(plan, Fin, dtype)) return 0;

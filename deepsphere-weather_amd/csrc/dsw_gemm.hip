@@ -532,7 +532,7 @@ int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* 
     P.C0 = Y; P.C1 = Y; P.c_plane_stride = 0; P.ldc = (int)Fout; P.n_planes_c = 1; P.n_per_plane = (int)Fout;
     P.bias = bias; P.M = N; P.relu = relu;
 #ifdef DSW_ABLATION   // build with -DDSW_ABLATION to enable the DSW_DBG ablation knobs (they produce wrong results by design)
-    { static const char* d = getenv("DSW_DBG"); P.dbg = d ? atoi(d) : 0; }
+    { static const char* d = dsw_diag_env("DSW_DBG"); P.dbg = d ? atoi(d) : 0; }
 #endif
     const uintptr_t am = (uintptr_t)(4 * es) - 1;
     P.a_vec = (Fin % 4 == 0) && (((uintptr_t)X & am) == 0) && (K == 1 || ((uintptr_t)T & am) == 0);
@@ -554,7 +554,7 @@ int dsw_mix_dgrad_launch(const void* dY, const void* W, void* G0, void* Grest, i
     P.n_per_plane = (int)Fin;
     P.bias = nullptr; P.M = N;
 #ifdef DSW_ABLATION   // build with -DDSW_ABLATION to enable the DSW_DBG ablation knobs (they produce wrong results by design)
-    { static const char* d = getenv("DSW_DBG"); P.dbg = d ? atoi(d) : 0; }
+    { static const char* d = dsw_diag_env("DSW_DBG"); P.dbg = d ? atoi(d) : 0; }
 #endif
     const uintptr_t am = (uintptr_t)(4 * es) - 1;
     P.a_vec = (Fout % 4 == 0) && (((uintptr_t)dY & am) == 0);

@@ -313,7 +313,7 @@ int launch_x3(const TsGemmParams& P, int col_tiles, size_t lds, hipStream_t stre
 // Takes the launch (returns 1, *rc = status) when the aligned problem's (split) W panel fits LDS.
 // fp32 storage -> 3-way split; bf16 storage -> plain bf16 MFMA.
 int dsw_ts_gemm_x3_try_launch(const TsGemmParams& P, int nt, int col_tiles, int bf16, hipStream_t stream, int* rc) {
-    static const char* x3env = getenv("DSW_GEMM_X3");   // "0": exact fp32 MFMA path (diagnostics / A-B)
+    static const char* x3env = dsw_diag_env("DSW_GEMM_X3");   // "0": exact fp32 MFMA path (diagnostics / A-B)
     if (x3env && x3env[0] == '0') return 0;
     const size_t ks = (size_t)P.n_planes_a * P.kd_per_plane + 8;
     const bool wide = bf16 && P.kd_per_plane % 64 == 0;

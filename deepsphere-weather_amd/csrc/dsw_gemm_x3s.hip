@@ -268,9 +268,9 @@ int launch_x3s(const TsGemmParams& P, int col_tiles, hipStream_t stream) {
 // Streaming-W x3 GEMM: fp32 storage, aligned operands (kd_per_plane % 32 == 0, 16-byte A rows).  Returns 1 when it
 // took the launch (*rc = status).
 int dsw_ts_gemm_x3s_try_launch(const TsGemmParams& P, hipStream_t stream, int* rc) {
-    static const char* x3env = getenv("DSW_GEMM_X3");   // "0": exact fp32 MFMA kernels (diagnostics / A-B)
+    static const char* x3env = dsw_diag_env("DSW_GEMM_X3");   // "0": exact fp32 MFMA kernels (diagnostics / A-B)
     if (x3env && x3env[0] == '0') return 0;
-    static const char* senv = getenv("DSW_GEMM_X3S");   // "0": disable only the streaming variant
+    static const char* senv = dsw_diag_env("DSW_GEMM_X3S");   // "0": disable only the streaming variant
     if (senv && senv[0] == '0') return 0;
     if (!P.a_vec || P.kd_per_plane % BK != 0 || P.M <= 0) return 0;
     const int n_total = P.n_planes_c * P.n_per_plane;
@@ -280,7 +280,7 @@ int dsw_ts_gemm_x3s_try_launch(const TsGemmParams& P, hipStream_t stream, int* r
     // waves per workgroup (tile rows = 32 * waves).  Measured over the UNet shapes: a chunk step costs about the same
     // for 4..8 waves (it is latency- not throughput-bound), so the 256-row tile wins whenever it still gives at
     // least half of the CUs a workgroup; tiny grids (nside=8 levels) take 128-row tiles to spread over more CUs.
-    static const char* nwvenv = getenv("DSW_X3S_NWV");
+    static const char* nwvenv = dsw_diag_env("DSW_X3S_NWV");
     const long tiles8 = ((P.M + 255) / 256) * col_tiles;
     const int nwv = nwvenv ? atoi(nwvenv) : (tiles8 < 128 ? 4 : 8);
 #define DSW_X3S(NT_, NWV_) (*rc = kfast ? launch_x3s<NT_, NWV_, true>(P, col_tiles, stream)   \

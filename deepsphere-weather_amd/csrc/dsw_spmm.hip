@@ -286,11 +286,11 @@ int launch_rowsplit(const int* rowptr, const int* colind, const float* vals, con
                     int v_in, int C, int B, hipStream_t stream, int hints = 0) {
     const int cpr = C / VEC;
     const long threads = (long)v_out * cpr;
-    static const char* bs_env = getenv("DSW_SPMM_BLOCK");   // diagnostics: threads per block (64..1024)
+    static const char* bs_env = dsw_diag_env("DSW_SPMM_BLOCK");   // diagnostics: threads per block (64..1024)
     const int bs = bs_env ? (atoi(bs_env) > 256 ? 256 : atoi(bs_env)) : 256;
     const long row_blocks = (threads + bs - 1) / bs;
     const long bgroups = (B + NB - 1) / NB;
-    static const char* sw = getenv("DSW_SPMM_XCD");  // "0" disables the XCD-aware block order (diagnostics)
+    static const char* sw = dsw_diag_env("DSW_SPMM_XCD");  // "0" disables the XCD-aware block order (diagnostics)
     // bit0: XCD block order, bit1: nt loads of Z/Z2, bit2: nt stores of Y (env overrides the caller's hints)
     const int swz = sw ? atoi(sw) : (1 | (hints & 6));
     dim3 grid((unsigned)(row_blocks * bgroups));
@@ -313,12 +313,12 @@ int dsw_spmm_launch(const int* rowptr, const int* colind, const float* vals, int
                     (Z2 == nullptr || dsw_aligned16(Z2));
     const int vo = (int)v_out, vi = (int)v_in, c = (int)C, b = (int)B;
     // kernel choice: LDS-tiled when a >=64-row tile of one sample fits 32 KiB and lanes divide evenly
-    static const char* force = getenv("DSW_SPMM_KERNEL");  // "rowsplit" | "tiled" (diagnostics only)
+    static const char* force = dsw_diag_env("DSW_SPMM_KERNEL");  // "rowsplit" | "tiled" (diagnostics only)
     const int es = dtype == DSW_BF16 ? 2 : 4;
     const int vec = dtype == DSW_BF16 ? 8 : 4;
     int tile_rows = 0;
     if (al && vo == vi && c % vec == 0 && c / vec <= 256) {  // square operators only: tile rows == tile columns
-        static const char* tb = getenv("DSW_SPMM_TILE_BYTES");
+        static const char* tb = dsw_diag_env("DSW_SPMM_TILE_BYTES");
         const long tile_bytes = tb ? atol(tb) : 32768;
         long r = tile_bytes / ((long)c * es);
         if (r > 1024) r = 1024;
@@ -333,7 +333,7 @@ int dsw_spmm_launch(const int* rowptr, const int* colind, const float* vals, int
         if (dtype == DSW_BF16)
             return launch_tiled<true, 8>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, tile_rows, stream);
     }
-    static const char* nbs = getenv("DSW_SPMM_NB");  // diagnostics: samples per thread
+    static const char* nbs = dsw_diag_env("DSW_SPMM_NB");  // diagnostics: samples per thread
     const int nbf = nbs ? atoi(nbs) : 0;
     if (dtype == DSW_F32) {
         if (al && c % 4 == 0) {

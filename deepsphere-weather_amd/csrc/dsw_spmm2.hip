@@ -421,7 +421,7 @@ int dsw_spmm2_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const 
     const int rpp_ = NTHREADS / A.lpr;
     const bool two_wg_regs = !((A.Z1 || A.Z1b) && (plan->max_n1 + rpp_ - 1) / rpp_ > 2);   // see __launch_bounds__
     A.single_buf = (lds2 <= 80 * 1024) ? 0 : (lds1 <= 80 * 1024 && two_wg_regs) ? 1 : (lds2 <= 160 * 1024) ? 0 : 1;
-    { static const char* sb = getenv("DSW_H2_SINGLE"); if (sb) A.single_buf = (sb[0] == '1') && lds1 <= 160 * 1024 ? 1 : (lds2 <= 160 * 1024 ? 0 : 1); }   // diagnostics
+    { static const char* sb = dsw_diag_env("DSW_H2_SINGLE"); if (sb) A.single_buf = (sb[0] == '1') && lds1 <= 160 * 1024 ? 1 : (lds2 <= 160 * 1024 ? 0 : 1); }   // diagnostics
     const size_t lds = A.single_buf ? lds1 : lds2;
     // batch chunks.  A workgroup = (tile, chunk of the batch); the launch runs in ceil(n_tiles * chunks / slots) rounds
     // over the resident slots, each round costing the plan staging (about 1.5 samples' worth) plus the samples of a
@@ -441,7 +441,7 @@ int dsw_spmm2_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const 
             if (best < 0 || cost < best - 1e-9) { best = cost; chunks = c; }
         }
     }
-    { static const char* ce = getenv("DSW_H2_CHUNKS"); if (ce) chunks = atol(ce); }   // diagnostics
+    { static const char* ce = dsw_diag_env("DSW_H2_CHUNKS"); if (ce) chunks = atol(ce); }   // diagnostics
     if (chunks < 1) chunks = 1;
     A.spc = (int)((B + chunks - 1) / chunks);
     A.n_chunks = (int)((B + A.spc - 1) / A.spc);

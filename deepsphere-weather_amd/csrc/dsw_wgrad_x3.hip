@@ -580,7 +580,7 @@ int launch_wx3(WgradParams& P, int groups, int otiles, int64_t max_slabs, int64_
 // Takes the launch (returns 1) for aligned problems: Fin % 32 == 0, Fout % 64 == 0, N % 32 == 0, 16-byte rows.
 // The (k, f)-tile / column tiling is chosen here: up to 8 waves per workgroup, 128 columns when Fout % 128 == 0.
 int dsw_wgrad_x3_try_launch(WgradParams& P, int bf16, int64_t max_slabs, int64_t* S_out, hipStream_t stream, int* rc) {
-    static const char* x3env = getenv("DSW_GEMM_X3");   // "0": exact fp32 MFMA kernels (diagnostics / A-B)
+    static const char* x3env = dsw_diag_env("DSW_GEMM_X3");   // "0": exact fp32 MFMA kernels (diagnostics / A-B)
     if (x3env && x3env[0] == '0') return 0;
     const int ntiles = P.K * P.tiles_per_plane;
     const int groups = (ntiles + 7) / 8;
@@ -627,9 +627,9 @@ int dsw_wgrad_x3_try_launch(WgradParams& P, int bf16, int64_t max_slabs, int64_t
 // workgroups per CU: the small layers of the path (north-star shape 32 -> 64, K = 3).  Returns 1 when it took the launch.
 int dsw_wgrad_dgrad_fused_try_launch(WgradParams& P, int bf16, int64_t max_slabs, int64_t* S_out, hipStream_t stream,
                                      int* rc) {
-    static const char* x3env = getenv("DSW_GEMM_X3");
+    static const char* x3env = dsw_diag_env("DSW_GEMM_X3");
     if (x3env && x3env[0] == '0') return 0;
-    static const char* fenv = getenv("DSW_BWD_FUSED");   // "0": separate dgrad and wgrad launches (A-B)
+    static const char* fenv = dsw_diag_env("DSW_BWD_FUSED");   // "0": separate dgrad and wgrad launches (A-B)
     if (fenv && fenv[0] == '0') return 0;
     if (P.dy_planes > 1 || !P.W || !P.G0 || (P.K > 1 && !P.Grest)) return 0;
     const int ntiles = P.K * P.tiles_per_plane;

@@ -35,6 +35,8 @@ def build(force=False, verbose=True):
     objdir = os.path.join(CSRC, "obj")
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    if os.environ.get("DSW_BUILD_DIAG") == "1":      # diagnostics build: enables the DSW_* run-time switches of csrc/
+        flags.append("-DDSW_DIAG")
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))

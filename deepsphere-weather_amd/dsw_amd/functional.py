@@ -79,10 +79,7 @@ class CsrOperator:
         if row_bytes not in self._plans:
             from . import hop2
 
-            import os
-
             plan = None
-            forced = os.environ.get("DSW_HOP2_ROWS")   # diagnostics: force a tile size
             host_csr = []
 
             def host_plan(rows):
@@ -99,7 +96,7 @@ class CsrOperator:
             # the 160 KiB LDS); a single resident workgroup (<= 156 KiB) is the last resort
             # (the kernel drops to ONE input-row buffer when that is what lets a second workgroup share the CU)
             for budget, single in ((80 * 1024, False), (80 * 1024, True), (156 * 1024, False), (156 * 1024, True)):
-                for rows in ((int(forced),) if forced else (256, 128, 64)):
+                for rows in (256, 128, 64):
                     if rows > self.shape[0]:
                         continue
                     cand = host_plan(rows)
@@ -215,7 +212,7 @@ def _plan_ptr(op, x, channels=None):
 
 
 _plan_ptr.disabled = False
-_FWD_FUSED = __import__("os").environ.get("DSW_HOP2_FWD") != "0"   # forward hop pairs fused unless disabled
+_FWD_FUSED = True   # forward hop pairs run fused whenever a plan exists
 
 
 class _HipBackend:

@@ -514,7 +514,7 @@ def test_equiangular_conv_and_cross_sampling_pooling():
 
 def test_mix_first_equals_basis_first(monkeypatch):
     """The two evaluation orders of a channel-shrinking layer agree to fp32 rounding (same inputs, both through
-    the C ABI; DSW_MIX_FIRST is read once per process, so the basis-first side is evaluated via the explicit
+    the C ABI; the product library has no run-time switch, so the basis-first side is evaluated via the explicit
     basis + mix entry points)."""
     from dsw_amd import _native, functional as F_
     from dsw_amd import sphere
