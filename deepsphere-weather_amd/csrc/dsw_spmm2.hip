@@ -80,7 +80,10 @@ struct Hop2Args {
     char* Y2;
     float a1, b1, d1, a2, b2, c2;
     int V, n_tiles, tile_rows, max_n1, max_n2, max_nnz;
-    int row_bytes;              // C * element size (multiple of 16)
+    int row_bytes;              // bytes of one STAGED row: the whole row (C * element size, multiple of 16) or one 128-byte
+                                // channel chunk of it
+    int row_stride;             // bytes between consecutive rows in HBM (C * element size)
+    int ncc;                    // channel chunks per row (row_stride / row_bytes); B counts (sample, chunk) pairs
     int lpr;                    // 16-byte lanes per row
     int B;
     int n_chunks;               // batch chunks per tile (grid = n_tiles * n_chunks)
@@ -199,7 +202,14 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
     const int rt = min(P.tile_rows, P.V - r0);
     const int tid = threadIdx.x;
     const int W = P.ell_w;
-    const size_t sample_bytes = (size_t)P.V * P.row_bytes;
+    const size_t sample_bytes = (size_t)P.V * P.row_stride;
+    // "sample" b of the loops below = (real sample b / ncc, channel chunk b % ncc): wide rows are processed one
+    // 128-byte channel chunk at a time (the operator acts on every channel alike), so that the staged neighbourhood is
+    // as small as for a 32-channel layer whatever the layer's width
+    auto vbase = [&](const int b) __attribute__((always_inline)) {
+        const int bs = b / P.ncc;
+        return (size_t)bs * sample_bytes + (size_t)(b - bs * P.ncc) * P.row_bytes;
+    };
 
     // ---- the tile's plan slice -> LDS, once for all samples of this workgroup.  Ordered so that nothing waits on
     // a chain of dependent global loads: (1) gather list + local row pointers (parked in bufT, free until the first
@@ -223,14 +233,14 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
         const int i = grp + k * rpp;
-        offU[k] = (unsigned)rows[min(i, n2 - 1)] * (unsigned)P.row_bytes + cb;
-        offZ1[k] = (unsigned)rows[min(i, n1 - 1)] * (unsigned)P.row_bytes + cb;
-        offZ2[k] = (unsigned)(r0 + min(i, rt - 1)) * (unsigned)P.row_bytes + cb;
+        offU[k] = (unsigned)rows[min(i, n2 - 1)] * (unsigned)P.row_stride + cb;
+        offZ1[k] = (unsigned)rows[min(i, n1 - 1)] * (unsigned)P.row_stride + cb;
+        offZ2[k] = (unsigned)(r0 + min(i, rt - 1)) * (unsigned)P.row_stride + cb;
     }
 
     u32x4 su[NST];
     if (b_begin < b_end) {
-        const size_t sb = (size_t)b_begin * sample_bytes;
+        const size_t sb = vbase(b_begin);
 #pragma unroll
         for (int k = 0; k < NST; ++k) su[k] = *reinterpret_cast<const u32x4*>(P.U + sb + offU[k]);
     }
@@ -264,7 +274,7 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
             if (lane_ok && i < n2) *reinterpret_cast<u32x4*>(bufX + (size_t)i * P.row_bytes + cb) = su[k];
         }
         __syncthreads();   // bufX(b) complete; every wave is past phase 2 of sample b-1 (bufT reusable)
-        const size_t sample = (size_t)b * sample_bytes;
+        const size_t sample = vbase(b);
         // burst: this sample's epilogue operands first, then the next sample's U rows
         // NS1 / NS2: slots that can hold an S1 row / a tile row (ceil(max_n1 / rpp), ceil(tile_rows / rpp))
         u32x4 cz1[HZA ? NS1 : 1], cz1b[HZA ? NS1 : 1], cz2[HZ2 ? NS2 : 1];
@@ -281,7 +291,7 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
             for (int k = 0; k < NS2; ++k) cz2[k] = *reinterpret_cast<const u32x4*>(P.Z2 + sample + offZ2[k]);
         }
         {
-            const size_t sb = (size_t)(b + 1 < b_end ? b + 1 : b) * sample_bytes;   // tail: harmless re-read
+            const size_t sb = vbase(b + 1 < b_end ? b + 1 : b);   // tail: harmless re-read
 #pragma unroll
             for (int k = 0; k < NST; ++k) su[k] = *reinterpret_cast<const u32x4*>(P.U + sb + offU[k]);
         }
@@ -313,7 +323,7 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
                 const uint4 packed = R::pack(o);
                 *reinterpret_cast<uint4*>(bufT + (size_t)i * P.row_bytes + cb) = packed;
                 if (P.Y1 != nullptr && i < rt)
-                    *reinterpret_cast<uint4*>(P.Y1 + sample + (size_t)(r0 + i) * P.row_bytes + cb) = packed;
+                    *reinterpret_cast<uint4*>(P.Y1 + sample + (size_t)(r0 + i) * P.row_stride + cb) = packed;
             }
         }
         __syncthreads();
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
 #pragma unroll
                     for (int j = 0; j < N; ++j) o[j] = fmav(R::splat(P.c2), z[j], o[j]);
                 }
-                *reinterpret_cast<uint4*>(P.Y2 + sample + (size_t)(r0 + i) * P.row_bytes + cb) = R::pack(o);
+                *reinterpret_cast<uint4*>(P.Y2 + sample + (size_t)(r0 + i) * P.row_stride + cb) = R::pack(o);
             }
         }
         // double-buffered: no barrier here - the next iteration writes the OTHER bufX, and its barrier orders bufT reuse
@@ -363,8 +373,10 @@ static size_t hop2_lds_bytes(const dsw_hop2_plan* plan, int row_bytes, bool sing
 int dsw_spmm2_supported(const dsw_hop2_plan* plan, int64_t C, int dtype) {
     if (!plan || plan->n_tiles <= 0 || plan->reserved <= 0) return 0;
     const int es = dtype == DSW_BF16 ? 2 : 4;
-    const int64_t row_bytes = C * es;
-    if (row_bytes % 16 != 0 || row_bytes / 16 > NTHREADS) return 0;
+    int64_t row_bytes = C * es;
+    if (row_bytes % 16 != 0) return 0;
+    if (row_bytes > 128 && row_bytes % 128 == 0) row_bytes = 128;   // wide rows: one 128-byte channel chunk at a time
+    if (row_bytes / 16 > NTHREADS) return 0;
     const int64_t rpp = NTHREADS / (row_bytes / 16);
     if ((plan->max_n2 + rpp - 1) / rpp > MAXST) return 0;   // register staging capacity
     return hop2_lds_bytes(plan, (int)row_bytes, true) <= 160 * 1024 ? 1 : 0;
@@ -413,7 +425,11 @@ int dsw_spmm2_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const 
     if (A.Z1 && !A.Z1b) A.Z1b = A.Z1;   // the kernel skips the second operand when both alias
     A.V = (int)V; A.n_tiles = plan->n_tiles; A.tile_rows = plan->tile_rows;
     A.max_n1 = plan->max_n1; A.max_n2 = plan->max_n2; A.max_nnz = plan->max_nnz;
-    A.row_bytes = (int)(C * es); A.lpr = A.row_bytes / 16; A.B = (int)B;
+    A.row_stride = (int)(C * es);
+    A.row_bytes = (A.row_stride > 128 && A.row_stride % 128 == 0) ? 128 : A.row_stride;
+    A.ncc = A.row_stride / A.row_bytes;
+    B *= A.ncc;                                            // from here on B counts (sample, channel chunk) pairs
+    A.lpr = A.row_bytes / 16; A.B = (int)B;
     A.ell_w = hop2_ell_w(plan);
     // staging buffers: double-buffered input rows unless that costs the second resident workgroup (<= 80 KiB each) or
     // does not fit at all - the k = 20 stencil's 2-ring is 4x the tile, and 8 waves per CU cannot hide the LDS latency

@@ -203,7 +203,10 @@ def _plan_ptr(op, x, channels=None):
     last axis of x), or None."""
     if _plan_ptr.disabled or op is None:
         return None, None
-    plan = op.hop2_plan((x.shape[-1] if channels is None else channels) * x.element_size())
+    row_bytes = (x.shape[-1] if channels is None else channels) * x.element_size()
+    if row_bytes > 128 and row_bytes % 128 == 0:
+        row_bytes = 128          # wide rows are staged one 128-byte channel chunk at a time (dsw_spmm2.hip)
+    plan = op.hop2_plan(row_bytes)
     if plan is None:
         return None, None
     import ctypes
