@@ -81,7 +81,8 @@ class _C5Block(torch.nn.Module):
 
         fine = sphere.SphereEquiangular(nlat=wl["nlat"], nlon=wl["nlon"], k=20)
         coarse = sphere.SphereHealpix(32, nest=True, k=20)
-        pool_m, unpool_m = sphere.knn_interp_pool_matrices(fine.coords, coarse.coords, k=9)
+        # conservative (overlap-area) weights between the two Voronoi meshes: what the reference builds with xsphere + CDO
+        pool_m, unpool_m = sphere.conservative_pool_matrices(fine.coords, coarse.coords)
         torch.manual_seed(10)
         self.conv_fine = ConvCheb(wl["fin"], wl["fout"], wl["K"], laplacian=prepare_torch_laplacian(fine.L, lmax=1.95))
         self.pool = GeneralAvgPool(pool_m)

@@ -49,10 +49,20 @@ def voronoi_cells(coords):
     vertex counts ``[V]`` and cell areas ``[V]`` (sum = 4 pi)."""
     sv = SphericalVoronoi(np.asarray(coords, dtype=np.float64), radius=1.0, center=np.zeros(3))
     sv.sort_vertices_of_regions()
-    counts = np.array([len(r) for r in sv.regions])
+    # ragged region lists -> padded array; coincident consecutive vertices are merged first (at a pole of an equiangular
+    # grid hundreds of Voronoi vertices coincide: the ring of cells around it would otherwise drag the padded width of
+    # EVERY cell to its vertex count)
+    regions = []
+    for r in sv.regions:
+        v = sv.vertices[r]
+        keep = np.linalg.norm(v - np.roll(v, -1, axis=0), axis=1) > 1e-11
+        if keep.sum() >= 3:
+            r = [ri for ri, k in zip(r, keep) if k]
+        regions.append(r)
+    counts = np.array([len(r) for r in regions])
     M = int(counts.max())
-    idx = np.zeros((len(sv.regions), M), dtype=np.int64)
-    for i, r in enumerate(sv.regions):     # one cheap pass to pad the ragged region lists
+    idx = np.zeros((len(regions), M), dtype=np.int64)
+    for i, r in enumerate(regions):
         idx[i, : len(r)] = r
         idx[i, len(r):] = r[0]
     P = sv.vertices[idx]
@@ -154,10 +164,18 @@ def conservative_weights(src_coords, dst_coords, min_frac=1e-12) -> RemapWeights
     close = sep <= (r_dst[pd_] + r_src[ps_]) * (1 + 1e-9)
     pd_, ps_ = pd_[close], ps_[close]
     area = np.empty(pd_.size)
+    # pairs are clipped in groups of similar vertex counts: the padded work arrays are as wide as the widest polygon
+    # of the group (a handful of cells - around poles, at face corners - have many more vertices than the rest)
+    key = np.maximum(src_n[ps_], 8) * 1000 + np.maximum(dst_n[pd_], 8)
+    order = np.argsort(key, kind="stable")
+    bounds = np.flatnonzero(np.diff(key[order])) + 1
     step = 200_000                           # bound the padded work arrays
-    for i in range(0, pd_.size, step):
-        sl = slice(i, i + step)
-        area[sl] = overlap_areas(src_P, src_n, dst_P, dst_n, pd_[sl], ps_[sl])
+    for lo, hi in zip(np.concatenate([[0], bounds]), np.concatenate([bounds, [order.size]])):
+        grp = order[lo:hi]
+        ms, md = int(src_n[ps_[grp]].max()), int(dst_n[pd_[grp]].max())
+        for i in range(0, grp.size, step):
+            sel = grp[i:i + step]
+            area[sel] = overlap_areas(src_P[:, :ms], src_n, dst_P[:, :md], dst_n, pd_[sel], ps_[sel])
     keep = area > min_frac * dst_area[pd_]
     pd_, ps_, area = pd_[keep], ps_[keep], area[keep]
     return RemapWeights(pd_, ps_, area / dst_area[pd_], src_area, dst_area)

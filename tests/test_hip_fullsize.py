@@ -122,7 +122,7 @@ def test_c5_equiangular_full_size_vs_oracle():
 
     fine = sphere.SphereEquiangular(nlat=200, nlon=400, k=20)
     coarse = sphere.SphereHealpix(32, nest=True, k=20)
-    pool_m, unpool_m = sphere.knn_interp_pool_matrices(fine.coords, coarse.coords, k=9)
+    pool_m, unpool_m = sphere.conservative_pool_matrices(fine.coords, coarse.coords)   # overlap areas, up to ~300 per row
     lap = prepare_torch_laplacian(fine.L, lmax=1.95)
     torch.manual_seed(5)
     conv = ConvCheb(32, 32, 3, laplacian=lap).to(DEV)

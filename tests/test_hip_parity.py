@@ -483,7 +483,7 @@ def test_equiangular_conv_and_cross_sampling_pooling():
     coarse = sphere.SphereHealpix(4, nest=True, k=8)
     deg = np.diff(fine.L.tocsr().indptr)
     assert deg.max() > deg.min()                       # the stress: rows of different length
-    pool_m, unpool_m = sphere.knn_interp_pool_matrices(fine.coords, coarse.coords, k=9)
+    pool_m, unpool_m = sphere.conservative_pool_matrices(fine.coords, coarse.coords)   # overlap areas (layers.py:529-581)
     lap = prepare_torch_laplacian(fine.L, lmax=1.95)
     torch.manual_seed(5)
     conv = ConvCheb(32, 32, 3, laplacian=lap).to(DEV)
@@ -751,3 +751,64 @@ def test_convblock_fused_bias_relu_vs_oracle(V, B, Fin, Fout, K, dt):
     # and the mask itself: only elements whose pre-activation is within rounding of zero may differ
     flips = (mask != (z64 > 0))
     assert np.abs(z64[flips]).max(initial=0.0) <= tol * np.abs(z64).max()
+
+
+@pytest.mark.parametrize("bn_before_act,pool_method", [(True, "interp"), (False, "maxval"), (False, "maxarea")])
+def test_unet_variants_vs_oracle_backed_run(bn_before_act, pool_method):
+    """The other branches of the model code the configs can select (my_models_graph.py:104-118, :401-412): batch norm
+    on either side of the activation (the conv then carries no bias and the activation is NOT fused when the norm sits
+    in between) and the max-value / max-area poolings - the same model object on the device and, with the fp64 oracle
+    behind the layers, on the CPU."""
+    import modules.my_models_graph as arch
+    from dsw_amd import functional
+    from _oracle_backend import OracleBackend
+
+    V = 768
+    tensor_info = {
+        "dim_order": {"dynamic": ["sample", "time", "node", "feature"]},
+        "input_n_feature": 6, "output_n_feature": 2, "input_n_time": 3, "output_n_time": 1,
+        "input_shape_info": {"dynamic": {"node": V}}, "output_shape_info": {"dynamic": {"node": V}},
+    }
+    torch.manual_seed(3)
+    model = arch.UNetSpherical(tensor_info, sampling="healpix", sampling_kwargs={"subdivisions": 8, "nest": True},
+                               kernel_size_conv=3, conv_type="graph", graph_type="knn", knn=8, pool_method=pool_method,
+                               batch_norm=True, batch_norm_before_activation=bn_before_act)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("rezero_weight"):
+                p.fill_(0.4)
+            elif n.endswith("bn.weight"):
+                p.fill_(0.8)       # (the last BN of a block starts at 0: give every branch a signal)
+    model.train()
+    x = torch.from_numpy(recipes.rand(71, (3, 3, V, 6)))
+    target = torch.from_numpy(recipes.rand(72, (3, 1, V, 2)))
+
+    def run(m, dev):
+        m.zero_grad(set_to_none=True)
+        y = m(x.to(dev))
+        loss = ((y - target.to(dev)) ** 2).mean()
+        loss.backward()
+        return y.detach().cpu(), {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None}
+
+    import copy
+    ref_model = copy.deepcopy(model)          # BatchNorm running statistics are updated by a forward: separate copies
+    functional.set_test_backend(OracleBackend())
+    try:
+        y_ref, g_ref = run(ref_model, "cpu")
+    finally:
+        functional.set_test_backend(None)
+    y_dev, g_dev = run(model.to(DEV), DEV)
+    assert set(g_dev) == set(g_ref)
+    if pool_method == "maxval":
+        # an arg-max is discontinuous: where two candidates tie to within fp32 rounding, the fp32 device run and the
+        # fp64-backed run may legitimately pick different cells; such flips are rare and local - bound their share
+        def close(a, b, tol):
+            a, b = a.double().numpy(), b.double().numpy()
+            return float(np.mean(np.abs(a - b) > tol * np.abs(b).max()))
+        assert close(y_dev, y_ref, 2e-5) <= 2e-3
+        for n in g_ref:
+            assert close(g_dev[n], g_ref[n], 2e-4) <= 2e-2, n
+    else:
+        assert orc.max_rel_err(y_dev, y_ref) <= 2e-5
+        for n in g_ref:
+            assert orc.max_rel_err(g_dev[n], g_ref[n]) <= 2e-4, n
