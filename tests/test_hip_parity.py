@@ -137,7 +137,17 @@ def test_unet_golden_g5():
 
     model, g, names = build_g5_model(DEV)
     assert model.conv1.convblock1.conv.laplacian.is_cuda
-    check_g5(model, g, names, device=DEV, tol=2e-5)
+    # measured on MI355X (round 2): output 5.9e-7, loss <1e-7, gradient fingerprints 1.2e-6 -> bound 5e-6 / 5e-5
+    errs = check_g5(model, g, names, device=DEV, tol=5e-6)
+    print("G5 on the device:", {k: "%.2e" % v for k, v in errs.items()})
+    try:
+        import json
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_fullsize.json")
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data["g5_unet_nside8_fp32"] = {k: float("%.3e" % v) for k, v in errs.items()}
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
 
 
 # ---------------------------------------------------------------------------------------------

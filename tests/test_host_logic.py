@@ -208,23 +208,30 @@ def build_g5_model(device="cpu"):
 
 
 def check_g5(model, g, names, device="cpu", tol=2e-5):
+    """Returns the measured errors {y, loss, grad_l2, grad_head, grad_dot} (all relative) after asserting the bounds:
+    ``tol`` on output and loss, ``10 * tol`` on the gradient fingerprints."""
     x = torch.from_numpy(recipes.rand(501, (2, 3, 768, 6))).to(device)
     target = torch.from_numpy(recipes.rand(502, (2, 1, 768, 2))).to(device)
     y = model(x)
     loss = ((y - target) ** 2).mean()
     loss.backward()
     assert y.shape == (2, 1, 768, 2)
-    assert orc.max_rel_err(y.detach().cpu(), g["y"]) < tol
-    assert abs(loss.item() - float(g["loss"][0])) < tol * max(1.0, float(g["loss"][0]))
     params = dict(model.named_parameters())
     probes = np.stack([recipes.grad_probe(i, params[n].grad.detach().cpu().numpy()) for i, n in enumerate(names)])
     ref = g["grad_probes"]
     scale = np.abs(ref[:, :1]) + 1e-12  # per-tensor gradient l2 norm
-    assert np.max(np.abs(probes[:, 0] - ref[:, 0]) / scale[:, 0]) < 10 * tol
-    assert np.max(np.abs(probes[:, 2:] - ref[:, 2:]) / scale) < 10 * tol
     # the dot-probe sums ~1e5 random-signed terms: compare against |g|*|r| ~ l2 * sqrt(n)
     n_el = np.array([params[n].numel() for n in names], dtype=np.float64)
-    assert np.max(np.abs(probes[:, 1] - ref[:, 1]) / (scale[:, 0] * np.sqrt(n_el))) < 10 * tol
+    errs = {
+        "y": orc.max_rel_err(y.detach().cpu(), g["y"]),
+        "loss": abs(loss.item() - float(g["loss"][0])) / max(1.0, float(g["loss"][0])),
+        "grad_l2": float(np.max(np.abs(probes[:, 0] - ref[:, 0]) / scale[:, 0])),
+        "grad_head": float(np.max(np.abs(probes[:, 2:] - ref[:, 2:]) / scale)),
+        "grad_dot": float(np.max(np.abs(probes[:, 1] - ref[:, 1]) / (scale[:, 0] * np.sqrt(n_el)))),
+    }
+    assert errs["y"] < tol and errs["loss"] < tol, errs
+    assert errs["grad_l2"] < 10 * tol and errs["grad_head"] < 10 * tol and errs["grad_dot"] < 10 * tol, errs
+    return errs
 
 
 def test_unet_matches_reference_fixture_on_cpu_wiring(oracle_backend):
