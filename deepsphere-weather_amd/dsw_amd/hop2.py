@@ -123,6 +123,8 @@ def build_hop2_plan(rowptr: np.ndarray, colind: np.ndarray, values: np.ndarray, 
             raise ValueError("tile neighbourhood exceeds 65535 rows; operator too dense for the fused path")
         lcol = pos[cols].astype(np.uint16)
         lrp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        order = _bank_friendly_order(lcol, lens)
+        lcol, idx = lcol[order], idx[order]
         pos[s2] = -1
         meta[t] = (s2_off, s1.size, s2.size, nnz_off, rp_off, 0)
         s2_chunks.append(s2.astype(np.int32))
@@ -138,6 +140,27 @@ def build_hop2_plan(rowptr: np.ndarray, colind: np.ndarray, values: np.ndarray, 
         tile_rows, meta, np.concatenate(s2_chunks), np.concatenate(rp_chunks), np.concatenate(col_chunks),
         np.concatenate(val_chunks), max_n1, max_n2, max_nnz, n, max_len,
     )
+
+
+def _bank_friendly_order(lcol: np.ndarray, lens: np.ndarray) -> np.ndarray:
+    """Permutation of one tile's local CSR entries (rows keep their extents) that removes most LDS bank conflicts
+    of the gather: a staged row is 128 bytes = one HALF of the 256-byte bank row, picked by the parity of its list
+    position, and ``ds_read_b128`` serves, in one cycle, the same 64-byte half of the entries that list rows
+    ``8m + {0, 3}`` (and ``{1, 2}``, ``{4, 7}``, ``{5, 6}``) gather at the same step - conflict-free exactly when the
+    two positions differ in parity.  So the entries of list row ``i`` alternate even / odd positions, starting with
+    parity ``(i >> 1) & 1`` (opposite for the two rows of every pair); the in-kernel padding (own position) has the
+    parity of ``i`` and is opposite within a pair as well.  Only the summation order inside a row changes."""
+    n1 = lens.shape[0]
+    rid = np.repeat(np.arange(n1), lens)
+    par = (lcol & 1).astype(np.int64)
+    first = par == ((rid >> 1) & 1)
+    key = rid * 2 + par
+    o = np.argsort(key, kind="stable")
+    ks = key[o]
+    rank = np.empty_like(rid)
+    rank[o] = np.arange(ks.size) - np.searchsorted(ks, ks, side="left")
+    slot = 2 * rank + (~first)
+    return np.lexsort((slot, rid))
 
 
 def emulate_hop2(plan: Hop2Plan, U, Z1, Z1b, Z2, a1, b1, d1, a2, b2, c2):

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Channel-mix GEMM alone (dsw_cheb_mix_fwd), HIP-event timed, for layer shapes given as N,Fin,Fout,K ...
+Prints us, fp32 TFLOP/s, fraction of the bf16 pipe (6 MFMA terms per product) and the HBM rate of the streamed bytes."""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(REPO, "deepsphere-weather_amd"), REPO]
+import torch
+from dsw_amd import _native
+
+
+def timeit(fn, n=30, w=5):
+    for _ in range(w): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / n
+
+
+def main():
+    lib = _native.load()
+    shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [
+        (98304, 256, 128, 3), (98304, 128, 256, 3), (98304, 64, 128, 3), (24576, 512, 256, 3), (24576, 192, 256, 3),
+        (6144, 512, 256, 3), (6144, 256, 512, 3), (786432, 32, 64, 3)]
+    st = torch.cuda.current_stream().cuda_stream
+    for N, Fin, Fout, K in shapes:
+        x = torch.randn(N, Fin, device="cuda")
+        T = torch.randn(max(K - 1, 1), N, Fin, device="cuda")
+        w = torch.randn(Fin, K, Fout, device="cuda") * 0.05
+        b = torch.randn(Fout, device="cuda")
+        y = torch.empty(N, Fout, device="cuda")
+        f = lambda: lib.dsw_cheb_mix_fwd(x.data_ptr(), T.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, Fin, Fout, K, 0, st)
+        assert f() == 0
+        us = timeit(f)
+        ref = (torch.cat([x] + [T[k] for k in range(K - 1)], 1).double() @ w.permute(1, 0, 2).reshape(K * Fin, Fout).double() + b.double())
+        err = ((y.double() - ref).abs().max() / ref.abs().max()).item()
+        fl = 2.0 * N * Fin * K * Fout
+        by = (N * Fin * K + N * Fout) * 4
+        print("N=%7d %4d->%4d K=%d  %8.1f us  %6.1f TF/s fp32  bf16-pipe %.3f  HBM %6.0f GB/s  err %.1e" % (
+            N, Fin, Fout, K, us, fl / us / 1e6, 6 * fl / us / 1e6 / 2500.0, by / us / 1e3, err))
+
+
+if __name__ == "__main__":
+    main()
