@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--torch-cat", action="store_true",
+                    help="unet: decoder concatenations through torch.cat instead of in-place buffers (A/B)")
     return ap.parse_args()
 
 
@@ -424,6 +426,9 @@ def main():
     torch.manual_seed(1234 + rank)
 
     if args.workload == "unet":
+        if args.torch_cat:
+            import modules.my_models_graph as _arch
+            _arch.UNetSpherical.concat_in_place = False
         model = make_unet(wl, args.knn if args.knn != 8 else 20, device)
         x = torch.randn(B, 3, V, 6, device=device)
         target = torch.randn(B, 1, V, 2, device=device)

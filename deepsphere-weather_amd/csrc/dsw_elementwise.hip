@@ -64,6 +64,27 @@ __global__ __launch_bounds__(EW_THREADS) void rezero_fwd_kernel(const void* c, c
         E::store1(y, i, fmaf(w, E::load1(c, i), E::load1(r, i)));
 }
 
+// same with a row stride on the output: y[row * ldy + j] = w * c[row * C + j] + r[row * C + j] - the block writes straight
+// into its half of the decoder's concatenation buffer (my_models_graph.py:528-545 builds that buffer with torch.cat)
+template <bool BF16>
+__global__ __launch_bounds__(EW_THREADS) void rezero_fwd_ld_kernel(const void* c, const void* r, const void* wp, void* y,
+                                                                   long rows, int cpr, long ldy) {
+    using E = Ew<BF16>;
+    constexpr int V = E::V;
+    const float w = E::load1(wp, 0);
+    const long nv = rows * cpr;
+    for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < nv; i += (long)gridDim.x * EW_THREADS) {
+        const long row = i / cpr;
+        const int j = (int)(i - row * cpr);
+        float a[V], b[V], o[V];
+        E::load(c, (size_t)i * V, a);
+        E::load(r, (size_t)i * V, b);
+#pragma unroll
+        for (int t = 0; t < V; ++t) o[t] = fmaf(w, a[t], b[t]);
+        E::store(y, (size_t)row * ldy + (size_t)j * V, o);
+    }
+}
+
 // grad_c = w * g; partial[block] = sum over the block's elements of g * c (fixed order -> reproducible)
 template <bool BF16>
 __global__ __launch_bounds__(EW_THREADS) void rezero_bwd_kernel(const void* g, const void* c, const void* wp, void* gc,
@@ -188,6 +209,25 @@ int dsw_rezero_residual_fwd(const void* c, const void* r, const void* w, void* y
                            (long)n, vec);
     else
         return DSW_ERR_BAD_DTYPE;
+    return dsw_check_launch();
+}
+
+int dsw_rezero_residual_fwd_ld(const void* c, const void* r, const void* w, void* y, int64_t rows, int64_t C, int64_t ldy,
+                               int dtype, dsw_stream_t stream) {
+    if (rows < 0 || C < 0 || ldy < C) return DSW_ERR_BAD_ARG;
+    if (rows == 0 || C == 0) return DSW_OK;
+    if (!c || !r || !w || !y) return DSW_ERR_BAD_ARG;
+    if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
+    const int V = dtype == DSW_BF16 ? 8 : 4;
+    if (C % V != 0 || ldy % V != 0 || !dsw_aligned16(c) || !dsw_aligned16(r) || !dsw_aligned16(y)) return DSW_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const int cpr = (int)(C / V);
+    if (dtype == DSW_F32)
+        hipLaunchKernelGGL(rezero_fwd_ld_kernel<false>, dim3(ew_blocks(rows * C, V)), dim3(EW_THREADS), 0, s, c, r, w, y,
+                           (long)rows, cpr, (long)ldy);
+    else
+        hipLaunchKernelGGL(rezero_fwd_ld_kernel<true>, dim3(ew_blocks(rows * C, V)), dim3(EW_THREADS), 0, s, c, r, w, y,
+                           (long)rows, cpr, (long)ldy);
     return dsw_check_launch();
 }
 

@@ -94,7 +94,9 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit(
     const int* __restrict__ rowptr, const int* __restrict__ colind, const float* __restrict__ vals,
     const void* __restrict__ X, void* Y, const void* Z, const void* Z2,
     float alpha, float beta, float gamma,
-    int v_out, int v_in, int C, int cpr, int B, long row_blocks, int xcd_swizzle) {
+    int v_out, int v_in, int C, int cpr, int B, long row_blocks, int xcd_swizzle, int ldx, int ldy) {
+    // ldx / ldy: elements between consecutive rows of X / Y (>= C: a channel slice of a wider node-major tensor, e.g.
+    // one half of the decoder's concatenation buffer); Z / Z2 are always dense [B, v_out, C]
     using V = Vec<BF16, VEC>;
     // XCD-aware block order: hardware block i runs on XCD i % 8 (each XCD has a private 4 MiB L2).
     // Remap so that every XCD walks ONE contiguous range of (batch group, row block) pairs: the
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit(
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[i][j] = 0.f;
 
-    const size_t xs = (size_t)v_in * C;  // sample stride of X
+    const size_t xs = (size_t)v_in * ldx;  // sample stride of X
     const int s = rowptr[row], e = rowptr[row + 1];
     int p = s;
     for (; p + 2 <= e; p += 2) {
@@ -131,8 +133,8 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit(
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int b = (b0 + i < B) ? b0 + i : B - 1;
-            V::load(X, (size_t)b * xs + (size_t)col0 * C + c0, x0[i]);
-            V::load(X, (size_t)b * xs + (size_t)col1 * C + c0, x1[i]);
+            V::load(X, (size_t)b * xs + (size_t)col0 * ldx + c0, x0[i]);
+            V::load(X, (size_t)b * xs + (size_t)col1 * ldx + c0, x1[i]);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i)
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit(
         for (int i = 0; i < NB; ++i) {
             const int b = (b0 + i < B) ? b0 + i : B - 1;
             float x0[VEC];
-            V::load(X, (size_t)b * xs + (size_t)col0 * C + c0, x0);
+            V::load(X, (size_t)b * xs + (size_t)col0 * ldx + c0, x0);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) acc[i][j] = fmaf(a0, x0[j], acc[i][j]);
         }
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit(
     for (int i = 0; i < NB; ++i) {
         if (b0 + i >= B) break;
         const size_t off = (size_t)(b0 + i) * ys + (size_t)row * C + c0;
+        const size_t offy = ((size_t)(b0 + i) * v_out + row) * (size_t)ldy + c0;
         float o[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o[j] = alpha * acc[i][j];
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit(
 #pragma unroll
             for (int j = 0; j < VEC; ++j) o[j] = fmaf(gamma, z[j], o[j]);
         }
-        if (xcd_swizzle & 4) V::store_nt(Y, off, o); else V::store(Y, off, o);
+        if (xcd_swizzle & 4) V::store_nt(Y, offy, o); else V::store(Y, offy, o);
     }
 }
 
@@ -283,7 +286,7 @@ int launch_tiled(const int* rowptr, const int* colind, const float* vals, const 
 template <bool BF16, int VEC, int NB>
 int launch_rowsplit(const int* rowptr, const int* colind, const float* vals, const void* X, void* Y,
                     const void* Z, const void* Z2, float alpha, float beta, float gamma, int v_out,
-                    int v_in, int C, int B, hipStream_t stream, int hints = 0) {
+                    int v_in, int C, int B, hipStream_t stream, int hints = 0, int ldx = 0, int ldy = 0) {
     const int cpr = C / VEC;
     const long threads = (long)v_out * cpr;
     static const char* bs_env = dsw_diag_env("DSW_SPMM_BLOCK");   // diagnostics: threads per block (64..1024)
@@ -295,29 +298,34 @@ int launch_rowsplit(const int* rowptr, const int* colind, const float* vals, con
     const int swz = sw ? atoi(sw) : (1 | (hints & 6));
     dim3 grid((unsigned)(row_blocks * bgroups));
     hipLaunchKernelGGL((spmm_csr_rowsplit<BF16, VEC, NB>), grid, dim3(bs), 0, stream, rowptr, colind,
-                       vals, X, Y, Z, Z2, alpha, beta, gamma, v_out, v_in, C, cpr, B, row_blocks, swz);
+                       vals, X, Y, Z, Z2, alpha, beta, gamma, v_out, v_in, C, cpr, B, row_blocks, swz, ldx > 0 ? ldx : C,
+                       ldy > 0 ? ldy : C);
     return dsw_check_launch();
 }
 
 }  // namespace
 
 // Internal C++ entry used by dsw_api.hip
-int dsw_spmm_launch(const int* rowptr, const int* colind, const float* vals, int64_t v_out, int64_t v_in,
-                    const void* X, void* Y, int64_t B, int64_t C, float alpha, const void* Z, float beta,
-                    const void* Z2, float gamma, int dtype, hipStream_t stream, int hints) {
+int dsw_spmm_launch_ld(const int* rowptr, const int* colind, const float* vals, int64_t v_out, int64_t v_in,
+                       const void* X, int64_t ldx_, void* Y, int64_t ldy_, int64_t B, int64_t C, float alpha, const void* Z,
+                       float beta, const void* Z2, float gamma, int dtype, hipStream_t stream, int hints) {
+    if (ldx_ < C || ldy_ < C || ldx_ > INT32_MAX || ldy_ > INT32_MAX) return DSW_ERR_BAD_ARG;
+    const int ldx = (int)ldx_, ldy = (int)ldy_;
+    const bool dense = ldx == C && ldy == C;
     if (v_out <= 0 || v_in <= 0 || B <= 0 || C <= 0) return (v_out == 0 || B == 0) ? DSW_OK : DSW_ERR_BAD_ARG;
     if (v_out > INT32_MAX || v_in > INT32_MAX || C > INT32_MAX || B > 65535 * 4) return DSW_ERR_BAD_ARG;
     if (Z == nullptr) beta = 0.f;
     if (Z2 == nullptr) gamma = 0.f;
+    const int vec_ = dtype == DSW_BF16 ? 8 : 4;
     const bool al = dsw_aligned16(X) && dsw_aligned16(Y) && (Z == nullptr || dsw_aligned16(Z)) &&
-                    (Z2 == nullptr || dsw_aligned16(Z2));
+                    (Z2 == nullptr || dsw_aligned16(Z2)) && ldx % vec_ == 0 && ldy % vec_ == 0;
     const int vo = (int)v_out, vi = (int)v_in, c = (int)C, b = (int)B;
     // kernel choice: LDS-tiled when a >=64-row tile of one sample fits 32 KiB and lanes divide evenly
     static const char* force = dsw_diag_env("DSW_SPMM_KERNEL");  // "rowsplit" | "tiled" (diagnostics only)
     const int es = dtype == DSW_BF16 ? 2 : 4;
     const int vec = dtype == DSW_BF16 ? 8 : 4;
     int tile_rows = 0;
-    if (al && vo == vi && c % vec == 0 && c / vec <= 256) {  // square operators only: tile rows == tile columns
+    if (dense && al && vo == vi && c % vec == 0 && c / vec <= 256) {  // square operators only: tile rows == tile columns
         static const char* tb = dsw_diag_env("DSW_SPMM_TILE_BYTES");
         const long tile_bytes = tb ? atol(tb) : 32768;
         long r = tile_bytes / ((long)c * es);
@@ -337,22 +345,29 @@ int dsw_spmm_launch(const int* rowptr, const int* colind, const float* vals, int
     const int nbf = nbs ? atoi(nbs) : 0;
     if (dtype == DSW_F32) {
         if (al && c % 4 == 0) {
-            if (nbf == 1) return launch_rowsplit<false, 4, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
-            if (nbf == 2) return launch_rowsplit<false, 4, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
-            if (b >= 4) return launch_rowsplit<false, 4, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
-            if (b >= 2) return launch_rowsplit<false, 4, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
-            return launch_rowsplit<false, 4, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
+            if (nbf == 1) return launch_rowsplit<false, 4, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
+            if (nbf == 2) return launch_rowsplit<false, 4, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
+            if (b >= 4) return launch_rowsplit<false, 4, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
+            if (b >= 2) return launch_rowsplit<false, 4, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
+            return launch_rowsplit<false, 4, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
         }
-        if (b >= 4) return launch_rowsplit<false, 1, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
-        return launch_rowsplit<false, 1, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
+        if (b >= 4) return launch_rowsplit<false, 1, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
+        return launch_rowsplit<false, 1, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
     }
     if (dtype == DSW_BF16) {
         if (al && c % 8 == 0) {
-            if (b >= 2) return launch_rowsplit<true, 8, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
-            return launch_rowsplit<true, 8, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
+            if (b >= 2) return launch_rowsplit<true, 8, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
+            return launch_rowsplit<true, 8, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
         }
-        if (b >= 4) return launch_rowsplit<true, 1, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
-        return launch_rowsplit<true, 1, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints);
+        if (b >= 4) return launch_rowsplit<true, 1, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
+        return launch_rowsplit<true, 1, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
     }
     return DSW_ERR_BAD_DTYPE;
+}
+
+int dsw_spmm_launch(const int* rowptr, const int* colind, const float* vals, int64_t v_out, int64_t v_in,
+                    const void* X, void* Y, int64_t B, int64_t C, float alpha, const void* Z, float beta,
+                    const void* Z2, float gamma, int dtype, hipStream_t stream, int hints) {
+    return dsw_spmm_launch_ld(rowptr, colind, vals, v_out, v_in, X, C, Y, C, B, C, alpha, Z, beta, Z2, gamma, dtype, stream,
+                              hints);
 }

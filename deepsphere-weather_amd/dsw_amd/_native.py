@@ -30,6 +30,10 @@ SIGNATURES = {
         _int,
         [_i32p, _i32p, _f32p, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _f32, _vp, _f32, _vp, _f32, _int, _vp],
     ),
+    "dsw_spmm_csr_ld": (
+        _int,
+        [_i32p, _i32p, _f32p, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _f32, _vp, _f32, _vp, _f32, _int, _vp],
+    ),
     "dsw_spmm2_fused": (
         _int,
         [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp],
@@ -43,6 +47,7 @@ SIGNATURES = {
     "dsw_cheb_mix_first": (_int, [_i64, _i64, _i64]),
     "dsw_rezero_residual_workspace_bytes": (_i64, []),
     "dsw_rezero_residual_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _vp]),
+    "dsw_rezero_residual_fwd_ld": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _vp]),
     "dsw_rezero_residual_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _int, _vp]),
     "dsw_maxval_pool_fwd": (_int, [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _int, _vp]),
     "dsw_maxval_pool_bwd": (_int, [_i32p, _i32p, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _int, _vp]),

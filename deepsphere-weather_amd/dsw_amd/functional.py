@@ -224,16 +224,26 @@ class _HipBackend:
     name = "hip"
 
     def spmm(self, op, x, alpha=1.0, z=None, beta=0.0, z2=None, gamma=0.0, out=None):
+        """``x`` / ``out``: dense ``[B, V, C]`` or row-strided channel slices of wider tensors (see ``row_stride``)."""
         lib = _native.load()
         B, v_in, C = x.shape
         assert v_in == op.shape[1]
         y = out if out is not None else torch.empty((B, op.shape[0], C), dtype=x.dtype, device=x.device)
+        ldx, ldy = row_stride(x), row_stride(y)
+        assert ldx is not None and ldy is not None and y.shape == (B, op.shape[0], C)
         with torch.cuda.device(x.device):
-            rc = lib.dsw_spmm_csr(
-                op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), op.shape[0], op.shape[1],
-                op.nnz, x.data_ptr(), y.data_ptr(), B, C, alpha, _ptr(z), beta, _ptr(z2), gamma,
-                _DTYPES[x.dtype], _stream(x),
-            )
+            if ldx == C and ldy == C:
+                rc = lib.dsw_spmm_csr(
+                    op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), op.shape[0], op.shape[1],
+                    op.nnz, x.data_ptr(), y.data_ptr(), B, C, alpha, _ptr(z), beta, _ptr(z2), gamma,
+                    _DTYPES[x.dtype], _stream(x),
+                )
+            else:
+                rc = lib.dsw_spmm_csr_ld(
+                    op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), op.shape[0], op.shape[1],
+                    op.nnz, x.data_ptr(), ldx, y.data_ptr(), ldy, B, C, alpha, _ptr(z), beta, _ptr(z2), gamma,
+                    _DTYPES[x.dtype], _stream(x),
+                )
         _native.check(rc, "dsw_spmm_csr")
         return y
 
@@ -310,8 +320,15 @@ class _HipBackend:
         _native.check(rc, "dsw_relu_bwd")
         return out
 
-    def rezero_fwd(self, c, r, w):
+    def rezero_fwd(self, c, r, w, out=None):
         lib = _native.load()
+        if out is not None:    # a row-strided destination: the block's half of a concatenation buffer
+            C = c.shape[-1]
+            with torch.cuda.device(c.device):
+                rc = lib.dsw_rezero_residual_fwd_ld(c.data_ptr(), r.data_ptr(), w.data_ptr(), out.data_ptr(),
+                                                    c.numel() // C, C, row_stride(out), _DTYPES[c.dtype], _stream(c))
+            _native.check(rc, "dsw_rezero_residual_fwd_ld")
+            return out
         y = torch.empty_like(c)
         with torch.cuda.device(c.device):
             rc = lib.dsw_rezero_residual_fwd(c.data_ptr(), r.data_ptr(), w.data_ptr(), y.data_ptr(), c.numel(),
@@ -448,14 +465,47 @@ class _ChebConvFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+class _Out:
+    """Carries a preallocated destination tensor into an autograd Function WITHOUT making it an input of the node."""
+
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
+def row_stride(t: torch.Tensor):
+    """Elements between consecutive node rows of a ``[B, V, C]`` tensor whose rows are contiguous and whose samples follow
+    each other without a gap (a dense tensor, or a channel slice ``buf[..., a:b]`` of a dense wider one); else None."""
+    if t.dim() != 3:
+        return None
+    B, V, C = t.shape
+    sb, sv, sc = t.stride()
+    if C == 0 or V == 0 or B == 0:
+        return C
+    if sc != 1 and C > 1:
+        return None
+    ld = sv if V > 1 else max(C, sb if B > 1 else C)
+    if ld < C or (B > 1 and sb != V * ld):
+        return None
+    return ld
+
+
+def _rows_ok(t: torch.Tensor) -> bool:
+    """Row-strided and 16-byte aligned (what the strided kernel entry points take)."""
+    ld = row_stride(t)
+    es = t.element_size()
+    return ld is not None and (ld * es) % 16 == 0 and (t.shape[-1] * es) % 16 == 0 and t.data_ptr() % 16 == 0
+
+
 class _RezeroResidualFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, c, r, w):
+    def forward(ctx, c, r, w, out):
         be = _backend_for(c)
         cc, rc = c.contiguous(), r.contiguous()
         ctx.save_for_backward(cc, w)
         ctx.be = be
-        return be.rezero_fwd(cc, rc, w)
+        return be.rezero_fwd(cc, rc, w, out=out.t if out is not None else None)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -463,21 +513,36 @@ class _RezeroResidualFn(torch.autograd.Function):
         c, w = ctx.saved_tensors
         g = g.contiguous()
         gc, gw = ctx.be.rezero_bwd(g, c, w, ctx.needs_input_grad[0])
-        return gc, (g if ctx.needs_input_grad[1] else None), (gw if ctx.needs_input_grad[2] else None)
+        return gc, (g if ctx.needs_input_grad[1] else None), (gw if ctx.needs_input_grad[2] else None), None
 
 
 class _RemapFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, op):
+    def forward(ctx, x, op, out):
         be = _backend_for(x)
         ctx.op = op
         ctx.be = be
-        return be.spmm(op, x.contiguous())
+        return be.spmm(op, x if _rows_ok(x) else x.contiguous(), out=out.t if out is not None else None)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
-        return ctx.be.spmm(ctx.op.transpose(), dy.contiguous()), None
+        return ctx.be.spmm(ctx.op.transpose(), dy if _rows_ok(dy) else dy.contiguous()), None, None
+
+
+class _ConcatInPlaceFn(torch.autograd.Function):
+    """``torch.cat((left, right), dim=2)`` when ``left`` and ``right`` already ARE the two channel slices of ``buf``:
+    no data moves forward, backward hands out the two slices of the gradient."""
+
+    @staticmethod
+    def forward(ctx, left, right, buf):
+        ctx.split = left.shape[-1]
+        return buf.t
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        return g[..., :ctx.split], g[..., ctx.split:], None
 
 
 class _MaxValPoolFn(torch.autograd.Function):
@@ -572,23 +637,87 @@ def dense_mix(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
     return y.reshape(*lead, weight.shape[1])
 
 
-def rezero_residual(c: torch.Tensor, r: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+def _check_out(out, shape, like):
+    if out is None:
+        return None
+    if tuple(out.shape) != tuple(shape) or out.dtype != like.dtype or out.device != like.device or not _rows_ok(out):
+        raise ValueError("`out` must be a 16-byte aligned [B, V, C] channel slice (or dense tensor) of the result's shape, "
+                         "dtype and device")
+    return _Out(out)
+
+
+def rezero_residual(c: torch.Tensor, r: torch.Tensor, w: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
     """``w * c + r`` with ``w`` a one-element tensor (the ReZero parameter): the epilogue of the residual block
-    (my_models_graph.py:211-215) in one pass forward and one pass + a tiny reduction backward."""
+    (my_models_graph.py:211-215) in one pass forward and one pass + a tiny reduction backward.  ``out``: an optional
+    preallocated destination (e.g. the block's channel slice of a concatenation buffer, see ``skip_slot``)."""
     if c.shape != r.shape or w.numel() != 1:
         raise ValueError("expected c and r of one shape and a one-element w")
     _check_dtype(c, r, w)
-    return _RezeroResidualFn.apply(c, r, w)
+    return _RezeroResidualFn.apply(c, r, w, _check_out(out, c.shape, c))
 
 
-def sparse_remap(op: CsrOperator, x: torch.Tensor) -> torch.Tensor:
-    """``Y[b, d, f] = sum_v M[d, v] X[b, v, f]`` (pooling / unpooling), output contiguous [B, Vd, F]."""
+def sparse_remap(op: CsrOperator, x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """``Y[b, d, f] = sum_v M[d, v] X[b, v, f]`` (pooling / unpooling), output contiguous [B, Vd, F] - or written into
+    ``out``, a preallocated channel slice of a wider tensor.  ``x`` may itself be such a slice (no copy is made)."""
     if x.dim() != 3:
         raise ValueError("expected input [B, V, F]")
     if x.shape[1] != op.shape[1]:
         raise ValueError(f"remap matrix has {op.shape[1]} source nodes, input has {x.shape[1]}")
     _check_dtype(x)
-    return _RemapFn.apply(x, op)
+    return _RemapFn.apply(x, op, _check_out(out, (x.shape[0], op.shape[0], x.shape[2]), x))
+
+
+def _alias(t: torch.Tensor, offset: int, size, stride) -> torch.Tensor:
+    """A tensor over the same storage as ``t`` that autograd does NOT treat as a view of it (no shared version counter,
+    no base): the slices of a concatenation buffer are written by different graph nodes, which the view + in-place
+    checks of autograd would otherwise refuse."""
+    return torch.empty(0, dtype=t.dtype, device=t.device).set_(t.untyped_storage(), offset, size, stride)
+
+
+def skip_slot(like: torch.Tensor, n_nodes: int, width_left: int, width_skip: int):
+    """Channel slice ``[..., width_left:]`` of a fresh ``[B, n_nodes, width_left + width_skip]`` buffer: the place an
+    encoder block writes its output to (``ResBlock(x, out=slot)``) so that the decoder's
+    ``torch.cat((unpooled, skip), dim=2)`` (my_models_graph.py:528-545) needs no copy - the unpooling later fills
+    ``[..., :width_left]`` of the same buffer (``concat_in_place``).  None when the slices would not be 16-byte aligned."""
+    es = like.element_size()
+    if (width_left * es) % 16 or (width_skip * es) % 16:
+        return None
+    width = width_left + width_skip
+    buf = like.new_empty((like.shape[0], n_nodes, width))
+    return _alias(buf, width_left, (like.shape[0], n_nodes, width_skip), (n_nodes * width, width, 1))
+
+
+def skip_buffer(skip: torch.Tensor, width_left: int):
+    """The ``[B, V, width_left + C]`` buffer whose right-hand channel slice ``skip`` is (``skip_slot``), or None when
+    ``skip`` is an ordinary tensor, or when the buffer was already completed once (a second concatenation with the same
+    skip tensor must not overwrite the first one's left half: it takes the copying path)."""
+    if skip.dim() != 3 or getattr(skip, "_dsw_concat_done", False):
+        return None
+    B, V, C = skip.shape
+    width = width_left + C
+    if width_left <= 0 or skip.stride() != (V * width, width, 1) or skip.storage_offset() != width_left:
+        return None
+    if skip.untyped_storage().nbytes() < B * V * width * skip.element_size():
+        return None
+    return _alias(skip, 0, (B, V, width), (V * width, width, 1))
+
+
+def left_slot(buf: torch.Tensor, width_left: int) -> torch.Tensor:
+    """Channel slice ``[..., :width_left]`` of a concatenation buffer, as a destination for the unpooling."""
+    B, V, width = buf.shape
+    return _alias(buf, 0, (B, V, width_left), (V * width, width, 1))
+
+
+def concat_in_place(left: torch.Tensor, skip: torch.Tensor, buf: torch.Tensor) -> torch.Tensor:
+    """``torch.cat((left, skip), dim=2)`` for ``left = buf[..., :w]`` (just written by the unpooling) and
+    ``skip = buf[..., w:]``: returns ``buf`` with the autograd edges of a concatenation."""
+    w = left.shape[-1]
+    es = buf.element_size()
+    if (left.data_ptr() != buf.data_ptr() or skip.data_ptr() != buf.data_ptr() + w * es
+            or left.stride() != buf.stride() or skip.stride() != buf.stride()):
+        raise ValueError("left / skip are not the two channel slices of buf")
+    skip._dsw_concat_done = True
+    return _ConcatInPlaceFn.apply(left, skip, _Out(buf))
 
 
 def cheb_basis(op: CsrOperator, x: torch.Tensor, K: int) -> torch.Tensor:

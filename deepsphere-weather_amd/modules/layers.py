@@ -269,13 +269,15 @@ class RemapBlock(_Fp32OperatorMixin, torch.nn.Module):
     """
 
     _operator_buffers = ("remap_matrix",)
+    supports_out = True    # forward(..., out=slice) writes into a preallocated channel slice (concat-free decoder)
 
     def __init__(self, remap_matrix):
         super().__init__()
         self.register_buffer("remap_matrix", self.process_remap_matrix(remap_matrix))
 
-    def forward(self, x, *args, **kwargs):
-        return _F.sparse_remap(_F.get_operator(self.remap_matrix), x)
+    def forward(self, x, *args, out=None, **kwargs):
+        """``out`` (extension): a preallocated ``[B, V_dst, F]`` channel slice of a wider tensor to write into."""
+        return _F.sparse_remap(_F.get_operator(self.remap_matrix), x, out=out)
 
     def process_remap_matrix(self, mat):
         return convert_to_torch_sparse(mat)
@@ -336,6 +338,8 @@ class GeneralMaxValPool(RemapBlock):
     cell per output element) - the same information as the reference's ``[2, B*F*Vd]`` int64 tensor at a sixteenth of
     the size; :meth:`reference_index` converts, and :class:`GeneralMaxValUnpool` accepts either form."""
 
+    supports_out = False
+
     def forward(self, x, *args, **kwargs):
         return _F.maxval_pool(_F.get_operator(self.remap_matrix), x)
 
@@ -347,6 +351,8 @@ class GeneralMaxValPool(RemapBlock):
 class GeneralMaxValUnpool(RemapBlock):
     """Max-value unpooling: coarse values go back to the fine cells they were pooled from, zeros elsewhere
     (reference ``layers.py:1082-1103``; only the SHAPE of ``remap_matrix`` is used, as in the reference)."""
+
+    supports_out = False
 
     def forward(self, x, index, *args, **kwargs):
         B, D, F_ = x.shape

@@ -121,14 +121,16 @@ class ResBlock(torch.nn.Module):
             torch.nn.init.constant_(last.bn.weight, 0)
             torch.nn.init.constant_(last.bn.bias, 0)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """``out`` (extension): a preallocated channel slice to write the block's output into (the encoder blocks of the
+        U-Net write straight into the decoder's concatenation buffer, ``dsw_functional.skip_slot``)."""
         y = x
         for name in self.conv_names_list:
             y = getattr(self, name)(y)
         if self.rezero:   # rezero_weight * y + residual in one pass (the reference: in-place mul, then in-place add)
-            return dsw_functional.rezero_residual(y, self.res_connection(x), self.rezero_weight)
+            return dsw_functional.rezero_residual(y, self.res_connection(x), self.rezero_weight, out=out)
         y += self.res_connection(x)
-        return y
+        return y if out is None else out.copy_(y)
 
 
 # (attribute, input width, output widths, level) of the six residual blocks; "in" / "out" stand for the model's
@@ -225,18 +227,44 @@ class UNetSpherical(UNet, torch.nn.Module):
         x_last_timestep = x[:, -1, :, -2:].unsqueeze(dim=1)
         order = [self.dim_names.index(d) for d in _CANONICAL_DIMS]
         x = x.permute(*order).reshape(batch, self.input_n_node, self.input_channels)
-        x_enc1 = self.conv1(x)
+        # the skip tensors are born inside the decoder's concatenation buffers (their right-hand channel slice; the
+        # unpooling fills the left one in `decode`): no `torch.cat` copy forward, no slice copies backward
+        x_enc1 = self.conv1(x, out=self._skip_slot(x, self.unpool1, self.uconv1, self.conv1))
         x_enc2_ini, idx1 = self.pool1(x_enc1)
-        x_enc2 = self.conv2(x_enc2_ini)
+        x_enc2 = self.conv2(x_enc2_ini, out=self._skip_slot(x_enc2_ini, self.unpool2, self.uconv2, self.conv2))
         x_enc3_ini, idx2 = self.pool2(x_enc2)
         x_enc3 = self.conv3(x_enc3_ini)
         return x_enc3, x_enc2, x_enc1, idx2, idx1, x_last_timestep
 
+    concat_in_place = True   # False: skip tensors are ordinary tensors and the decoder calls torch.cat (A/B runs)
+
+    @classmethod
+    def _skip_slot(cls, x, unpool, decoder_block, encoder_block):
+        """Where `encoder_block` should write: the right-hand slice of the buffer `decoder_block` will read (None: plain
+        tensor + `torch.cat`, e.g. for unpooling layers that cannot write into a slice)."""
+        if not (cls.concat_in_place and getattr(unpool, "supports_out", False)):
+            return None
+        width_in = getattr(decoder_block, decoder_block.conv_names_list[0]).conv.in_channels
+        width_skip = getattr(encoder_block, encoder_block.conv_names_list[-1]).conv.out_channels
+        if width_in <= width_skip:
+            return None
+        return dsw_functional.skip_slot(x, x.shape[1], width_in - width_skip, width_skip)
+
+    @staticmethod
+    def _unpool_concat(unpool, x, idx, skip):
+        """`torch.cat((unpool(x, idx), skip), dim=2)` (my_models_graph.py:528-545), without the copy when `skip` lives
+        in a concatenation buffer."""
+        if getattr(unpool, "supports_out", False):
+            width_left = x.shape[2]
+            buf = dsw_functional.skip_buffer(skip, width_left)
+            if buf is not None:
+                left = unpool(x, idx, out=dsw_functional.left_slot(buf, width_left))
+                return dsw_functional.concat_in_place(left, skip, buf)
+        return torch.cat((unpool(x, idx), skip), dim=2)
+
     def decode(self, x_enc3, x_enc2, x_enc1, idx2, idx1, x_last_timestep):
-        x = self.unpool2(x_enc3, idx2)
-        x = self.uconv2(torch.cat((x, x_enc2), dim=2))
-        x = self.unpool1(x, idx1)
-        x = self.uconv1(torch.cat((x, x_enc1), dim=2))
+        x = self.uconv2(self._unpool_concat(self.unpool2, x_enc3, idx2, x_enc2))
+        x = self.uconv1(self._unpool_concat(self.unpool1, x, idx1, x_enc1))
         x = self.uconv1_final(x)
         batch = x.shape[0]
         x = x.reshape(batch, self.output_n_node, self.output_n_time, self.output_n_feature)

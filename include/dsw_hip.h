@@ -74,6 +74,15 @@ int dsw_spmm_csr(const int32_t* rowptr, const int32_t* colind, const float* vals
                  float alpha, const void* Z, float beta, const void* Z2, float gamma,
                  int dtype, dsw_stream_t stream);
 
+/* The same product on channel SLICES of wider node-major tensors: ldx / ldy = elements between consecutive rows of
+ * X / Y (>= C; Z and Z2 stay dense [B, v_out, C]).  The U-Net decoder's `torch.cat((unpooled, skip), dim=2)`
+ * (my_models_graph.py:528-545) disappears with it: the unpooling writes the left half of the concatenation buffer
+ * (ldy = its width), the encoder block wrote the right half (dsw_rezero_residual_fwd_ld), the pooling reads that half
+ * (ldx), and the backward of the unpooling reads its half of the buffer's gradient (ldx). */
+int dsw_spmm_csr_ld(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t v_out, int64_t v_in,
+                    int64_t nnz, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t B, int64_t C, float alpha,
+                    const void* Z, float beta, const void* Z2, float gamma, int dtype, dsw_stream_t stream);
+
 /* Two applications of one square operator A (V x V) in a single launch, per sample:
  *     Y1 = a1 * (A U)  + b1 * Z1 + d1 * Z1b
  *     Y2 = a2 * (A Y1) + b2 * U  + c2 * Z2
@@ -174,6 +183,10 @@ int dsw_rezero_residual_fwd(const void* c, const void* r, const void* w, void* y
                             dsw_stream_t stream);
 int dsw_rezero_residual_bwd(const void* g, const void* c, const void* w, void* grad_c, void* grad_w,
                             void* workspace, int64_t workspace_bytes, int64_t n, int dtype, dsw_stream_t stream);
+/* forward with a row stride on the output: y[row * ldy + j] = w * c[row * C + j] + r[row * C + j] (rows x C dense inputs,
+ * ldy >= C elements; C, ldy multiples of 16 bytes and 16-byte aligned pointers, else DSW_ERR_ALIGN). */
+int dsw_rezero_residual_fwd_ld(const void* c, const void* r, const void* w, void* y, int64_t rows, int64_t C, int64_t ldy,
+                               int dtype, dsw_stream_t stream);
 
 /* Max-value pooling over a sparse remap matrix (layers.py:1040-1079, GeneralMaxValPool.forward: the Python Counter
  * loop + torch.gather / argmax per coarse row):  for every sample b, coarse row d, channel f

@@ -21,7 +21,8 @@ class OracleBackend:
             y = y + beta * z.detach().double().numpy()
         if z2 is not None:
             y = y + gamma * z2.detach().double().numpy()
-        return torch.from_numpy(y).to(x.dtype)
+        y = torch.from_numpy(y).to(x.dtype)
+        return y if out is None else out.copy_(y)
 
     def cheb_basis(self, op, x, K):
         rp, ci, va = _csr_np(op)
@@ -58,8 +59,9 @@ class OracleBackend:
             torch.from_numpy(db).to(w.dtype) if need_db else None,
         )
 
-    def rezero_fwd(self, c, r, w):
-        return (w.double() * c.double() + r.double()).to(c.dtype)
+    def rezero_fwd(self, c, r, w, out=None):
+        y = (w.double() * c.double() + r.double()).to(c.dtype)
+        return y if out is None else out.copy_(y)
 
     def rezero_bwd(self, g, c, w, need_c):
         gc = (w.double() * g.double()).to(g.dtype) if need_c else None

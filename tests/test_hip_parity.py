@@ -822,3 +822,25 @@ def test_unet_variants_vs_oracle_backed_run(bn_before_act, pool_method):
         assert orc.max_rel_err(y_dev, y_ref) <= 2e-5
         for n in g_ref:
             assert orc.max_rel_err(g_dev[n], g_ref[n]) <= 2e-4, n
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_concat_in_place_strided_kernels(dt):
+    """dsw_spmm_csr_ld / dsw_rezero_residual_fwd_ld behind the decoder's copy-free concatenation."""
+    from test_host_logic import check_concat_in_place
+
+    check_concat_in_place(DEV, dt, TOL_F64 if dt == torch.float32 else TOL_BF16)
+
+
+def test_strided_entry_points_reject_bad_strides():
+    from dsw_amd import functional as F_, _native
+
+    lib = _native.load()
+    x = torch.randn(2, 8, 8, device=DEV)
+    y = torch.empty(2, 8, 8, device=DEV)
+    w = torch.ones(1, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.dsw_rezero_residual_fwd_ld(x.data_ptr(), x.data_ptr(), w.data_ptr(), y.data_ptr(), 16, 8, 4, 0, st) == -1
+    assert lib.dsw_rezero_residual_fwd_ld(x.data_ptr(), x.data_ptr(), w.data_ptr(), y.data_ptr(), 16, 6, 6, 0, st) == -5
+    with pytest.raises(ValueError):
+        F_.rezero_residual(x, x, w, out=torch.empty(2, 8, 9, device=DEV)[..., 1:])   # misaligned slice

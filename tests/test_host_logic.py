@@ -491,3 +491,81 @@ def test_ar_training_steps_match_reference_fixture_on_cpu_wiring(oracle_backend)
     trainer, g, names = build_g9_trainer()
     assert trainer.launch == "eager"
     check_g9(trainer, g, names)
+
+
+def check_concat_in_place(device, dtype=torch.float32, tol=2e-6):
+    """Decoder concatenation without the copy: an encoder-side `rezero_residual(..., out=slot)` and an
+    unpooling `sparse_remap(..., out=left)` fill the two channel slices of one buffer, a pooling reads the strided
+    slice; values and every gradient against the plain `torch.cat` formulation in fp64."""
+    import scipy.sparse as sp
+    from dsw_amd import functional as F_
+
+    rng = np.random.default_rng(31)
+    B, Vf, Vc, c_up, c_skip = 3, 48, 12, 8, 16
+    up = sp.random(Vf, Vc, density=0.3, random_state=5, format="csr", dtype=np.float64) + sp.eye(Vf, Vc, format="csr")
+    down = sp.random(Vc, Vf, density=0.2, random_state=6, format="csr", dtype=np.float64) + sp.eye(Vc, Vf, format="csr")
+
+    def op_of(m):
+        m = m.tocoo()
+        t = torch.sparse_coo_tensor(np.stack([m.row, m.col]), m.data.astype(np.float32), m.shape).coalesce()
+        return F_.get_operator(t.to(device))
+
+    op_up, op_down = op_of(up), op_of(down)
+    leaves64 = {k: torch.from_numpy(rng.standard_normal(s)) for k, s in
+                (("c", (B, Vf, c_skip)), ("r", (B, Vf, c_skip)), ("xc", (B, Vc, c_up)))}
+    w64 = torch.tensor([0.4], dtype=torch.float64)
+    gcat64 = torch.from_numpy(rng.standard_normal((B, Vf, c_up + c_skip)))
+    gpool64 = torch.from_numpy(rng.standard_normal((B, Vc, c_skip)))
+
+    def run(t_dtype, dev, in_place):
+        lv = {k: v.to(t_dtype).to(dev).requires_grad_(True) for k, v in leaves64.items()}
+        w = w64.to(t_dtype).to(dev).requires_grad_(True)
+        if in_place:
+            slot = F_.skip_slot(lv["c"], Vf, c_up, c_skip)
+            assert slot is not None and F_.row_stride(slot) == c_up + c_skip
+            skip = F_.rezero_residual(lv["c"], lv["r"], w, out=slot)
+            pooled = F_.sparse_remap(op_down, skip)                       # reads the strided slice
+            buf = F_.skip_buffer(skip, c_up)
+            assert buf is not None and buf.shape == (B, Vf, c_up + c_skip)
+            left = F_.sparse_remap(op_up, lv["xc"], out=F_.left_slot(buf, c_up))
+            cat = F_.concat_in_place(left, skip, buf)
+            assert cat.data_ptr() == buf.data_ptr() and F_.skip_buffer(skip, c_up) is None   # one completion only
+        else:
+            skip = w * lv["c"] + lv["r"]
+            U = torch.from_numpy(up.toarray()).to(t_dtype).to(dev)
+            D = torch.from_numpy(down.toarray()).to(t_dtype).to(dev)
+            pooled = torch.einsum("dv,bvf->bdf", D, skip)
+            cat = torch.cat((torch.einsum("dv,bvf->bdf", U, lv["xc"]), skip), dim=2)
+        loss = (cat * gcat64.to(t_dtype).to(dev)).sum() + (pooled * gpool64.to(t_dtype).to(dev)).sum()
+        loss.backward()
+        return cat.detach(), pooled.detach(), {k: v.grad for k, v in lv.items()}, w.grad
+
+    cat, pooled, grads, gw = run(dtype, device, True)
+    cat_r, pooled_r, grads_r, gw_r = run(torch.float64, "cpu", False)
+    assert orc.max_rel_err(cat, cat_r.numpy()) <= tol
+    assert orc.max_rel_err(pooled, pooled_r.numpy()) <= tol
+    for k in grads:
+        assert orc.max_rel_err(grads[k], grads_r[k].numpy()) <= tol, k
+    assert abs(float(gw) - float(gw_r)) <= 50 * tol * max(1.0, abs(float(gw_r)))
+
+
+def test_concat_in_place_cpu_wiring(oracle_backend):
+    check_concat_in_place("cpu")
+
+
+def test_skip_slot_is_used_by_the_unet_and_only_once(oracle_backend):
+    """encode() hands out skip tensors that live in the concatenation buffers; a SECOND decode of the same encodings must
+    not overwrite the first one's buffer (it takes the copying path) and gives the same values."""
+    from dsw_amd import functional as F_
+    model, g, names = build_g5_model("cpu")
+    x = torch.from_numpy(recipes.rand(501, (2, 3, 768, 6)))
+    enc = model.encode(x)
+    x_enc2, x_enc1 = enc[1], enc[2]
+    assert F_.skip_buffer(x_enc1, model.uconv1.convblock1.conv.in_channels - x_enc1.shape[2]) is not None
+    assert F_.skip_buffer(x_enc2, model.uconv2.convblock1.conv.in_channels - x_enc2.shape[2]) is not None
+    y1 = model.decode(*enc)
+    keep = y1.detach().clone()
+    assert F_.skip_buffer(x_enc1, model.uconv1.convblock1.conv.in_channels - x_enc1.shape[2]) is None
+    y2 = model.decode(*enc)
+    assert torch.equal(y1.detach(), keep)
+    assert orc.max_rel_err(y2.detach(), keep.numpy()) <= 1e-6
