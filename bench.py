@@ -411,7 +411,7 @@ def cpu_baseline_c5(model, wl, V):
 def main():
     args = parse()
     from dsw_amd import _native
-    from dsw_amd.parallel import FlatGradAllReduce, init_from_env
+    from dsw_amd.parallel import GradBucket, init_from_env
 
     rank, world, local = init_from_env()
     assert torch.cuda.is_available(), "bench.py measures the HIP path; a ROCm device is required"
@@ -435,7 +435,7 @@ def main():
         lap = None
 
         def step():
-            model.zero_grad(set_to_none=True)
+            zero_grads()
             loss = ((model(x) - target) ** 2).mean()
             loss.backward()
     else:
@@ -447,11 +447,20 @@ def main():
         gy = torch.randn(B, V, wl["fout"], device=device, dtype=dtype)
 
         def step():
-            model.zero_grad(set_to_none=True)
+            zero_grads()
             x.grad = None
             model(x).backward(gy)
 
-    sync_grads = FlatGradAllReduce(model.parameters())
+    # N > 1: the parameter gradients live in one flat bucket (no pack / unpack copies around the collective); the step is
+    # replayed from a HIP graph, so the bucket's chunks are all-reduced right after the replay
+    bucket = GradBucket(model.parameters(), overlap=False, attach=False)
+    if bucket.active():
+        bucket.attach()
+        zero_grads = bucket.zero
+    else:
+        def zero_grads():
+            model.zero_grad(set_to_none=True)
+    sync_grads = bucket.finish
 
     # The step is ~8 back-to-back kernels of 80-120 us each; launched eagerly from Python the GPU idles ~5 us between
     # them.  Capture one fwd+bwd into a HIP graph and replay it (same kernels, same work, same buffers); the gradient

@@ -81,44 +81,139 @@ def broadcast_module_state(module, src: int = 0, group=None):
     return module
 
 
-class FlatGradAllReduce:
-    """Average the gradients of ``params`` across ranks with a single flat-bucket all-reduce."""
+class GradBucket:
+    """The parameter gradients of one replica as ONE flat HBM buffer, averaged across ranks in place.
 
-    def __init__(self, params, group=None):
+    * ``attach()`` (default) makes every ``p.grad`` a view of the bucket: backward accumulates straight into it, the
+      collective runs on it, the optimizer reads it - no pack / unpack copies (the whole UNetSpherical: 7 MB each way).
+      ``zero()`` replaces ``optimizer.zero_grad()`` (one memset; ``set_to_none`` would detach the views).
+    * The bucket is laid out in REVERSE registration order - the order in which backward finishes the gradients - and cut
+      into chunks of ``chunk_bytes``.  With ``overlap`` a chunk's all-reduce is enqueued (``async_op``) by the
+      post-accumulate hook of the last of its parameters to become ready, i.e. it travels over xGMI while backward is
+      still computing the earlier layers; ``finish()`` enqueues whatever is left and waits.  xGMI is point-to-point and
+      the payload small, so a few MB-sized chunks (not per-tensor collectives) keep the collectives bandwidth- rather
+      than latency-bound.
+    * Hooks only fire when autograd runs: a step replayed from a HIP graph calls ``finish()`` after the replay and
+      the chunks go out back to back (``capturing`` suppresses launches while the graph is being recorded).
+    """
+
+    def __init__(self, params, group=None, chunk_bytes=2 << 20, overlap=True, attach=True):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
-        n = sum(p.numel() for p in self.params)
-        ref = self.params[0]
+        self.overlap = overlap
+        self.capturing = False
+        order = list(reversed(self.params))
+        ref = order[0]
+        n = sum(p.numel() for p in order)
         self.bucket = torch.zeros(n, dtype=ref.dtype, device=ref.device)
-        self.views = []
-        off = 0
-        for p in self.params:
-            self.views.append(self.bucket[off : off + p.numel()].view_as(p))
+        self.views, self.chunk_of, self.chunks = {}, {}, []
+        off = start = 0
+        members = []
+        for p in order:
+            self.views[p] = self.bucket[off:off + p.numel()].view_as(p)
             off += p.numel()
+            members.append(p)
+            if (off - start) * self.bucket.element_size() >= chunk_bytes:
+                self.chunks.append((start, off, members))
+                start, members = off, []
+        if members:
+            self.chunks.append((start, off, members))
+        for ci, (_, _, ps) in enumerate(self.chunks):
+            for p in ps:
+                self.chunk_of[p] = ci
+        self.attached = False
+        self._pending = [len(ps) for _, _, ps in self.chunks]
+        self._launched = [False] * len(self.chunks)
+        self._works = []
+        self._hooks = []
+        if attach:
+            self.attach()
 
-    def __call__(self):
-        if not dist.is_initialized() or (dist.get_world_size(self.group) == 1
-                                         and os.environ.get("DSW_FORCE_GRAD_SYNC") != "1"):
-            return
-        have = [p.grad is not None for p in self.params]
-        if all(have):
-            torch._foreach_copy_(self.views, [p.grad for p in self.params])   # one launch for the whole bucket
+    # ---- gradients live in the bucket
+    def attach(self):
+        for p in self.params:
+            p.grad = self.views[p]
+        if self.overlap and not self._hooks:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._ready))
+        self.attached = True
+        return self
+
+    def zero(self):
+        if not self.attached:
+            raise RuntimeError("zero() is the zero_grad of an attached bucket")
+        for p in self.params:          # an optimizer.zero_grad(set_to_none=True) in between would have detached them
+            if p.grad is not self.views[p]:
+                p.grad = self.views[p]
+        self.bucket.zero_()
+
+    def active(self):
+        return dist.is_initialized() and (dist.get_world_size(self.group) > 1
+                                          or os.environ.get("DSW_FORCE_GRAD_SYNC") == "1")
+
+    # ---- the exchange
+    def _ready(self, p):
+        ci = self.chunk_of[p]
+        self._pending[ci] -= 1
+        if self._pending[ci] == 0 and self.overlap and not self.capturing and self.active():
+            self._launch(ci)
+
+    def _launch(self, ci):
+        start, stop, _ = self.chunks[ci]
+        seg = self.bucket[start:stop]
+        if dist.get_backend(self.group) == "nccl":     # RCCL averages in the collective: no separate scale kernel
+            work = dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
         else:
-            for p, v in zip(self.params, self.views):
+            work = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._launched[ci] = True
+        self._works.append(work)
+
+    def finish(self):
+        """All chunks averaged across ranks when this returns (stream-ordered for RCCL: later kernels on the current
+        stream see the result).  No-op in a single-process world."""
+        if self.active():
+            if not self.attached:
+                self._pack()
+            for ci in range(len(self.chunks)):
+                if not self._launched[ci]:
+                    self._launch(ci)
+            for w in self._works:
+                w.wait()
+            if dist.get_backend(self.group) != "nccl":
+                self.bucket.div_(dist.get_world_size(self.group))
+            if not self.attached:
+                self._unpack()
+        self._works = []
+        self._launched = [False] * len(self.chunks)
+        self._pending = [len(ps) for _, _, ps in self.chunks]
+
+    __call__ = finish
+
+    # ---- detached mode (gradients are ordinary tensors: copy in, exchange, copy out)
+    def _pack(self):
+        have = [p.grad is not None for p in self.params]
+        views = [self.views[p] for p in self.params]
+        if all(have):
+            torch._foreach_copy_(views, [p.grad for p in self.params])   # one launch for the whole bucket
+        else:
+            for p, v in zip(self.params, views):
                 if p.grad is None:
                     v.zero_()
                 else:
                     v.copy_(p.grad)
-        if dist.get_backend(self.group) == "nccl":     # RCCL averages in the collective: no separate scale kernel
-            dist.all_reduce(self.bucket, op=dist.ReduceOp.AVG, group=self.group)
-        else:
-            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
-            self.bucket.div_(dist.get_world_size(self.group))
-        if all(have):
-            torch._foreach_copy_([p.grad for p in self.params], self.views)
-        else:
-            for p, v in zip(self.params, self.views):
-                if p.grad is None:
-                    p.grad = v.clone()
-                else:
-                    p.grad.copy_(v)
+
+    def _unpack(self):
+        for p in self.params:
+            v = self.views[p]
+            if p.grad is None:
+                p.grad = v.clone()
+            else:
+                p.grad.copy_(v)
+
+
+class FlatGradAllReduce(GradBucket):
+    """Average the gradients of ``params`` across ranks with a single flat-bucket all-reduce (gradients stay ordinary
+    tensors: packed before and unpacked after the collective)."""
+
+    def __init__(self, params, group=None):
+        super().__init__(params, group=group, chunk_bytes=1 << 62, overlap=False, attach=False)

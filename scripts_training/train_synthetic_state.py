@@ -98,13 +98,17 @@ def ar_training_step(model, x, targets, n_dyn, stack_most_recent_prediction=True
 
 
 class Trainer:
-    """model + WeightedMSELoss + Adam(eps=1e-7) + one flat-bucket gradient all-reduce, stepping on static
-    HBM-resident tensors.  ``step()`` launches the whole optimisation step - zero_grad, the AR forwards, backward,
-    optimizer update - as ONE HIP graph replay when ``use_graph`` (single process; with N > 1 ranks the graph ends after
-    the gradients are packed into the bucket, the RCCL all-reduce and the optimizer update follow eagerly)."""
+    """model + WeightedMSELoss + Adam(eps=1e-7) + gradient bucket, stepping on static HBM-resident tensors.
+
+    The gradients live in ONE flat buffer (``dsw_amd.parallel.GradBucket``): backward accumulates into it, RCCL averages
+    it in place, Adam reads it.  Single process: ``step()`` launches the whole optimisation step - zero, the AR forwards,
+    backward, optimizer update - as ONE HIP graph replay when ``use_graph``.  N > 1 ranks: the step runs eagerly and the
+    bucket's chunks are all-reduced from the post-accumulate hooks WHILE backward is still computing the earlier layers
+    (``overlap``); with ``use_graph`` and N > 1 the graph holds forwards + backward, the chunks go out back to back after
+    the replay and the optimizer update follows eagerly."""
 
     def __init__(self, model, x, targets, n_dyn, lr, weights=None, stack=True, use_graph=True, dim_names=None):
-        from dsw_amd.parallel import FlatGradAllReduce
+        from dsw_amd.parallel import GradBucket
         from modules.loss import WeightedMSELoss
 
         self.model, self.x, self.targets, self.n_dyn, self.stack = model, x, targets, n_dyn, stack
@@ -116,22 +120,22 @@ class Trainer:
         # capturable: the step counter lives on the device, so optimizer.step() can sit inside a HIP graph
         self.optimizer = torch.optim.Adam(model.parameters(), lr=lr, eps=1e-7, weight_decay=0, amsgrad=False,
                                           capturable=bool(use_graph and x.is_cuda))
-        self.sync_grads = FlatGradAllReduce(model.parameters())
+        self.bucket = GradBucket(model.parameters(), overlap=True)
         self.loss = None
         self.graph = None
-        self.launch = "eager"
+        self.launch = "eager" if not self.distributed else "eager, chunked all-reduce overlapped with backward"
         if use_graph and x.is_cuda:
             self._capture()
 
     def _fwd_bwd(self):
-        self.optimizer.zero_grad(set_to_none=True)
+        self.bucket.zero()
         loss = ar_training_step(self.model, self.x, self.targets, self.n_dyn, self.stack, self.criterion, self.dim_info)
         loss.backward()
         return loss.detach()
 
     def _eager_step(self):
         loss = self._fwd_bwd()
-        self.sync_grads()
+        self.bucket.finish()
         self.optimizer.step()
         return loss
 
@@ -148,16 +152,21 @@ class Trainer:
         torch.cuda.synchronize()
         try:
             g = torch.cuda.CUDAGraph()
+            self.bucket.capturing = True      # the hooks must not enqueue collectives into the recording
             with torch.cuda.graph(g):
                 self.loss = self._fwd_bwd()
                 if not self.distributed:
                     self.optimizer.step()
+            self.bucket.capturing = False
+            self.bucket.finish()              # resets the hook counters of the recorded backward
             self.graph = g
-            self.launch = "hip graph: whole step" if not self.distributed else "hip graph: fwd+bwd, eager all-reduce + Adam"
+            self.launch = "hip graph: whole step" if not self.distributed else \
+                "hip graph: fwd+bwd; chunked all-reduce + Adam eagerly after the replay"
         except Exception as exc:  # noqa: BLE001 - capture not possible: stay eager
             print("trainer: HIP graph capture unavailable (%s: %s); stepping eagerly" % (type(exc).__name__, exc),
                   file=sys.stderr)
             self.graph = None
+            self.bucket.capturing = False
             torch.cuda.synchronize()
         with torch.no_grad():
             for p, v in zip(self.model.parameters(), saved):
@@ -172,7 +181,7 @@ class Trainer:
             return self._eager_step()
         self.graph.replay()
         if self.distributed:
-            self.sync_grads()
+            self.bucket.finish()
             self.optimizer.step()
         return self.loss
 
@@ -222,6 +231,9 @@ def main(argv=None):
     ap.add_argument("--batch_size", type=int, default=None, help="per GPU; default training_batch_size of the config")
     ap.add_argument("--ar_iterations", type=int, default=None, help="override ar_settings.ar_iterations")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--graph", action="store_true",
+                    help="N > 1: replay forwards + backward from a HIP graph (the all-reduce then follows the replay "
+                         "instead of overlapping backward); single process: the default")
     args = ap.parse_args(argv)
 
     from dsw_amd import _native
@@ -236,7 +248,7 @@ def main(argv=None):
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     trainer, info = build_trainer(cfg, device, batch_size=args.batch_size, ar_iterations=args.ar_iterations, rank=rank,
-                                  use_graph=not args.no_graph)
+                                  use_graph=(not args.no_graph) and (world == 1 or args.graph))
 
     losses = []
     for _ in range(args.warmup):

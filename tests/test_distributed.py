@@ -123,3 +123,65 @@ def test_two_rank_broadcast_makes_operators_and_parameters_identical():
     for k in range(1, 7):
         assert torch.equal(out[0][k], out[1][k]), k
     assert torch.equal(out[0][0], out[0][1])                     # rank 0's state is the one that survives
+
+
+def _bucket_worker(rank, world, port, out):
+    for p in (os.path.join(REPO, "deepsphere-weather_amd"), REPO, os.path.join(REPO, "tests"), os.path.join(REPO, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from dsw_amd.parallel import GradBucket, init_from_env
+
+    init_from_env("gloo")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(),
+                                torch.nn.Linear(16, 3))
+    model[4].bias.requires_grad_(False)                       # a frozen parameter stays out of the bucket
+    bucket = GradBucket(model.parameters(), chunk_bytes=200, overlap=True)   # 5 params -> three chunks
+    n_chunks = len(bucket.chunks)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    launched_in_backward = []
+    for step in range(3):
+        g = torch.Generator().manual_seed(10 * step + rank)
+        x, y = torch.randn(4 + rank, 6, generator=g), torch.randn(4 + rank, 3, generator=g)
+        bucket.zero()
+        ((model(x) - y) ** 2).sum().backward()
+        launched_in_backward.append(sum(bucket._launched))    # hooks enqueued these while autograd was still running
+        bucket.finish()
+        assert all(p.grad is bucket.views[p] for p in bucket.params)
+        opt.step()
+    out[rank] = ([p.detach().clone() for p in model.parameters()], bucket.bucket.clone(), n_chunks, launched_in_backward)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_attached_overlapped_bucket():
+    """Gradients living in the bucket + chunked all-reduce enqueued from the post-accumulate hooks: three SGD steps on
+    two ranks with different (ragged) data give the parameters of the same steps taken on the summed-then-halved
+    gradients, identically on both ranks."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_bucket_worker, args=(world, port, out), nprocs=world, join=True)
+    torch.manual_seed(0)
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(),
+                              torch.nn.Linear(16, 3)).double()
+    ref[4].bias.requires_grad_(False)
+    opt = torch.optim.SGD(ref.parameters(), lr=0.1)
+    for step in range(3):
+        opt.zero_grad()
+        for rank in range(world):
+            g = torch.Generator().manual_seed(10 * step + rank)
+            x, y = torch.randn(4 + rank, 6, generator=g), torch.randn(4 + rank, 3, generator=g)
+            (((ref(x.double()) - y.double()) ** 2).sum() / world).backward()
+        opt.step()
+    for r in range(world):
+        params, _, n_chunks, launched = out[r]
+        assert n_chunks >= 3 and all(n >= 1 for n in launched)         # some chunk left before backward returned
+        for p, q in zip(params, ref.parameters()):
+            np.testing.assert_allclose(p.numpy(), q.detach().numpy(), rtol=0, atol=2e-6)
+    for p, q in zip(out[0][0], out[1][0]):
+        assert torch.equal(p, q)
+    assert torch.equal(out[0][1], out[1][1])
