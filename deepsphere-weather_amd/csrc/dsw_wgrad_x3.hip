@@ -533,7 +533,7 @@ int launch_wbf16(WgradParams& P, int groups, int otiles, int64_t max_slabs, int6
     const int zdim = otiles * (P.dy_planes > 1 ? P.dy_planes : 1);
     P.otiles = otiles;
     int64_t want = 256L * occ / ((int64_t)groups * zdim);
-    if (want < 32) want = 32;
+    if (want < 8) want = 8;   // many (k, f) x column tiles already fill the CUs: fewer, longer slabs = fewer partials to reduce
     if (want > max_slabs) want = max_slabs;
     int64_t rps = (P.N + want - 1) / want;
     rps = ((rps + 63) / 64) * 64;
@@ -562,7 +562,7 @@ int launch_wx3(WgradParams& P, int groups, int otiles, int64_t max_slabs, int64_
     const int zdim = otiles * (P.dy_planes > 1 ? P.dy_planes : 1);
     P.otiles = otiles;
     int64_t want = 256L * occ / ((int64_t)groups * zdim);
-    if (want < 32) want = 32;
+    if (want < 8) want = 8;   // many (k, f) x column tiles already fill the CUs: fewer, longer slabs = fewer partials to reduce
     if (want > max_slabs) want = max_slabs;
     int64_t rps = (P.N + want - 1) / want;
     rps = ((rps + WR - 1) / WR) * WR;
