@@ -100,7 +100,7 @@ struct Hop2Args {
 // round trips, so 8 (then 4, then 2) entries are fetched per batch and their data rows requested back to back.
 // BYTEOFF: the u16 entries are BYTE offsets of the rows (list position x row bytes < 64 KiB: the add folds the 16-bit
 // select, v_add_u32_sdwa); otherwise they are list positions and the address costs a multiply-add.
-template <bool BF16, bool BYTEOFF>
+template <bool BF16, bool BYTEOFF, int GB = 8>
 static __device__ __forceinline__ void gather_ell(const unsigned short* __restrict__ row_idx, const float* __restrict__ row_val,
                                                   const int W, const unsigned row_bytes,
                                                   const unsigned char* __restrict__ bufc,
@@ -109,7 +109,8 @@ static __device__ __forceinline__ void gather_ell(const unsigned short* __restri
     using VT = typename R::V;
     constexpr int N = R::N;
     int j = 0;
-    for (; j + 8 <= W; j += 8) {
+    // GB = 4: batches of four only - 16 registers less, what the k = 20 adjoint variant needs to stay under 128
+    for (; GB >= 8 && j + 8 <= W; j += 8) {
         const uint2 i0 = *reinterpret_cast<const uint2*>(row_idx + j), i1 = *reinterpret_cast<const uint2*>(row_idx + j + 4);
         const float4 v0 = *reinterpret_cast<const float4*>(row_val + j), v1 = *reinterpret_cast<const float4*>(row_val + j + 4);
         const unsigned ix[8] = {i0.x & 0xffffu, i0.x >> 16, i0.y & 0xffffu, i0.y >> 16,
@@ -127,7 +128,7 @@ static __device__ __forceinline__ void gather_ell(const unsigned short* __restri
             for (int c = 0; c < N; ++c) acc[c] = fmav(v, x[c], acc[c]);
         }
     }
-    if (j + 4 <= W) {
+    for (; j + 4 <= W; j += 4) {
         const uint2 i0 = *reinterpret_cast<const uint2*>(row_idx + j);
         const float4 v0 = *reinterpret_cast<const float4*>(row_val + j);
         const unsigned ix[4] = {i0.x & 0xffffu, i0.x >> 16, i0.y & 0xffffu, i0.y >> 16};
@@ -143,7 +144,6 @@ static __device__ __forceinline__ void gather_ell(const unsigned short* __restri
 #pragma unroll
             for (int c = 0; c < N; ++c) acc[c] = fmav(v, x[c], acc[c]);
         }
-        j += 4;
     }
     if (j < W) {   // W is even: one last pair
         const unsigned i0 = *reinterpret_cast<const unsigned*>(row_idx + j);
@@ -172,11 +172,14 @@ constexpr int MAXST = 8;
 // barrier; vmcnt completes in order, so waiting for Z* (first use: end of the first phase-1 task) leaves
 // the U burst in flight under phases 1 and 2, and it lands in the other half of the double-buffered bufX
 // at the top of the next iteration.
-template <bool BF16, int NST, bool HZA, bool HZ2, int NS1 = NST, int NS2 = NST, bool BYTEOFF = false>
-__global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fused_kernel(const Hop2Args P) {
+// HZB: a second first-hop operand Z1b may be present (K >= 4 adjoint steps); without it the K = 3 adjoint pair of the
+// k = 20 stencil (3 S1 slots) fits 128 registers = two workgroups per CU.
+template <bool BF16, int NST, bool HZA, bool HZ2, int NS1 = NST, int NS2 = NST, bool BYTEOFF = false, bool HZB = HZA>
+__global__ __launch_bounds__(NTHREADS, ((HZA && HZB && NS1 > 2) ? 2 : 4)) void spmm2_fused_kernel(const Hop2Args P) {
     using R = Row16<BF16>;
     using VT = typename R::V;
     constexpr int N = R::N;
+    constexpr int GBATCH = (HZA && !HZB && NS1 > 2) ? 4 : 8;   // the variant squeezed under 128 registers
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     // LDS carve-up (all offsets multiples of 16)
     unsigned char* bufX0 = lds;                                            // [max_n2][row_bytes], sample s
@@ -229,13 +232,13 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
     const int cb = ((tid - grp0 * lpr) * 16) % P.row_bytes;   // byte offset of this lane inside the row
 
     // per-slot byte offsets (sample-relative), clamped so that every load is legal and unconditional
-    unsigned offU[NST], offZ1[NST], offZ2[NST];   // < 2^32: one sample of one tensor
+    unsigned offU[NST], offZ1[NS1], offZ2[NS2];   // < 2^32: one sample of one tensor
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
         const int i = grp + k * rpp;
         offU[k] = (unsigned)rows[min(i, n2 - 1)] * (unsigned)P.row_stride + cb;
-        offZ1[k] = (unsigned)rows[min(i, n1 - 1)] * (unsigned)P.row_stride + cb;
-        offZ2[k] = (unsigned)(r0 + min(i, rt - 1)) * (unsigned)P.row_stride + cb;
+        if (k < NS1) offZ1[k] = (unsigned)rows[min(i, n1 - 1)] * (unsigned)P.row_stride + cb;
+        if (k < NS2) offZ2[k] = (unsigned)(r0 + min(i, rt - 1)) * (unsigned)P.row_stride + cb;
     }
 
     u32x4 su[NST];
@@ -277,12 +280,12 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
         const size_t sample = vbase(b);
         // burst: this sample's epilogue operands first, then the next sample's U rows
         // NS1 / NS2: slots that can hold an S1 row / a tile row (ceil(max_n1 / rpp), ceil(tile_rows / rpp))
-        u32x4 cz1[HZA ? NS1 : 1], cz1b[HZA ? NS1 : 1], cz2[HZ2 ? NS2 : 1];
+        u32x4 cz1[HZA ? NS1 : 1], cz1b[(HZA && HZB) ? NS1 : 1], cz2[HZ2 ? NS2 : 1];
         if constexpr (HZA) {
 #pragma unroll
             for (int k = 0; k < NS1; ++k) cz1[k] = *reinterpret_cast<const u32x4*>(P.Z1 + sample + offZ1[k]);
         }
-        if (HZA && P.Z1b != P.Z1) {   // uniform; Z1b aliases Z1 (weight 0) when the caller has only one
+        if (HZA && HZB && P.Z1b != P.Z1) {   // uniform; Z1b aliases Z1 (weight 0) when the caller has only one
 #pragma unroll
             for (int k = 0; k < NS1; ++k) cz1b[k] = *reinterpret_cast<const u32x4*>(P.Z1b + sample + offZ1[k]);
         }
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
                 VT acc[N];
 #pragma unroll
                 for (int j = 0; j < N; ++j) acc[j] = R::splat(0.f);
-                gather_ell<BF16, BYTEOFF>(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, (unsigned)P.row_bytes, bufX + cb, acc);
+                gather_ell<BF16, BYTEOFF, GBATCH>(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, (unsigned)P.row_bytes, bufX + cb, acc);
                 VT o[N];
 #pragma unroll
                 for (int j = 0; j < N; ++j) o[j] = R::splat(P.a1) * acc[j];
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
 #pragma unroll
                     for (int j = 0; j < N; ++j) o[j] = fmav(R::splat(P.b1), z[j], o[j]);
                 }
-                if (HZA && P.Z1b != P.Z1) {
+                if (HZA && HZB && P.Z1b != P.Z1) {
                     VT z[N];
                     R::unpack(__builtin_bit_cast(uint4, cz1b[k]), z);
 #pragma unroll
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && NS1 > 2) ? 2 : 4)) void spmm2_fu
                 VT acc[N];
 #pragma unroll
                 for (int j = 0; j < N; ++j) acc[j] = R::splat(0.f);
-                gather_ell<BF16, BYTEOFF>(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, (unsigned)P.row_bytes, bufT + cb, acc);
+                gather_ell<BF16, BYTEOFF, GBATCH>(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, (unsigned)P.row_bytes, bufT + cb, acc);
                 VT u[N], o[N];
                 R::unpack(*reinterpret_cast<const uint4*>(bufX + (size_t)i * P.row_bytes + cb), u);
 #pragma unroll
@@ -386,6 +389,22 @@ namespace {
 template <bool BF16, int NST, int NS1, int NS2, bool BYTEOFF = false>
 int launch_h2(const Hop2Args& A, long nwg, size_t lds, hipStream_t stream) {
     const int sel = ((A.Z1 || A.Z1b) ? 1 : 0) | (A.Z2 ? 2 : 0);
+    if constexpr (BYTEOFF) {   // the exact-slot variants also exist without the second first-hop operand
+        if (NS1 > 2 && (A.Z1 || A.Z1b) && A.Z1b == A.Z1) {
+#define DSW_H2_NOB(Z2_)                                                                                          \
+    do {                                                                                                         \
+        if (lds > 64 * 1024 &&                                                                                   \
+            hipFuncSetAttribute((const void*)spmm2_fused_kernel<BF16, NST, true, Z2_, NS1, NS2, BYTEOFF, false>,          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
+            return DSW_ERR_LAUNCH;                                                                               \
+        hipLaunchKernelGGL((spmm2_fused_kernel<BF16, NST, true, Z2_, NS1, NS2, BYTEOFF, false>), dim3((unsigned)nwg),     \
+                           dim3(NTHREADS), lds, stream, A);                                                      \
+    } while (0)
+            if (A.Z2) DSW_H2_NOB(true); else DSW_H2_NOB(false);
+#undef DSW_H2_NOB
+            return dsw_check_launch();
+        }
+    }
 #define DSW_H2_SEL(S, ZA_, Z2_)                                                                                  \
     case S: {                                                                                                    \
         if (lds > 64 * 1024 &&                                                                                   \
@@ -435,7 +454,9 @@ int dsw_spmm2_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const 
     // does not fit at all - the k = 20 stencil's 2-ring is 4x the tile, and 8 waves per CU cannot hide the LDS latency
     const size_t lds2 = hop2_lds_bytes(plan, A.row_bytes, false), lds1 = hop2_lds_bytes(plan, A.row_bytes, true);
     const int rpp_ = NTHREADS / A.lpr;
-    const bool two_wg_regs = !((A.Z1 || A.Z1b) && (plan->max_n1 + rpp_ - 1) / rpp_ > 2);   // see __launch_bounds__
+    // see __launch_bounds__: only the exact-slot variants (byte offsets) come without the Z1b registers
+    const bool byteoff_ = (long)plan->max_n2 * A.row_bytes <= 65535;
+    const bool two_wg_regs = !((A.Z1 || A.Z1b) && (plan->max_n1 + rpp_ - 1) / rpp_ > 2 && !(byteoff_ && A.Z1b == A.Z1));
     A.single_buf = (lds2 <= 80 * 1024) ? 0 : (lds1 <= 80 * 1024 && two_wg_regs) ? 1 : (lds2 <= 160 * 1024) ? 0 : 1;
     { static const char* sb = dsw_diag_env("DSW_H2_SINGLE"); if (sb) A.single_buf = (sb[0] == '1') && lds1 <= 160 * 1024 ? 1 : (lds2 <= 160 * 1024 ? 0 : 1); }   // diagnostics
     const size_t lds = A.single_buf ? lds1 : lds2;
