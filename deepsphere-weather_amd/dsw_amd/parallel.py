@@ -102,8 +102,12 @@ class GradBucket:
         self.group = group
         self.overlap = overlap
         self.capturing = False
+        if not self.params:
+            raise ValueError("GradBucket needs at least one parameter that requires grad")
         order = list(reversed(self.params))
         ref = order[0]
+        if any(p.dtype != ref.dtype or p.device != ref.device for p in order):
+            raise ValueError("GradBucket: all parameters must share one dtype and device (one flat buffer)")
         n = sum(p.numel() for p in order)
         self.bucket = torch.zeros(n, dtype=ref.dtype, device=ref.device)
         self.views, self.chunk_of, self.chunks = {}, {}, []
