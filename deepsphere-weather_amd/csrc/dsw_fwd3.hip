@@ -59,6 +59,7 @@ struct Fwd3Args {
     int B, n_chunks, spc, ell_w;
     int Fout;
     int relu;            // ReLU after the bias (ConvBlock)
+    int explicit_tiles;  // the plan's tiles are explicit row sets (see dsw_hop2_plan)
 };
 
 static __device__ __forceinline__ float trunc_bf16(float f) { return __uint_as_float(__float_as_uint(f) & 0xffff0000u); }
@@ -157,8 +158,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
     const int b_end = min(P.B, b_begin + P.spc);
     const int* meta = P.tile_meta + (size_t)tile * 6;
     const int s2_off = meta[0], n1 = meta[1], n2 = meta[2], nnz_off = meta[3], rp_off = meta[4];
-    const int r0 = tile * 64;
-    const int rt = min(64, P.V - r0);
+    const int rt = P.explicit_tiles ? meta[5] : min(64, P.V - tile * 64);   // tile rows = the first rt list entries
     const int tid = threadIdx.x;
     const int W = P.ell_w;
     const size_t sample_bytes = (size_t)P.V * RB;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
     const int grp = tid >> 3;                       // row of a 64-row pass
     const unsigned c4 = (unsigned)(tid & 7);        // 16-byte chunk (4 channels) of this lane inside a row
     const unsigned cb = c4 * 16;
-    const unsigned tile_off = (unsigned)(r0 + grp) * (unsigned)RB + cb;    // this thread's tile row (slot 0), sample-relative
+    const unsigned tile_off = (unsigned)rows[min(grp, rt - 1)] * (unsigned)RB + cb;    // this thread's tile row (slot 0), sample-relative
     // byte offset (sample-relative) of list position grp + k * 64, index-clamped so that every load is legal and
     // unconditional; re-read from LDS where needed instead of kept in registers (the W fragments need those)
     auto offU = [&](const int k) __attribute__((always_inline)) {
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
             }
             if (FULL || row < rt)
                 *reinterpret_cast<f32x4_t*>(P.Y + (size_t)b * ((size_t)P.V * P.Fout * 4) +
-                                            (unsigned)((r0 + row) * P.Fout * 4 + (16 * cbk + 4 * kc) * 4)) = acc[r];
+                                            (unsigned)(rows[FULL ? row : min(row, rt - 1)] * P.Fout * 4 + (16 * cbk + 4 * kc) * 4)) = acc[r];
         }
     }
 }
@@ -382,6 +382,7 @@ int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X,
     A.W = static_cast<const float*>(W); A.bias = static_cast<const float*>(bias);
     A.V = (int)V; A.n_tiles = plan->n_tiles; A.max_n1 = plan->max_n1; A.max_n2 = plan->max_n2;
     A.B = (int)B; A.ell_w = (plan->reserved + 3) & ~3; A.Fout = (int)Fout; A.relu = relu;
+    A.explicit_tiles = plan->explicit_tiles;
 
     // batch chunks: same cost model as the two-hop kernel (rounds x (staging + samples per chunk))
     const long slots = 256L * ((160 * 1024) / (long)lds > 0 ? (160 * 1024) / (long)lds : 1);
@@ -400,7 +401,7 @@ int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X,
     const long nwg = (long)plan->n_tiles * A.n_chunks;
     if (nwg > 2147483647L) return 0;
     int r;
-    const bool full = (V % 64 == 0) && T != nullptr;
+    const bool full = (V % 64 == 0) && T != nullptr && !plan->explicit_tiles;
     if (nst == 3 && ns1 == 2) r = full ? launch_ncb<3, 2, true>(A, nwg, lds, stream) : launch_ncb<3, 2, false>(A, nwg, lds, stream);
     else if (nst == 2 && ns1 <= 2) r = full ? launch_ncb<2, 2, true>(A, nwg, lds, stream) : launch_ncb<2, 2, false>(A, nwg, lds, stream);
     else if (nst == 3) r = full ? launch_ncb<3, 3, true>(A, nwg, lds, stream) : launch_ncb<3, 3, false>(A, nwg, lds, stream);

@@ -90,6 +90,7 @@ struct Hop2Args {
     int spc;                    // samples per chunk
     int ell_w;                  // ELL width in LDS: max row length of the plan rounded up to 4
     int single_buf;             // 1: one input-row buffer (halves the staging LDS so that a second workgroup fits the CU)
+    int explicit_tiles;         // 1: the tile's rows are the first meta[5] entries of its gather list (any row set)
 };
 
 
@@ -201,8 +202,9 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && HZB && NS1 > 2) ? 2 : 4)) void s
     const int b_end = min(P.B, b_begin + P.spc);
     const int* meta = P.tile_meta + (size_t)tile * 6;
     const int s2_off = meta[0], n1 = meta[1], n2 = meta[2], nnz_off = meta[3], rp_off = meta[4];
-    const int r0 = tile * P.tile_rows;
-    const int rt = min(P.tile_rows, P.V - r0);
+    // tile rows = the first rt entries of the gather list (consecutive rows tile * tile_rows .. unless the plan carries
+    // explicit row sets); every address below goes through that list
+    const int rt = P.explicit_tiles ? meta[5] : min(P.tile_rows, P.V - tile * P.tile_rows);
     const int tid = threadIdx.x;
     const int W = P.ell_w;
     const size_t sample_bytes = (size_t)P.V * P.row_stride;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && HZB && NS1 > 2) ? 2 : 4)) void s
         const int i = grp + k * rpp;
         offU[k] = (unsigned)rows[min(i, n2 - 1)] * (unsigned)P.row_stride + cb;
         if (k < NS1) offZ1[k] = (unsigned)rows[min(i, n1 - 1)] * (unsigned)P.row_stride + cb;
-        if (k < NS2) offZ2[k] = (unsigned)(r0 + min(i, rt - 1)) * (unsigned)P.row_stride + cb;
+        if (k < NS2) offZ2[k] = (unsigned)rows[min(i, rt - 1)] * (unsigned)P.row_stride + cb;   // = this slot's OUTPUT row
     }
 
     u32x4 su[NST];
@@ -325,8 +327,8 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && HZB && NS1 > 2) ? 2 : 4)) void s
                 }
                 const uint4 packed = R::pack(o);
                 *reinterpret_cast<uint4*>(bufT + (size_t)i * P.row_bytes + cb) = packed;
-                if (P.Y1 != nullptr && i < rt)
-                    *reinterpret_cast<uint4*>(P.Y1 + sample + (size_t)(r0 + i) * P.row_stride + cb) = packed;
+                if (k < NS2 && P.Y1 != nullptr && i < rt)
+                    *reinterpret_cast<uint4*>(P.Y1 + sample + offZ2[k < NS2 ? k : 0]) = packed;
             }
         }
         __syncthreads();
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && HZB && NS1 > 2) ? 2 : 4)) void s
 #pragma unroll
                     for (int j = 0; j < N; ++j) o[j] = fmav(R::splat(P.c2), z[j], o[j]);
                 }
-                *reinterpret_cast<uint4*>(P.Y2 + sample + (size_t)(r0 + i) * P.row_stride + cb) = R::pack(o);
+                *reinterpret_cast<uint4*>(P.Y2 + sample + offZ2[k]) = R::pack(o);
             }
         }
         // double-buffered: no barrier here - the next iteration writes the OTHER bufX, and its barrier orders bufT reuse
@@ -442,7 +444,7 @@ int dsw_spmm2_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const 
     A.a1 = a1; A.b1 = Z1 ? b1 : 0.f; A.d1 = Z1b ? d1 : 0.f; A.a2 = a2; A.b2 = b2; A.c2 = Z2 ? c2 : 0.f;
     if (!A.Z1 && A.Z1b) { A.Z1 = A.Z1b; A.b1 = A.d1; A.Z1b = nullptr; A.d1 = 0.f; }
     if (A.Z1 && !A.Z1b) A.Z1b = A.Z1;   // the kernel skips the second operand when both alias
-    A.V = (int)V; A.n_tiles = plan->n_tiles; A.tile_rows = plan->tile_rows;
+    A.V = (int)V; A.n_tiles = plan->n_tiles; A.tile_rows = plan->tile_rows; A.explicit_tiles = plan->explicit_tiles;
     A.max_n1 = plan->max_n1; A.max_n2 = plan->max_n2; A.max_nnz = plan->max_nnz;
     A.row_stride = (int)(C * es);
     A.row_bytes = (A.row_stride > 128 && A.row_stride % 128 == 0) ? 128 : A.row_stride;

@@ -82,19 +82,31 @@ class CsrOperator:
             plan = None
             host_csr = []
 
-            def host_plan(rows):
-                if rows not in self._plans_by_rows:
+            def host_plan(rows, clustered=False):
+                key = (rows, clustered)
+                if key not in self._plans_by_rows:
                     if not host_csr:
                         host_csr.extend(t.cpu().numpy() for t in (self.rowptr, self.colind, self.values))
                     try:
-                        self._plans_by_rows[rows] = hop2.build_hop2_plan(*host_csr, rows)
+                        tiles = None
+                        if clustered:
+                            # neighbourhood caps = what two workgroups per CU can stage of 128-byte rows (one input
+                            # buffer, ELL of the longest row): n1 * (128 + 6 w) + n2 * 128 <= 80 KiB at n2 ~ 1.8 n1
+                            lens = host_csr[0][1:] - host_csr[0][:-1]
+                            w = (int(lens.max()) + 3) & ~3 if lens.size else 4
+                            cap1 = int((80 * 1024 - 2048) / (128 + 6 * w + 1.8 * 128))
+                            tiles = hop2.cluster_tiles(host_csr[0], host_csr[1], rows, max_n1=cap1, max_n2=int(1.8 * cap1))
+                        self._plans_by_rows[key] = hop2.build_hop2_plan(*host_csr, rows, tiles=tiles)
                     except ValueError:
-                        self._plans_by_rows[rows] = None
-                return self._plans_by_rows[rows]
+                        self._plans_by_rows[key] = None
+                return self._plans_by_rows[key]
 
             # largest tile whose workgroup still leaves room for >= 2 workgroups per CU (<= 80 KiB of
             # the 160 KiB LDS); a single resident workgroup (<= 156 KiB) is the last resort
-            # (the kernel drops to ONE input-row buffer when that is what lets a second workgroup share the CU)
+            # (the kernel drops to ONE input-row buffer when that is what lets a second workgroup share the CU).
+            # Tiles of CONSECUTIVE rows first (HEALPix nested order: a tile is a square patch); when their
+            # neighbourhoods are too large - row order that is not 2-D local: equiangular row-major, HEALPix ring
+            # order - tiles clustered from the operator's graph.
             for budget, single in ((80 * 1024, False), (80 * 1024, True), (156 * 1024, False), (156 * 1024, True)):
                 for rows in (256, 128, 64):
                     if rows > self.shape[0]:
@@ -103,6 +115,16 @@ class CsrOperator:
                     if cand is not None and cand.lds_bytes(row_bytes, single) <= budget:
                         plan = cand
                         break
+                if plan is None:
+                    # clustered tiles: of the tile heights that fit, the one that needs the fewest tiles (a height whose
+                    # tiles had to be halved to respect the neighbourhood caps loses to the next smaller one)
+                    for rows in (64, 48):
+                        if self.shape[0] < 8 * rows:
+                            continue    # a graph of a few tiles gains nothing from the fused path
+                        cand = host_plan(rows, True)
+                        if cand is not None and cand.lds_bytes(row_bytes, single) <= budget and \
+                                (plan is None or cand.n_tiles < plan.n_tiles):
+                            plan = cand
                 if plan is not None:
                     break
             self._plans[row_bytes] = None if plan is None else plan.to(self.device)

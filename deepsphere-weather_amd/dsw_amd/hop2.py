@@ -41,13 +41,15 @@ class Hop2PlanStruct(ctypes.Structure):
         ("lrowptr", ctypes.c_void_p),     # int32, concatenated, (n1 + 1) per tile, tile-relative
         ("lcol", ctypes.c_void_p),        # uint16, concatenated
         ("lval", ctypes.c_void_p),        # float32, concatenated
+        ("explicit_tiles", ctypes.c_int32),   # 1: tile rows = the first tile_meta[t][5] entries of the gather list
     ]
 
 
 class Hop2Plan:
     def __init__(self, tile_rows, tile_meta, s2_rows, lrowptr, lcol, lval, max_n1, max_n2, max_nnz, n_rows,
-                 max_row_len=0):
+                 max_row_len=0, explicit_tiles=False):
         self.max_row_len = int(max_row_len)
+        self.explicit_tiles = bool(explicit_tiles)
         self.tile_rows = int(tile_rows)
         self.tile_meta = tile_meta
         self.s2_rows = s2_rows
@@ -81,7 +83,7 @@ class Hop2Plan:
         st = Hop2PlanStruct(
             self.n_tiles, self.tile_rows, self.max_n1, self.max_n2, self.max_nnz, self.max_row_len,
             arrs["tile_meta"].data_ptr(), arrs["s2_rows"].data_ptr(), arrs["lrowptr"].data_ptr(),
-            arrs["lcol"].data_ptr(), arrs["lval"].data_ptr(),
+            arrs["lcol"].data_ptr(), arrs["lval"].data_ptr(), 1 if self.explicit_tiles else 0,
         )
         self._dev = (device, arrs)   # keeps the device tensors alive
         self._struct = st
@@ -92,23 +94,116 @@ class Hop2Plan:
         return ctypes.byref(self._struct)
 
 
-def build_hop2_plan(rowptr: np.ndarray, colind: np.ndarray, values: np.ndarray, tile_rows: int) -> Hop2Plan:
-    """Plan for a square CSR operator (int32 rowptr/colind, fp32 values) and a tile size."""
+def _ring_sizes(rowptr, colind, tile, mark):
+    """(|S1|, |S2|) of a row set: the set plus its 1-ring, plus its 2-ring (``mark``: all-False scratch, restored)."""
+    def nbrs(rows):
+        starts, lens = rowptr[rows], rowptr[rows + 1] - rowptr[rows]
+        idx = np.repeat(starts - np.cumsum(np.concatenate([[0], lens[:-1]])), lens) + np.arange(int(lens.sum()))
+        return np.unique(colind[idx])
+    mark[tile] = True
+    c1 = nbrs(tile)
+    h1 = c1[~mark[c1]]
+    mark[h1] = True
+    s1 = np.concatenate([tile, h1])
+    c2 = nbrs(s1)
+    n2 = s1.size + int((~mark[c2]).sum())
+    mark[s1] = False
+    return s1.size, n2
+
+
+def cluster_tiles(rowptr: np.ndarray, colind: np.ndarray, tile_rows: int, max_n1: int = 0, max_n2: int = 0):
+    """Partition the rows of a square operator into compact tiles of <= ``tile_rows`` rows by greedy breadth-first growth
+    over its graph (no coordinates needed): the seed is the lowest unassigned row, every level adds the unassigned
+    neighbours of the previous one; the search front also walks through rows that are already taken, so that the slivers
+    left between earlier tiles are swept up instead of becoming one-row tiles.  Seeds advance in row order, i.e.
+    consecutive tiles stay neighbours (what the XCD-aware launch order wants).  Equiangular 200 x 400, k = 20: 1260 tiles
+    for 80 000 rows (ideal 1250), 1-/2-ring sizes 152 / 267 on average - a row-major strip of 64 rows has 340 / 648.
+    ``max_n1`` / ``max_n2`` (> 0): a tile whose tile + 1-ring / + 2-ring exceeds them is halved (in growth order, so both
+    halves stay compact) until it fits - the kernel sizes its LDS by the LARGEST neighbourhood of the plan, and a few
+    ragged tiles (poles, swept-up slivers) would otherwise cost every workgroup its second CU slot."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    colind = np.asarray(colind, dtype=np.int64)
+    n = rowptr.shape[0] - 1
+    assigned = np.zeros(n, dtype=bool)
+    seen = np.zeros(n, dtype=np.int64)
+    mark = np.zeros(n, dtype=bool)
+    tiles = []
+
+    def emit(tile):
+        if (max_n1 > 0 or max_n2 > 0) and tile.size > 8:
+            n1, n2 = _ring_sizes(rowptr, colind, tile, mark)
+            if (max_n1 > 0 and n1 > max_n1) or (max_n2 > 0 and n2 > max_n2):
+                half = tile.size // 2
+                emit(tile[:half])
+                emit(tile[half:])
+                return
+        tiles.append(tile)
+
+    seed = 0
+    stamp = 0
+    while True:
+        while seed < n and assigned[seed]:
+            seed += 1
+        if seed >= n:
+            break
+        stamp += 1
+        parts = [np.array([seed], dtype=np.int64)]
+        count = 1
+        assigned[seed] = True
+        seen[seed] = stamp
+        frontier = parts[0]
+        levels = 0
+        while count < tile_rows and frontier.size and levels < 24:
+            starts, lens = rowptr[frontier], rowptr[frontier + 1] - rowptr[frontier]
+            idx = np.repeat(starts - np.cumsum(np.concatenate([[0], lens[:-1]])), lens) + np.arange(int(lens.sum()))
+            nb = np.unique(colind[idx])
+            nb = nb[seen[nb] != stamp]
+            seen[nb] = stamp
+            take = nb[~assigned[nb]][:tile_rows - count]
+            if take.size:
+                assigned[take] = True
+                parts.append(take)
+                count += take.size
+            frontier = nb
+            levels += 1
+        emit(np.concatenate(parts))
+    return tiles
+
+
+def build_hop2_plan(rowptr: np.ndarray, colind: np.ndarray, values: np.ndarray, tile_rows: int, tiles=None) -> Hop2Plan:
+    """Plan for a square CSR operator (int32 rowptr/colind, fp32 values) and a tile size.  ``tiles``: explicit row sets
+    (a partition of the rows, each of <= ``tile_rows`` rows, e.g. from ``cluster_tiles``); default: consecutive rows."""
     rowptr = np.asarray(rowptr, dtype=np.int64)
     colind = np.asarray(colind, dtype=np.int64)
     values = np.asarray(values, dtype=np.float32)
     n = rowptr.shape[0] - 1
-    n_tiles = (n + tile_rows - 1) // tile_rows
+    explicit = tiles is not None
+    if explicit:
+        sizes = np.array([len(t) for t in tiles], dtype=np.int64)
+        cover = np.concatenate([np.asarray(t, dtype=np.int64) for t in tiles]) if len(tiles) else np.zeros(0, np.int64)
+        if sizes.size == 0 or sizes.max() > tile_rows or sizes.min() < 1 or cover.size != n or \
+                not np.array_equal(np.sort(cover), np.arange(n)):
+            raise ValueError("tiles must partition the rows into sets of 1..tile_rows rows")
+    n_tiles = len(tiles) if explicit else (n + tile_rows - 1) // tile_rows
     meta = np.zeros((n_tiles, 6), dtype=np.int32)
     s2_chunks, rp_chunks, col_chunks, val_chunks = [], [], [], []
     s2_off = nnz_off = rp_off = 0
     max_n1 = max_n2 = max_nnz = max_len = 0
     pos = np.full(n, -1, dtype=np.int64)   # scratch: global row -> position in the current gather list
     for t in range(n_tiles):
-        r0, r1 = t * tile_rows, min(n, (t + 1) * tile_rows)
-        tile = np.arange(r0, r1)
-        c1 = np.unique(colind[rowptr[r0]:rowptr[r1]])
-        halo1 = c1[(c1 < r0) | (c1 >= r1)]
+        if explicit:
+            tile = np.asarray(tiles[t], dtype=np.int64)
+            starts_t, lens_t = rowptr[tile], rowptr[tile + 1] - rowptr[tile]
+            idx_t = np.repeat(starts_t - np.cumsum(np.concatenate([[0], lens_t[:-1]])), lens_t) + np.arange(int(lens_t.sum()))
+            c1 = np.unique(colind[idx_t])
+            pos[tile] = 0
+            halo1 = c1[pos[c1] < 0]
+            pos[tile] = -1
+        else:
+            r0, r1 = t * tile_rows, min(n, (t + 1) * tile_rows)
+            tile = np.arange(r0, r1)
+            c1 = np.unique(colind[rowptr[r0]:rowptr[r1]])
+            halo1 = c1[(c1 < r0) | (c1 >= r1)]
         s1 = np.concatenate([tile, halo1])
         # columns referenced by the S1 rows
         starts, ends = rowptr[s1], rowptr[s1 + 1]
@@ -126,7 +221,7 @@ def build_hop2_plan(rowptr: np.ndarray, colind: np.ndarray, values: np.ndarray, 
         order = _bank_friendly_order(lcol, lens)
         lcol, idx = lcol[order], idx[order]
         pos[s2] = -1
-        meta[t] = (s2_off, s1.size, s2.size, nnz_off, rp_off, 0)
+        meta[t] = (s2_off, s1.size, s2.size, nnz_off, rp_off, tile.size if explicit else 0)
         s2_chunks.append(s2.astype(np.int32))
         rp_chunks.append(lrp)
         col_chunks.append(lcol)
@@ -138,7 +233,7 @@ def build_hop2_plan(rowptr: np.ndarray, colind: np.ndarray, values: np.ndarray, 
         max_len = max(max_len, int(lens.max()) if lens.size else 0)
     return Hop2Plan(
         tile_rows, meta, np.concatenate(s2_chunks), np.concatenate(rp_chunks), np.concatenate(col_chunks),
-        np.concatenate(val_chunks), max_n1, max_n2, max_nnz, n, max_len,
+        np.concatenate(val_chunks), max_n1, max_n2, max_nnz, n, max_len, explicit_tiles=explicit,
     )
 
 
@@ -189,13 +284,12 @@ def emulate_hop2(plan: Hop2Plan, U, Z1, Z1b, Z2, a1, b1, d1, a2, b2, c2):
             buft += b1 * Z1[rows[:n1]]
         if Z1b is not None:
             buft += d1 * Z1b[rows[:n1]]
-        r0 = t * plan.tile_rows
-        rt = min(plan.tile_rows, V - r0)
+        rt = int(plan.tile_meta[t][5]) if plan.explicit_tiles else min(plan.tile_rows, V - t * plan.tile_rows)
         for i in range(rt):
             sl = slice(lrp[i], lrp[i + 1])
             acc = a2 * (lval[sl, None] * buft[lcol[sl]]).sum(0) + b2 * bufx[i]
             if Z2 is not None:
-                acc = acc + c2 * Z2[r0 + i]
-            y2[r0 + i] = acc
-        y1[r0:r0 + rt] = buft[:rt]
+                acc = acc + c2 * Z2[rows[i]]
+            y2[rows[i]] = acc
+        y1[rows[:rt]] = buft[:rt]
     return y1, y2

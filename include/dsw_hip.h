@@ -43,17 +43,21 @@ extern "C" {
 typedef void* dsw_stream_t; /* hipStream_t */
 
 /* Tile plan of the fused two-hop SpMM (built once per operator on the host, see
- * deepsphere-weather_amd/dsw_amd/hop2.py): for every tile of `tile_rows` consecutive rows, the list
- * of rows it gathers (tile rows, then its 1-ring, then its 2-ring) and the CSR of tile + 1-ring rows
- * with columns rewritten as positions in that list.  All pointers are device pointers. */
+ * deepsphere-weather_amd/dsw_amd/hop2.py): for every tile, the list of rows it gathers (tile rows, then its
+ * 1-ring, then its 2-ring) and the CSR of tile + 1-ring rows with columns rewritten as positions in that list.
+ * A tile is `tile_rows` CONSECUTIVE rows (explicit_tiles = 0: tile t = rows t * tile_rows ..., what HEALPix nested
+ * order wants) or ANY set of <= tile_rows rows (explicit_tiles = 1: the first tile_meta[t][5] entries of its gather
+ * list; the builder clusters the operator's graph, so that samplings whose row order is not 2-D local - equiangular
+ * row-major, HEALPix ring order - still get compact neighbourhoods).  All pointers are device pointers. */
 typedef struct dsw_hop2_plan {
     int32_t n_tiles, tile_rows, max_n1, max_n2, max_nnz;
     int32_t reserved;          /* longest local CSR row (the kernel's ELL width before rounding up to 4) */
-    const int32_t* tile_meta;  /* [n_tiles][6]: s2_off, n1, n2, nnz_off, rp_off, 0 */
+    const int32_t* tile_meta;  /* [n_tiles][6]: s2_off, n1, n2, nnz_off, rp_off, rows of the tile (explicit_tiles) */
     const int32_t* s2_rows;    /* concatenated gather lists (global row ids) */
     const int32_t* lrowptr;    /* concatenated local row pointers, n1 + 1 per tile, tile-relative */
     const uint16_t* lcol;      /* concatenated local column positions */
     const float* lval;         /* concatenated values */
+    int32_t explicit_tiles;
 } dsw_hop2_plan;
 
 /* Library version (major*10000 + minor*100 + patch). */

@@ -844,3 +844,41 @@ def test_strided_entry_points_reject_bad_strides():
     assert lib.dsw_rezero_residual_fwd_ld(x.data_ptr(), x.data_ptr(), w.data_ptr(), y.data_ptr(), 16, 6, 6, 0, st) == -5
     with pytest.raises(ValueError):
         F_.rezero_residual(x, x, w, out=torch.empty(2, 8, 9, device=DEV)[..., 1:])   # misaligned slice
+
+
+@pytest.mark.parametrize("sampling,knn,Fin,Fout,K,B,dt", [
+    ("ring", 8, 32, 64, 3, 3, torch.float32),        # whole-forward kernel + fused backward on clustered tiles
+    ("ring", 20, 32, 32, 3, 2, torch.float32),       # k = 20 variants (5 / 3 / 1 slots, two workgroups per CU)
+    ("equiangular", 20, 32, 64, 3, 2, torch.float32),
+    ("equiangular", 20, 64, 32, 4, 2, torch.float32),  # mix-first, K = 4 (second first-hop operand), 256-byte rows
+    ("ring", 20, 64, 128, 5, 2, torch.bfloat16),
+])
+def test_conv_on_non_local_row_orders_takes_clustered_tiles(sampling, knn, Fin, Fout, K, B, dt):
+    """HEALPix ring order / equiangular row-major: strips of consecutive rows do not fit LDS, the plan's tiles are
+    clustered from the graph (explicit row sets) - forward and backward against the fp64 oracle through that path."""
+    from dsw_amd import functional as F_, sphere
+    from modules.layers import ConvCheb
+
+    g = sphere.SphereHealpix(32, nest=False, k=knn) if sampling == "ring" else sphere.SphereEquiangular(nlat=72, nlon=144, k=knn)
+    lap = orc.prepare_laplacian_fixed_lmax(g.L, 1.9)
+    rp, ci, va = orc.csr_arrays_from_coo(lap)
+    V = len(rp) - 1
+    layer = ConvCheb(Fin, Fout, K, laplacian=lap)
+    w = recipes.rand(71, (Fin, K, Fout), np.sqrt(2.0 / (Fin * K)))
+    b = recipes.rand(72, (Fout,), 0.1)
+    layer.set_parameters(torch.from_numpy(w), torch.from_numpy(b))
+    layer = layer.to(DEV).to(dt)
+    plan = F_.get_operator(layer.laplacian).hop2_plan(128)
+    assert plan is not None and plan.explicit_tiles, "expected tiles clustered from the graph"
+    x = recipes.rand(73, (B, V, Fin))
+    gy = recipes.rand(74, (B, V, Fout))
+    y, dx, dw, db = _run_layer(layer, torch.from_numpy(x).to(DEV).to(dt), torch.from_numpy(gy).to(DEV).to(dt))
+    if dt == torch.bfloat16:
+        x, w, b, gy = (torch.from_numpy(a).to(dt).float().numpy() for a in (x, w, b, gy))
+    y64 = orc.cheb_forward_f64(rp, ci, va, x, w, b)
+    dx64, dw64, db64 = orc.cheb_backward_f64(rp, ci, va, x, w, gy, True)
+    tol = TOL_F64 if dt == torch.float32 else TOL_BF16
+    assert orc.max_rel_err(y.float(), y64) <= tol
+    assert orc.max_rel_err(dx.float(), dx64) <= tol
+    assert orc.max_rel_err(dw.float(), dw64) <= 2 * tol
+    assert orc.max_rel_err(db.float(), db64) <= 2 * tol

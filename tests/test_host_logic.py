@@ -294,7 +294,37 @@ def test_hop2_plan_matches_two_plain_hops():
             r2 = 1.5 * (L @ r1) - U + 0.5 * Z2
             np.testing.assert_allclose(y1, r1, atol=1e-12)
             np.testing.assert_allclose(y2, r2, atol=1e-12)
+        # tiles clustered from the graph (any row sets): a partition into <= rows rows each, same two hops
+        for rows in (64, 48):
+            tiles = hop2.cluster_tiles(rp, ci, rows)
+            cover = np.sort(np.concatenate(tiles))
+            assert np.array_equal(cover, np.arange(n)) and max(len(t) for t in tiles) <= rows
+            plan = hop2.build_hop2_plan(rp, ci, va, rows, tiles=tiles)
+            assert plan.explicit_tiles and plan.n_tiles == len(tiles)
+            assert [int(m[5]) for m in plan.tile_meta] == [len(t) for t in tiles]
+            U, Z1, Z1b, Z2 = (rng.standard_normal((n, 3)) for _ in range(4))
+            y1, y2 = hop2.emulate_hop2(plan, U, Z1, Z1b, Z2, 2.0, 1.0, -1.0, 1.5, -1.0, 0.5)
+            r1 = 2.0 * (L @ U) + Z1 - Z1b
+            np.testing.assert_allclose(y1, r1, atol=1e-12)
+            np.testing.assert_allclose(y2, 1.5 * (L @ r1) - U + 0.5 * Z2, atol=1e-12)
+    with pytest.raises(ValueError):
+        hop2.build_hop2_plan(rp, ci, va, 64, tiles=[np.arange(10)])     # not a partition of the rows
 
+
+def test_clustered_tiles_make_non_local_row_orders_compact():
+    """HEALPix RING order and equiangular row-major order: a strip of 64 consecutive rows has a 2-ring several times the
+    tile; the graph clustering brings it down to what a square patch has, so the operator takes the fused two-hop path."""
+    from dsw_amd import hop2, sphere
+
+    for name, L in (("ring", sphere.SphereHealpix(16, nest=False, k=20).L),
+                    ("equiangular", sphere.SphereEquiangular(nlat=48, nlon=96, k=20).L)):
+        L = L.tocsr()
+        rp, ci, va = L.indptr, L.indices, L.data.astype(np.float32)
+        strips = hop2.build_hop2_plan(rp, ci, va, 64)
+        patches = hop2.build_hop2_plan(rp, ci, va, 64, tiles=hop2.cluster_tiles(rp, ci, 64))
+        assert patches.n_tiles <= 1.1 * strips.n_tiles + 2, name
+        assert patches.tile_meta[:, 2].mean() < 0.7 * strips.tile_meta[:, 2].mean(), name
+        assert patches.lds_bytes(128, True) <= 156 * 1024, name
 
 def test_training_driver_config_and_ar_logic():
     """scripts_training/train_synthetic_state.py host logic: config schema, tensor_info, model factory convention and the
