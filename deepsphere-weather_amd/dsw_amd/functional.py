@@ -116,15 +116,19 @@ class CsrOperator:
                         plan = cand
                         break
                 if plan is None:
-                    # clustered tiles: of the tile heights that fit, the one that needs the fewest tiles (a height whose
-                    # tiles had to be halved to respect the neighbourhood caps loses to the next smaller one)
-                    for rows in (64, 48):
+                    # clustered tiles: of the tile heights that fit, the one with the fewest 64-slot gather passes per
+                    # output row (a pass costs the same whether its slots are full or not; a height whose tiles had to
+                    # be halved to respect the neighbourhood caps loses to a smaller one)
+                    best = None
+                    for rows in (64, 56, 48):
                         if self.shape[0] < 8 * rows:
                             continue    # a graph of a few tiles gains nothing from the fused path
                         cand = host_plan(rows, True)
-                        if cand is not None and cand.lds_bytes(row_bytes, single) <= budget and \
-                                (plan is None or cand.n_tiles < plan.n_tiles):
-                            plan = cand
+                        if cand is None or cand.lds_bytes(row_bytes, single) > budget:
+                            continue
+                        cost = cand.gather_passes_per_row()
+                        if best is None or cost < best:
+                            best, plan = cost, cand
                 if plan is not None:
                     break
             self._plans[row_bytes] = None if plan is None else plan.to(self.device)

@@ -71,6 +71,14 @@ class Hop2Plan:
         s += ((self.max_n2 + 3) & ~3) * 4 + 16            # gather list + the tile's loop length
         return (s + 15) & ~15
 
+    def gather_passes_per_row(self, slots: int = 64) -> float:
+        """Passes of ``slots`` row slots the kernel spends per output row (first hop on tile + 1-ring, second hop on the
+        tile) - the cost figure tile heights are compared by."""
+        n1 = self.tile_meta[:, 1].astype(np.int64)
+        rt = self.tile_meta[:, 5].astype(np.int64) if self.explicit_tiles else \
+            np.minimum(self.tile_rows, self.n_rows - np.arange(self.n_tiles) * self.tile_rows)
+        return float((-(-n1 // slots) + -(-rt // slots)).sum()) / float(rt.sum())
+
     def to(self, device):
         """Device-resident copy (cached) + the ctypes struct handed to the C ABI."""
         if self._dev is not None and self._dev[0] == device:
