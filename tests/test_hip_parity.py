@@ -852,6 +852,7 @@ def test_strided_entry_points_reject_bad_strides():
     ("equiangular", 20, 32, 64, 3, 2, torch.float32),
     ("equiangular", 20, 64, 32, 4, 2, torch.float32),  # mix-first, K = 4 (second first-hop operand), 256-byte rows
     ("ring", 20, 64, 128, 5, 2, torch.bfloat16),
+    ("scattered", 10, 32, 64, 3, 2, torch.float32),   # random points on the sphere in RANDOM row order: no structure at all
 ])
 def test_conv_on_non_local_row_orders_takes_clustered_tiles(sampling, knn, Fin, Fout, K, B, dt):
     """HEALPix ring order / equiangular row-major: strips of consecutive rows do not fit LDS, the plan's tiles are
@@ -859,8 +860,15 @@ def test_conv_on_non_local_row_orders_takes_clustered_tiles(sampling, knn, Fin, 
     from dsw_amd import functional as F_, sphere
     from modules.layers import ConvCheb
 
-    g = sphere.SphereHealpix(32, nest=False, k=knn) if sampling == "ring" else sphere.SphereEquiangular(nlat=72, nlon=144, k=knn)
-    lap = orc.prepare_laplacian_fixed_lmax(g.L, 1.9)
+    if sampling == "scattered":
+        rng = np.random.default_rng(5)
+        pts = rng.standard_normal((3000, 3))
+        pts /= np.linalg.norm(pts, axis=1, keepdims=True)
+        graph_l = sphere.knn_graph_laplacian(pts, knn)[1]
+    else:
+        g = sphere.SphereHealpix(32, nest=False, k=knn) if sampling == "ring" else sphere.SphereEquiangular(nlat=72, nlon=144, k=knn)
+        graph_l = g.L
+    lap = orc.prepare_laplacian_fixed_lmax(graph_l, 1.9)
     rp, ci, va = orc.csr_arrays_from_coo(lap)
     V = len(rp) - 1
     layer = ConvCheb(Fin, Fout, K, laplacian=lap)
