@@ -47,26 +47,28 @@ class WeightedMSELoss(nn.MSELoss):
             self.check_weights(weights)
         self.weights = weights
 
-    def forward(self, pred, label):
-        mse = super().forward(pred, label)
-        weights = self.weights
-        n_batch, num_nodes, n_val = mse.shape
-        if weights is None:
-            weights = torch.ones((num_nodes), dtype=mse.dtype, device=mse.device)
-        if num_nodes != len(weights):
+    def _node_weights(self, like, n_nodes):
+        w = self.weights
+        if w is None:
+            return torch.ones(n_nodes, dtype=like.dtype, device=like.device)
+        if len(w) != n_nodes:
             raise ValueError(
-                "The number of weights does not match the the number of pixels. {} != {}".format(len(weights), num_nodes)
+                "The number of weights does not match the the number of pixels. {} != {}".format(len(w), n_nodes)
             )
-        if weights.device != mse.device or weights.dtype != mse.dtype:
-            weights = weights.to(device=mse.device, dtype=mse.dtype)
-            if self.weights is not None:
-                self.weights = weights      # moved once: later calls (and HIP-graph captures) see a resident tensor
-        weighted_mse = mse * weights.view(1, -1, 1)
-        if self.weighted_mse_reduction == "sum":
-            return torch.sum(weighted_mse) * len(weights)
-        if self.weighted_mse_reduction == "mean":
-            return torch.sum(weighted_mse) / torch.sum(weights) / n_batch / n_val
-        return weighted_mse
+        if w.device != like.device or w.dtype != like.dtype:
+            w = self.weights = w.to(device=like.device, dtype=like.dtype)   # moved once: HIP-graph captures see a resident tensor
+        return w
+
+    def forward(self, pred, label):
+        err2 = super().forward(pred, label)                  # element-wise (reduction="none" in the base class)
+        n_points, n_nodes, n_feat = err2.shape
+        w = self._node_weights(err2, n_nodes)
+        weighted = err2 * w.view(1, n_nodes, 1)
+        how = self.weighted_mse_reduction
+        if how == "none":
+            return weighted
+        total = weighted.sum()
+        return total * n_nodes if how == "sum" else total / w.sum() / n_points / n_feat
 
     def check_weights(self, weights):
         if not isinstance(weights, torch.Tensor):
