@@ -890,3 +890,43 @@ def test_conv_on_non_local_row_orders_takes_clustered_tiles(sampling, knn, Fin, 
     assert orc.max_rel_err(dx.float(), dx64) <= tol
     assert orc.max_rel_err(dw.float(), dw64) <= 2 * tol
     assert orc.max_rel_err(db.float(), db64) <= 2 * tol
+
+
+@pytest.mark.parametrize("pool_method", ["interp", "maxval"])
+def test_unet_bf16_storage_tracks_fp32(pool_method):
+    """`model.to(torch.bfloat16)` end to end (every kernel's bf16 variant, the copy-free concatenation on 2-byte rows,
+    operators kept at fp32): output and parameter gradients stay within bf16 rounding of the fp32 run."""
+    import modules.my_models_graph as arch
+    from test_host_logic import build_g5_model
+
+    base, g, names = build_g5_model(DEV)
+    if pool_method != "interp":
+        tensor_info = {
+            "dim_order": {"dynamic": ["sample", "time", "node", "feature"]},
+            "input_n_feature": 6, "output_n_feature": 2, "input_n_time": 3, "output_n_time": 1,
+            "input_shape_info": {"dynamic": {"node": 768}}, "output_shape_info": {"dynamic": {"node": 768}},
+        }
+        other = arch.UNetSpherical(tensor_info, sampling="healpix", sampling_kwargs={"subdivisions": 8, "nest": True},
+                                   kernel_size_conv=3, conv_type="graph", graph_type="knn", knn=20, pool_method=pool_method)
+        sd = {k: v for k, v in base.state_dict().items() if "pool" not in k}
+        other.load_state_dict(sd, strict=False)
+        base = other.to(DEV)
+    x = torch.from_numpy(recipes.rand(501, (2, 3, 768, 6))).to(DEV)
+    target = torch.from_numpy(recipes.rand(502, (2, 1, 768, 2))).to(DEV)
+
+    def run(model, dt):
+        model = model.to(dt)
+        model.zero_grad(set_to_none=True)
+        y = model(x.to(dt))
+        ((y.float() - target) ** 2).mean().backward()
+        return y.detach().float(), {n: p.grad.detach().float().clone() for n, p in model.named_parameters()}
+
+    y32, g32 = run(base, torch.float32)
+    y16, g16 = run(base, torch.bfloat16)
+    assert base.conv1.convblock1.conv.laplacian.dtype == torch.float32      # operators are not rounded by the cast
+    assert torch.isfinite(y16).all()
+    # max-value pooling: bf16 rounding moves the arg-max of near-ties to another fine cell, a discrete change
+    tol_y, tol_g = (6e-2, 0.15) if pool_method == "interp" else (0.25, 0.6)
+    assert orc.max_rel_err(y16, y32.cpu().numpy()) <= tol_y
+    worst = max(float((g16[n] - g32[n]).norm() / (g32[n].norm() + 1e-12)) for n in g32)
+    assert worst <= tol_g, worst
