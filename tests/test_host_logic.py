@@ -599,3 +599,51 @@ def test_skip_slot_is_used_by_the_unet_and_only_once(oracle_backend):
     y2 = model.decode(*enc)
     assert torch.equal(y1.detach(), keep)
     assert orc.max_rel_err(y2.detach(), keep.numpy()) <= 1e-6
+
+
+def test_cluster_tiles_random_graphs_property():
+    """Random sparse graphs (isolated nodes, hubs, several components, asymmetric patterns): `cluster_tiles` always returns
+    a partition into tiles of 1..R rows, with or without neighbourhood caps, and the plan built on it reproduces two
+    plain hops."""
+    from hypothesis import given, settings, strategies as st
+    from dsw_amd import hop2
+
+    @settings(max_examples=25, deadline=None)
+    @given(n=st.integers(5, 400), deg=st.integers(0, 12), seed=st.integers(0, 10_000), R=st.sampled_from([8, 48, 64]),
+           capped=st.booleans())
+    def check(n, deg, seed, R, capped):
+        rng = np.random.default_rng(seed)
+        rows = np.repeat(np.arange(n), rng.integers(0, deg + 1, size=n))
+        cols = rng.integers(0, n, size=rows.size)
+        vals = rng.standard_normal(rows.size)
+        A = sparse.csr_matrix((vals, (rows, cols)), shape=(n, n))
+        A.sum_duplicates()
+        rp, ci, va = A.indptr, A.indices, A.data.astype(np.float32)
+        tiles = hop2.cluster_tiles(rp, ci, R, max_n1=40 if capped else 0, max_n2=90 if capped else 0)
+        assert np.array_equal(np.sort(np.concatenate(tiles)), np.arange(n))
+        assert all(1 <= len(t) <= R for t in tiles)
+        plan = hop2.build_hop2_plan(rp, ci, va, R, tiles=tiles)
+        U = rng.standard_normal((n, 2))
+        y1, y2 = hop2.emulate_hop2(plan, U, None, None, None, 1.0, 0.0, 0.0, 2.0, -1.0, 0.0)
+        L = sparse.csr_matrix((va.astype(np.float64), ci, rp), shape=(n, n))
+        np.testing.assert_allclose(y1, L @ U, atol=1e-10)
+        np.testing.assert_allclose(y2, 2.0 * (L @ (L @ U)) - U, atol=1e-10)
+
+    check()
+
+
+def test_row_stride_helper():
+    from dsw_amd import functional as F_
+
+    buf = torch.zeros(3, 10, 24)
+    assert F_.row_stride(buf) == 24
+    assert F_.row_stride(buf[..., 8:]) == 24 and F_.row_stride(buf[..., :8]) == 24
+    assert F_.row_stride(buf[:, ::2, :]) == 48             # every other row: still rows at a fixed stride, samples back to back
+    assert F_.row_stride(buf[:, :4, :]) is None            # a row range: the sample stride is no longer V * ld
+    assert F_.row_stride(buf.transpose(1, 2)) is None      # channels not contiguous
+    assert F_.row_stride(buf[0]) is None                   # not [B, V, C]
+    assert F_.row_stride(torch.zeros(1, 10, 24)[..., 4:12]) == 24
+    assert F_.row_stride(torch.zeros(2, 1, 16)) == 16
+    slot = F_.skip_slot(torch.zeros(2, 5, 4), 5, 8, 16)
+    assert slot.shape == (2, 5, 16) and F_.row_stride(slot) == 24 and slot.storage_offset() == 8
+    assert F_.skip_slot(torch.zeros(2, 5, 4), 5, 3, 16) is None        # 12-byte left slice: not 16-byte aligned
