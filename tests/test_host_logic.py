@@ -647,3 +647,13 @@ def test_row_stride_helper():
     slot = F_.skip_slot(torch.zeros(2, 5, 4), 5, 8, 16)
     assert slot.shape == (2, 5, 16) and F_.row_stride(slot) == 24 and slot.storage_offset() == 8
     assert F_.skip_slot(torch.zeros(2, 5, 4), 5, 3, 16) is None        # 12-byte left slice: not 16-byte aligned
+
+
+def test_in_tree_library_is_the_product_build():
+    """The library that travels to the GPU box reads no environment variable: the diagnostic switches of csrc/ exist only
+    in a `DSW_BUILD_DIAG=1` build, which must never be what is left in the tree."""
+    from dsw_amd import _native
+
+    blob = open(_native.LIB_PATH, "rb").read()
+    for name in (b"DSW_GEMM_X3", b"DSW_FWD_FUSED", b"DSW_H2_CHUNKS", b"DSW_SPMM_XCD", b"DSW_MIX_FIRST"):
+        assert name not in blob, "diagnostics build in the tree: rebuild with `python -m dsw_amd.build --force`"
