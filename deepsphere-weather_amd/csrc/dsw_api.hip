@@ -247,7 +247,13 @@ int64_t dsw_cheb_bwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t 
         const int64_t S1 = dsw_wgrad_slabs(N, Fin, Fout, 1), SK = dsw_wgrad_slabs(N, Fin, Fout, K);
         const int64_t p1 = (S1 > 0 ? S1 : 1) * (Fin + 1) * Fout * 4;        // one K = 1 launch per order (fallback)
         const int64_t pk = (SK > 0 ? SK : 1) * (K * Fin + 1) * Fout * 4;    // single launch over all orders
-        return d + round_up(p1 > pk ? p1 : pk, 256) + 256;
+        int64_t pm = p1 > pk ? p1 : pk;
+        if (K * Fout <= 64) {   // narrow output: the K planes side by side, one K = 1 launch of width K * Fout
+            const int64_t Sn = dsw_wgrad_slabs(N, Fin, K * Fout, 1);
+            const int64_t pn = (Sn > 0 ? Sn : 1) * (Fin + 1) * K * Fout * 4;
+            if (pn > pm) pm = pn;
+        }
+        return d + round_up(pm, 256) + 256;
     }
     // G_1..G_{K-1} planes, plus two spare planes for the pairwise fused adjoint when K >= 4
     const int64_t g = round_up((K - 1 + (K >= 4 ? 2 : 0)) * N * Fin * elem_size(dtype), 256);

@@ -326,7 +326,24 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_kernel(const WgradParams P
                 const long r = n0 + dr;
                 const int o = o0 + dc4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < WR * BN / 4 && r < n_end) {
+                if (P.dy_planes > 1) {
+                    // narrow mix-first layers: column j of the tile = channel j % F0 of plane j / F0 (plane 0 = dY,
+                    // plane z >= 1 = dY1 + (z - 1) * dy_plane_stride): all K planes of [N, F0] in ONE pass over X
+                    if (e < WR * BN / 4 && r < n_end) {
+                        const int F0 = P.Fout / P.dy_planes;
+                        float t4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int j = o + t;
+                            if (j < P.Fout) {
+                                const int z = j / F0, oo = j - z * F0;
+                                const size_t off = (size_t)r * F0 + oo;
+                                t4[t] = z == 0 ? ld1<BF16>(P.dY, off) : ld1<BF16>(P.dY1, (size_t)(z - 1) * P.dy_plane_stride + off);
+                            }
+                        }
+                        v = make_float4(t4[0], t4[1], t4[2], t4[3]);
+                    }
+                } else if (e < WR * BN / 4 && r < n_end) {
                     const size_t off = (size_t)r * P.Fout + o;
                     if (P.dy_vec && o + 3 < P.Fout) {
                         v = ld4<BF16>(P.dY, off);
@@ -414,7 +431,7 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_kernel(const WgradParams P
 template <bool BF16>
 __global__ __launch_bounds__(256) void cheb_wgrad_reduce_kernel(const float* __restrict__ partial, int S,
                                                                 int Fin, int Fout, int K, void* dW,
-                                                                void* db, int K_out, int k_off) {
+                                                                void* db, int K_out, int k_off, int db_cols = 1 << 30) {
     __shared__ float red[8][32];
     const int Kd = K * Fin;
     const long total = (long)(Kd + 1) * Fout;
@@ -438,7 +455,7 @@ __global__ __launch_bounds__(256) void cheb_wgrad_reduce_kernel(const float* __r
         for (int g = 0; g < 8; ++g) v += red[g][lane_o];
         const int kd = (int)(idx / Fout), o = (int)(idx - (long)kd * Fout);
         if (kd == Kd) {
-            if (db != nullptr) st1<BF16>(db, o, v);
+            if (db != nullptr && o < db_cols) st1<BF16>(db, o, v);   // (planes side by side: only plane 0 is dY)
         } else {
             const int k = kd / Fin, f = kd - k * Fin;
             st1<BF16>(dW, ((size_t)f * K_out + k_off + k) * Fout + o, v);   // dW is [Fin, K_out, Fout]
@@ -640,9 +657,22 @@ int dsw_wgrad_launch(const void* X, const void* T, const void* dY, void* dW, voi
     return dsw_wgrad_launch_ex(X, T, dY, dW, db, partial, N, Fin, Fout, K, dtype, stream, K, 0);
 }
 
+// dy_planes > 1 (narrow mix-first layers, K * F0 <= 64): the dY side is `dy_planes` planes of [N, F0] (plane 0 = dY, the
+// others at dY1 + (z - 1) * N * F0) laid side by side as ONE virtual [N, dy_planes * F0] operand - Fout is that total,
+// K must be 1 - so that dW[f, k, o] = sum_n X[n, f] D_k[n, o] comes out of one pass over X, already in [Fin, K, F0] order.
+static int dsw_wgrad_launch_impl(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
+                                 int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
+                                 int64_t K_out, int64_t k_off, const void* dY1, int dy_planes);
+
 int dsw_wgrad_launch_ex(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
                         int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
                         int64_t K_out, int64_t k_off) {
+    return dsw_wgrad_launch_impl(X, T, dY, dW, db, partial, N, Fin, Fout, K, dtype, stream, K_out, k_off, nullptr, 1);
+}
+
+static int dsw_wgrad_launch_impl(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
+                                 int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
+                                 int64_t K_out, int64_t k_off, const void* dY1, int dy_planes) {
     if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     const int es = dtype == DSW_BF16 ? 2 : 4;
@@ -656,11 +686,15 @@ int dsw_wgrad_launch_ex(const void* X, const void* T, const void* dY, void* dW, 
         const uintptr_t am = (uintptr_t)(4 * es) - 1;
         P.t_vec = (Fin % 4 == 0) && (((uintptr_t)X & am) == 0) && (K == 1 || ((uintptr_t)T & am) == 0);
         P.dy_vec = (Fout % 4 == 0) && (((uintptr_t)dY & am) == 0);
+        if (dy_planes > 1) {
+            P.dY1 = dY1; P.dy_planes = dy_planes; P.dy_plane_stride = (size_t)N * (size_t)(Fout / dy_planes);
+            P.dy_vec = 0;
+        }
         const int ntiles = (int)K * P.tiles_per_plane;
         // waves per workgroup: spread the (k, f) tiles evenly over the fewest groups of <= 4
         const int groups = (ntiles + 3) / 4;
         const int nw = (ntiles + groups - 1) / groups;
-        const bool aligned = P.t_vec && P.dy_vec && (Fin % 32 == 0) && (Fout % BN == 0) && (N % WR == 0);
+        const bool aligned = dy_planes <= 1 && P.t_vec && P.dy_vec && (Fin % 32 == 0) && (Fout % BN == 0) && (N % WR == 0);
         const int64_t otiles = (Fout + BN - 1) / BN;
         {   // bf16 matrix pipe (3-way split for fp32 storage) when the problem is aligned
             int rc3 = DSW_OK;
@@ -706,13 +740,14 @@ int dsw_wgrad_launch_ex(const void* X, const void* T, const void* dY, void* dW, 
     }
 reduce:
     const long total = (long)(K * Fin + 1) * Fout;
+    const int db_cols = dy_planes > 1 ? (int)(Fout / dy_planes) : (int)Fout;
     dim3 rgrid((unsigned)((total + 31) / 32));
     if (dtype == DSW_F32)
         hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, stream, partial, (int)S,
-                           (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off);
+                           (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols);
     else
         hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, stream, partial, (int)S,
-                           (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off);
+                           (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols);
     return dsw_check_launch();
 }
 
@@ -755,6 +790,8 @@ int dsw_wgrad_mixfirst_launch(const void* X, const void* dY, const void* D, void
             return dsw_check_launch();
         }
     }
+    if (N > 0 && K > 1 && K * Fout <= BN)   // narrow output (e.g. the model's last layer, 64 -> 2): all K planes in ONE pass over X
+        return dsw_wgrad_launch_impl(X, nullptr, dY, dW, db, partial, N, Fin, K * Fout, 1, dtype, stream, 1, 0, D, (int)K);
     int rc = DSW_OK;
     const size_t dplane = (size_t)N * Fout * es;
     for (int64_t k = 0; k < K && rc == DSW_OK; ++k)
