@@ -427,12 +427,13 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_kernel(const WgradParams P
 }
 
 // dW[f, k, o] = sum_s partial[s][k*Fin + f][o];  db[o] = sum_s partial[s][Kd][o]
-// 256 threads = 32 outputs x 8 slab groups; fixed summation order -> bit-reproducible.
-template <bool BF16>
-__global__ __launch_bounds__(256) void cheb_wgrad_reduce_kernel(const float* __restrict__ partial, int S,
-                                                                int Fin, int Fout, int K, void* dW,
-                                                                void* db, int K_out, int k_off, int db_cols = 1 << 30) {
-    __shared__ float red[8][32];
+// 32 * NG threads = 32 outputs x NG slab groups; fixed summation order -> bit-reproducible.  NG = 8 for wide layers
+// (hundreds of blocks), 32 for narrow ones: a 64 -> 2 layer has 130 outputs = 5 blocks, each walking ~770 slabs.
+template <bool BF16, int NG = 8>
+__global__ __launch_bounds__(32 * NG) void cheb_wgrad_reduce_kernel(const float* __restrict__ partial, int S,
+                                                                    int Fin, int Fout, int K, void* dW,
+                                                                    void* db, int K_out, int k_off, int db_cols = 1 << 30) {
+    __shared__ float red[NG][32];
     const int Kd = K * Fin;
     const long total = (long)(Kd + 1) * Fout;
     const int lane_o = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -441,9 +442,9 @@ __global__ __launch_bounds__(256) void cheb_wgrad_reduce_kernel(const float* __r
     float s0 = 0.f, s1 = 0.f;
     if (idx < total) {
         int s = grp;
-        for (; s + 8 < S; s += 16) {
+        for (; s + NG < S; s += 2 * NG) {
             s0 += partial[(size_t)s * slab + idx];
-            s1 += partial[(size_t)(s + 8) * slab + idx];
+            s1 += partial[(size_t)(s + NG) * slab + idx];
         }
         if (s < S) s0 += partial[(size_t)s * slab + idx];
     }
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(256) void cheb_wgrad_reduce_kernel(const float* __r
     if (grp == 0 && idx < total) {
         float v = 0.f;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) v += red[g][lane_o];
+        for (int g = 0; g < NG; ++g) v += red[g][lane_o];
         const int kd = (int)(idx / Fout), o = (int)(idx - (long)kd * Fout);
         if (kd == Kd) {
             if (db != nullptr && o < db_cols) st1<BF16>(db, o, v);   // (planes side by side: only plane 0 is dY)
@@ -742,6 +743,15 @@ reduce:
     const long total = (long)(K * Fin + 1) * Fout;
     const int db_cols = dy_planes > 1 ? (int)(Fout / dy_planes) : (int)Fout;
     dim3 rgrid((unsigned)((total + 31) / 32));
+    if (total <= 4096 && S > 64) {   // few outputs, many slabs: 32 slab groups per block
+        if (dtype == DSW_F32)
+            hipLaunchKernelGGL((cheb_wgrad_reduce_kernel<false, 32>), rgrid, dim3(1024), 0, stream, partial, (int)S,
+                               (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols);
+        else
+            hipLaunchKernelGGL((cheb_wgrad_reduce_kernel<true, 32>), rgrid, dim3(1024), 0, stream, partial, (int)S,
+                               (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols);
+        return dsw_check_launch();
+    }
     if (dtype == DSW_F32)
         hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, stream, partial, (int)S,
                            (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols);
