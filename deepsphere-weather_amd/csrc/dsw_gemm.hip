@@ -22,6 +22,15 @@ int dsw_ts_gemm_x3_try_launch(const TsGemmParams& P, int nt, int col_tiles, int 
 
 // streaming-W variant for wide fp32 layers (dsw_gemm_x3s.hip); returns 1 if it took the launch
 int dsw_ts_gemm_x3s_try_launch(const TsGemmParams& P, hipStream_t stream, int* rc);
+// narrow layers (K * Fout <= 16) on the vector ALU (dsw_narrow.hip)
+int dsw_narrow_fwd_try(const void* X, const void* W, const void* bias, void* Z0, void* Zrest, int64_t N, int64_t Fin,
+                       int64_t Fout, int64_t K, int dtype, hipStream_t stream, int relu, int* rc);
+int dsw_narrow_dgrad_try(const void* dY, const void* D, const void* W, void* dX, int64_t N, int64_t Fin, int64_t Fout,
+                         int64_t K, int dtype, hipStream_t stream, int* rc);
+int dsw_narrow_wgrad_try(const void* X, const void* dY, const void* D, void* dW, void* db, float* partial,
+                         int64_t max_blocks, int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype,
+                         hipStream_t stream, int* rc);
+int64_t dsw_wgrad_slabs(int64_t N, int64_t Fin, int64_t Fout, int64_t K);
 
 // wgrad on the bf16 matrix pipe (dsw_wgrad_x3.hip); returns 1 if it took the launch
 int dsw_wgrad_x3_try_launch(WgradParams& P, int bf16, int64_t max_slabs, int64_t* S_out, hipStream_t stream, int* rc);
@@ -542,6 +551,10 @@ int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* 
                        int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int relu) {
     if (N == 0) return DSW_OK;
     if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
+    if (K == 1) {
+        int rcn = DSW_OK;
+        if (dsw_narrow_fwd_try(X, W, bias, Y, nullptr, N, Fin, Fout, 1, dtype, stream, relu, &rcn)) return rcn;
+    }
     const int es = dtype == DSW_BF16 ? 2 : 4;
     TsGemmParams P{};
     P.A0 = X; P.A1 = T; P.a_plane_stride = (size_t)N * Fin; P.lda = (int)Fin;
@@ -564,6 +577,10 @@ int dsw_mix_dgrad_launch(const void* dY, const void* W, void* G0, void* Grest, i
                          int64_t Fout, int64_t K, int dtype, hipStream_t stream) {
     if (N == 0) return DSW_OK;
     if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
+    if (K == 1) {
+        int rcn = DSW_OK;
+        if (dsw_narrow_dgrad_try(dY, nullptr, W, G0, N, Fin, Fout, 1, dtype, stream, &rcn)) return rcn;
+    }
     const int es = dtype == DSW_BF16 ? 2 : 4;
     TsGemmParams P{};
     P.A0 = dY; P.A1 = dY; P.a_plane_stride = 0; P.lda = (int)Fout; P.n_planes_a = 1; P.kd_per_plane = (int)Fout;
@@ -588,6 +605,10 @@ int dsw_zmix_launch(const void* X, const void* W, const void* bias, void* Z0, vo
                     int64_t Fout, int64_t K, int dtype, hipStream_t stream) {
     if (N == 0) return DSW_OK;
     if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
+    {
+        int rcn = DSW_OK;
+        if (dsw_narrow_fwd_try(X, W, bias, Z0, Zrest, N, Fin, Fout, K, dtype, stream, 0, &rcn)) return rcn;
+    }
     const int es = dtype == DSW_BF16 ? 2 : 4;
     TsGemmParams P{};
     P.A0 = X; P.A1 = X; P.a_plane_stride = 0; P.lda = (int)Fin; P.n_planes_a = 1; P.kd_per_plane = (int)Fin;
@@ -607,6 +628,10 @@ int dsw_zdgrad_launch(const void* dY, const void* D, const void* W, void* dX, in
                       int64_t K, int dtype, hipStream_t stream) {
     if (N == 0) return DSW_OK;
     if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
+    {
+        int rcn = DSW_OK;
+        if (dsw_narrow_dgrad_try(dY, D, W, dX, N, Fin, Fout, K, dtype, stream, &rcn)) return rcn;
+    }
     const int es = dtype == DSW_BF16 ? 2 : 4;
     TsGemmParams P{};
     P.A0 = dY; P.A1 = D; P.a_plane_stride = (size_t)N * Fout; P.lda = (int)Fout; P.n_planes_a = (int)K;
@@ -676,6 +701,12 @@ static int dsw_wgrad_launch_impl(const void* X, const void* T, const void* dY, v
                                  int64_t K_out, int64_t k_off, const void* dY1, int dy_planes) {
     if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
+    if (N > 0 && K == 1 && K_out == 1 && k_off == 0 && dy_planes <= 1 && Fout <= 16) {   // narrow dense map (residual linear)
+        int rcn = DSW_OK;
+        if (dsw_narrow_wgrad_try(X, dY, nullptr, dW, db, partial, dsw_wgrad_slabs(N, Fin, Fout, 1), N, Fin, Fout, 1, dtype,
+                                 stream, &rcn))
+            return rcn;
+    }
     const int es = dtype == DSW_BF16 ? 2 : 4;
     int64_t rps = 0;
     int64_t S = N > 0 ? 1 : 0;
@@ -761,6 +792,29 @@ reduce:
     return dsw_check_launch();
 }
 
+// partial [S][K * Fin + 1][Fout] -> dW / db (used by dsw_narrow.hip as well)
+int dsw_wgrad_reduce_launch(const float* partial, int64_t S, int64_t Fin, int64_t Fout, int64_t K, void* dW, void* db,
+                            int64_t K_out, int64_t k_off, int db_cols, int dtype, hipStream_t stream) {
+    const long total = (long)(K * Fin + 1) * Fout;
+    dim3 rgrid((unsigned)((total + 31) / 32));
+    if (total <= 4096 && S > 64) {
+        if (dtype == DSW_F32)
+            hipLaunchKernelGGL((cheb_wgrad_reduce_kernel<false, 32>), rgrid, dim3(1024), 0, stream, partial, (int)S,
+                               (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols);
+        else
+            hipLaunchKernelGGL((cheb_wgrad_reduce_kernel<true, 32>), rgrid, dim3(1024), 0, stream, partial, (int)S,
+                               (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols);
+        return dsw_check_launch();
+    }
+    if (dtype == DSW_F32)
+        hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, stream, partial, (int)S,
+                           (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols);
+    else
+        hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, stream, partial, (int)S,
+                           (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols);
+    return dsw_check_launch();
+}
+
 // mix-first backward: dW[f, k, o] = sum_n X[n, f] * D_k[n, o] (D_0 = dY, D_1.. = planes of [N, Fout]), db = column sums
 // of dY.  One launch over (slab, f-tiles, (k, o-tile)) when the problem is aligned (bf16-pipe kernels); otherwise one
 // plain K = 1 wgrad per Chebyshev order.
@@ -799,6 +853,12 @@ int dsw_wgrad_mixfirst_launch(const void* X, const void* dY, const void* D, void
                                    (int)Fin, (int)Fout, (int)K, dW, db, (int)K, 0);
             return dsw_check_launch();
         }
+    }
+    if (N > 0 && K > 1 && K * Fout <= 16) {  // a handful of output columns: vector-ALU kernel (dsw_narrow.hip)
+        int rcn = DSW_OK;
+        if (dsw_narrow_wgrad_try(X, dY, D, dW, db, partial, dsw_wgrad_slabs(N, Fin, K * Fout, 1), N, Fin, Fout, K, dtype,
+                                 stream, &rcn))
+            return rcn;
     }
     if (N > 0 && K > 1 && K * Fout <= BN)   // narrow output (e.g. the model's last layer, 64 -> 2): all K planes in ONE pass over X
         return dsw_wgrad_launch_impl(X, nullptr, dY, dW, db, partial, N, Fin, K * Fout, 1, dtype, stream, 1, 0, D, (int)K);

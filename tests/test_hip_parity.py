@@ -193,6 +193,11 @@ CASES = [
     (768, 2, 64, 64, 2, False, "healpix"),
     (1000, 3, 32, 64, 3, True, "irregular"),  # N % 32 != 0 -> falls back to the separate kernels; same answer
     (1024, 2, 32, 64, 3, True, "irregular"),
+    # narrow outputs (K * Fout <= 16): vector-ALU kernels of dsw_narrow.hip, forward / dgrad / wgrad
+    (768, 2, 128, 4, 3, True, "healpix"),
+    (192, 3, 32, 5, 2, False, "healpix"),
+    (1000, 2, 256, 1, 3, True, "irregular"),  # ragged row count, one output channel
+    (768, 5, 16, 3, 4, True, "healpix"),      # 4 lanes per row
 ]
 
 
@@ -440,7 +445,8 @@ def test_fused_recurrences_equal_unfused(K):
     assert orc.max_rel_err(res[True][0], Tref) <= TOL_F64
 
 
-@pytest.mark.parametrize("N,Fin,Fout", [(768 * 3, 256, 128), (1000, 48, 20), (64, 512, 256), (768 * 3, 128, 64), (1024, 96, 64)])
+@pytest.mark.parametrize("N,Fin,Fout", [(768 * 3, 256, 128), (1000, 48, 20), (64, 512, 256), (768 * 3, 128, 64), (1024, 96, 64),
+                                         (1537, 64, 2), (98304, 64, 2), (999, 128, 16), (40, 32, 7)])   # last four: narrow outputs
 def test_dense_mix_vs_f64(N, Fin, Fout):
     """K = 1 channel mix (residual branch of ResBlock) against an fp64 matmul: forward, dX, dW, db."""
     from dsw_amd import functional as F_
