@@ -98,7 +98,7 @@ static __device__ __forceinline__ void split_store(unsigned char* __restrict__ s
 }
 
 // acc += sum_j val[j] * buf[pos[j]] over the first W entries of one ELL row: fp32 values + u8 list POSITIONS of the rows
-// in the staging buffer (W % 4 == 0 storage, W even in use, padded with {own row, 0}); bufc = staging buffer + this
+// in the staging buffer (W % 4 == 0 storage, any W <= that in use, padded with {own row, 0}); bufc = staging buffer + this
 // lane's byte offset in a row.  One byte per index (the 2-ring of a 64-row tile has < 256 rows) is what keeps the
 // workgroup under 80 KB at nside = 64 (115 / 175 rows in the fattest tile).
 // 4 rows in flight per batch (the two-hop kernel takes 8): 36 registers hold the W fragments for the whole workgroup,
@@ -120,7 +120,7 @@ static __device__ __forceinline__ void gather_ell(const unsigned char* __restric
             acc[2] = fmaf(vv[t], d[t].z, acc[2]); acc[3] = fmaf(vv[t], d[t].w, acc[3]);
         }
     }
-    if (j < W) {   // W is even: one last pair
+    if (j + 2 <= W) {   // a pair
         const unsigned w = *reinterpret_cast<const unsigned short*>(row_idx + j);
         const float2 v0 = *reinterpret_cast<const float2*>(row_val + j);
         const float4 d0 = *reinterpret_cast<const float4*>(bufc + ((w & 0xffu) << 7));
@@ -129,6 +129,14 @@ static __device__ __forceinline__ void gather_ell(const unsigned char* __restric
         acc[2] = fmaf(v0.x, d0.z, acc[2]); acc[3] = fmaf(v0.x, d0.w, acc[3]);
         acc[0] = fmaf(v0.y, d1.x, acc[0]); acc[1] = fmaf(v0.y, d1.y, acc[1]);
         acc[2] = fmaf(v0.y, d1.z, acc[2]); acc[3] = fmaf(v0.y, d1.w, acc[3]);
+        j += 2;
+    }
+    if (j < W) {        // odd loop length (HEALPix k = 8: 9 entries in 96 % of the rows): a single last entry
+        const unsigned w = row_idx[j];
+        const float v0 = row_val[j];
+        const float4 d0 = *reinterpret_cast<const float4*>(bufc + (w << 7));
+        acc[0] = fmaf(v0, d0.x, acc[0]); acc[1] = fmaf(v0, d0.y, acc[1]);
+        acc[2] = fmaf(v0, d0.z, acc[2]); acc[3] = fmaf(v0, d0.w, acc[3]);
     }
 }
 
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
     if (P.bias != nullptr) bias4 = *reinterpret_cast<const f32x4_t*>(P.bias + 16 * cbk + 4 * kc);
 
     __syncthreads();   // ELL complete (and lrp in bufT dead)
-    const int Wt = (*tile_w + 1) & ~1;
+    const int Wt = *tile_w;                           // gather loop length of this tile: its longest row (may be odd)
     // the first sample's rows (the loop writes the NEXT sample's rows after its barrier C)
 #pragma unroll
     for (int k = 0; k < NST; ++k) {

@@ -94,7 +94,7 @@ struct Hop2Args {
 };
 
 
-// acc += sum_j val[j] * buf[idx[j]] over the first W entries of one ELL row (W even, padded with {own row, 0}); the row
+// acc += sum_j val[j] * buf[idx[j]] over the first W entries of one ELL row (padded with {own row, 0}); the row
 // INDICES (position in the staged list, u16) and the VALUES (fp32) are two separate arrays: 6 bytes per entry instead
 // of 8 - what lets the k = 20 stencil (23 entries on 155 rows) keep two workgroups on a CU.  bufc = staging buffer +
 // this lane's byte offset inside a row.  The chain index -> address -> data -> fma is a sequence of dependent LDS
@@ -146,7 +146,7 @@ static __device__ __forceinline__ void gather_ell(const unsigned short* __restri
             for (int c = 0; c < N; ++c) acc[c] = fmav(v, x[c], acc[c]);
         }
     }
-    if (j < W) {   // W is even: one last pair
+    if (j + 2 <= W) {   // a pair
         const unsigned i0 = *reinterpret_cast<const unsigned*>(row_idx + j);
         const float2 v0 = *reinterpret_cast<const float2*>(row_val + j);
         const uint4 d0 = *reinterpret_cast<const uint4*>(bufc + (BYTEOFF ? (i0 & 0xffffu) : (i0 & 0xffffu) * row_bytes));
@@ -159,6 +159,16 @@ static __device__ __forceinline__ void gather_ell(const unsigned short* __restri
             acc[c] = fmav(va, x0[c], acc[c]);
             acc[c] = fmav(vb, x1[c], acc[c]);
         }
+        j += 2;
+    }
+    if (j < W) {        // odd loop length (HEALPix k = 8: 9 entries in 96 % of the rows): a single last entry
+        const unsigned i0 = row_idx[j];
+        const uint4 d0 = *reinterpret_cast<const uint4*>(bufc + (BYTEOFF ? i0 : i0 * row_bytes));
+        VT x0[N];
+        R::unpack(d0, x0);
+        const VT va = R::splat(row_val[j]);
+#pragma unroll
+        for (int c = 0; c < N; ++c) acc[c] = fmav(va, x0[c], acc[c]);
     }
 }
 
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && HZB && NS1 > 2) ? 2 : 4)) void s
         ell_val[t] = live ? val : 0.f;
     }
     __syncthreads();   // ELL complete (and lrp in bufT dead) before the first phase 1
-    const int Wt = (*tile_w + 1) & ~1;              // gather loop length of this tile (<= W, even)
+    const int Wt = *tile_w;                         // gather loop length of this tile: its longest row (<= W, may be odd)
 
     for (int b = b_begin; b < b_end; ++b) {
         unsigned char* bufX = ((b - b_begin) & 1) ? bufX1 : bufX0;
