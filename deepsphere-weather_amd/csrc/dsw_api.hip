@@ -6,7 +6,8 @@
 // internal launchers (dsw_spmm.hip / dsw_gemm.hip)
 int dsw_spmm_launch_ld(const int* rowptr, const int* colind, const float* vals, int64_t v_out, int64_t v_in,
                        const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t B, int64_t C, float alpha, const void* Z,
-                       float beta, const void* Z2, float gamma, int dtype, hipStream_t stream, int hints = 0);
+                       float beta, const void* Z2, float gamma, int dtype, hipStream_t stream, int hints = 0,
+                       int64_t ldz = 0);
 int dsw_spmm_launch(const int* rowptr, const int* colind, const float* vals, int64_t v_out, int64_t v_in,
                     const void* X, void* Y, int64_t B, int64_t C, float alpha, const void* Z, float beta,
                     const void* Z2, float gamma, int dtype, hipStream_t stream, int hints = 0);
@@ -85,13 +86,13 @@ int dsw_spmm_csr(const int32_t* rowptr, const int32_t* colind, const float* vals
 
 int dsw_spmm_csr_ld(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t v_out, int64_t v_in,
                     int64_t nnz, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t B, int64_t C, float alpha,
-                    const void* Z, float beta, const void* Z2, float gamma, int dtype, dsw_stream_t stream) {
-    if (v_out < 0 || v_in < 0 || nnz < 0 || B < 0 || C < 0 || ldx < C || ldy < C) return DSW_ERR_BAD_ARG;
+                    const void* Z, int64_t ldz, float beta, const void* Z2, float gamma, int dtype, dsw_stream_t stream) {
+    if (v_out < 0 || v_in < 0 || nnz < 0 || B < 0 || C < 0 || ldx < C || ldy < C || (Z && ldz < C)) return DSW_ERR_BAD_ARG;
     if (v_out == 0 || B == 0 || C == 0) return DSW_OK;
     if (!rowptr || !X || !Y || (nnz > 0 && (!colind || !vals))) return DSW_ERR_BAD_ARG;
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     return dsw_spmm_launch_ld(rowptr, colind, vals, v_out, v_in, X, ldx, Y, ldy, B, C, alpha, Z, beta, Z2, gamma, dtype,
-                              (hipStream_t)stream);
+                              (hipStream_t)stream, 0, Z ? ldz : C);
 }
 
 int dsw_spmm2_fused(const dsw_hop2_plan* plan, int64_t V, const void* U, const void* Z1, const void* Z1b,

@@ -448,16 +448,18 @@ __global__ __launch_bounds__(32 * NG) void cheb_wgrad_reduce_kernel(const float*
     const int lane_o = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const long idx = (long)blockIdx.x * 32 + lane_o;
     const size_t slab = (size_t)(Kd + 1) * Fout;
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (idx < total) {
         int s = grp;
-        for (; s + NG < S; s += 2 * NG) {
+        for (; s + 3 * NG < S; s += 4 * NG) {     // four loads in flight per lane
             s0 += partial[(size_t)s * slab + idx];
             s1 += partial[(size_t)(s + NG) * slab + idx];
+            s2 += partial[(size_t)(s + 2 * NG) * slab + idx];
+            s3 += partial[(size_t)(s + 3 * NG) * slab + idx];
         }
-        if (s < S) s0 += partial[(size_t)s * slab + idx];
+        for (; s < S; s += NG) s0 += partial[(size_t)s * slab + idx];
     }
-    red[grp][lane_o] = s0 + s1;
+    red[grp][lane_o] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (grp == 0 && idx < total) {
         float v = 0.f;
@@ -476,6 +478,8 @@ __global__ __launch_bounds__(32 * NG) void cheb_wgrad_reduce_kernel(const float*
 }  // namespace
 
 // ------------------------------- host-side launchers (internal) ------------------------------
+int dsw_wgrad_reduce_launch(const float* partial, int64_t S, int64_t Fin, int64_t Fout, int64_t K, void* dW, void* db,
+                            int64_t K_out, int64_t k_off, int db_cols, int dtype, hipStream_t stream);
 template <bool BF16, int NT>
 static int launch_ts_gemm_nt(const TsGemmParams& P, int col_tiles, hipStream_t stream) {
     constexpr int BNT = 32 * NT;
@@ -771,25 +775,8 @@ static int dsw_wgrad_launch_impl(const void* X, const void* T, const void* dY, v
         if (rc != DSW_OK) return rc;
     }
 reduce:
-    const long total = (long)(K * Fin + 1) * Fout;
     const int db_cols = dy_planes > 1 ? (int)(Fout / dy_planes) : (int)Fout;
-    dim3 rgrid((unsigned)((total + 31) / 32));
-    if (total <= 4096 && S > 64) {   // few outputs, many slabs: 32 slab groups per block
-        if (dtype == DSW_F32)
-            hipLaunchKernelGGL((cheb_wgrad_reduce_kernel<false, 32>), rgrid, dim3(1024), 0, stream, partial, (int)S,
-                               (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols);
-        else
-            hipLaunchKernelGGL((cheb_wgrad_reduce_kernel<true, 32>), rgrid, dim3(1024), 0, stream, partial, (int)S,
-                               (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols);
-        return dsw_check_launch();
-    }
-    if (dtype == DSW_F32)
-        hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, stream, partial, (int)S,
-                           (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols);
-    else
-        hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, stream, partial, (int)S,
-                           (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols);
-    return dsw_check_launch();
+    return dsw_wgrad_reduce_launch(partial, S, Fin, Fout, K, dW, db, K_out, k_off, db_cols, dtype, stream);
 }
 
 // partial [S][K * Fin + 1][Fout] -> dW / db (used by dsw_narrow.hip as well)
@@ -797,7 +784,7 @@ int dsw_wgrad_reduce_launch(const float* partial, int64_t S, int64_t Fin, int64_
                             int64_t K_out, int64_t k_off, int db_cols, int dtype, hipStream_t stream) {
     const long total = (long)(K * Fin + 1) * Fout;
     dim3 rgrid((unsigned)((total + 31) / 32));
-    if (total <= 4096 && S > 64) {
+    if (total <= 16384 && S > 64) {   // few outputs (<= 512 blocks), many slabs: 32 slab groups per block
         if (dtype == DSW_F32)
             hipLaunchKernelGGL((cheb_wgrad_reduce_kernel<false, 32>), rgrid, dim3(1024), 0, stream, partial, (int)S,
                                (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols);
@@ -843,15 +830,7 @@ int dsw_wgrad_mixfirst_launch(const void* X, const void* dY, const void* D, void
         if (aligned && dsw_wgrad_x3_try_launch(P, dtype == DSW_BF16 ? 1 : 0, wgrad_max_slabs(Fin, Fout, K), &S3, stream,
                                                &rc3)) {
             if (rc3 != DSW_OK) return rc3;
-            const long total = (long)(K * Fin + 1) * Fout;
-            dim3 rgrid((unsigned)((total + 31) / 32));
-            if (dtype == DSW_F32)
-                hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, stream, partial, (int)S3,
-                                   (int)Fin, (int)Fout, (int)K, dW, db, (int)K, 0);
-            else
-                hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, stream, partial, (int)S3,
-                                   (int)Fin, (int)Fout, (int)K, dW, db, (int)K, 0);
-            return dsw_check_launch();
+            return dsw_wgrad_reduce_launch(partial, S3, Fin, Fout, K, dW, db, K, 0, 1 << 30, dtype, stream);
         }
     }
     if (N > 0 && K > 1 && K * Fout <= 16) {  // a handful of output columns: vector-ALU kernel (dsw_narrow.hip)
@@ -893,14 +872,6 @@ int dsw_bwd_gemm_fused_try(const void* X, const void* T, const void* W, const vo
     int64_t S = 0;
     if (!dsw_wgrad_dgrad_fused_try_launch(P, dtype == DSW_BF16 ? 1 : 0, wgrad_max_slabs(Fin, Fout, K), &S, stream, rc)) return 0;
     if (*rc != DSW_OK) return 1;
-    const long total = (long)(K * Fin + 1) * Fout;
-    dim3 rgrid((unsigned)((total + 31) / 32));
-    if (dtype == DSW_F32)
-        hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, stream, partial, (int)S, (int)Fin,
-                           (int)Fout, (int)K, dW, db, (int)K, 0);
-    else
-        hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, stream, partial, (int)S, (int)Fin,
-                           (int)Fout, (int)K, dW, db, (int)K, 0);
-    *rc = dsw_check_launch();
+    *rc = dsw_wgrad_reduce_launch(partial, S, Fin, Fout, K, dW, db, K, 0, 1 << 30, dtype, stream);
     return 1;
 }

@@ -94,9 +94,9 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit(
     const int* __restrict__ rowptr, const int* __restrict__ colind, const float* __restrict__ vals,
     const void* __restrict__ X, void* Y, const void* Z, const void* Z2,
     float alpha, float beta, float gamma,
-    int v_out, int v_in, int C, int cpr, int B, long row_blocks, int xcd_swizzle, int ldx, int ldy) {
+    int v_out, int v_in, int C, int cpr, int B, long row_blocks, int xcd_swizzle, int ldx, int ldy, int ldz) {
     // ldx / ldy: elements between consecutive rows of X / Y (>= C: a channel slice of a wider node-major tensor, e.g.
-    // one half of the decoder's concatenation buffer); Z / Z2 are always dense [B, v_out, C]
+    // one half of the decoder's concatenation buffer); ldz: the same for Z; Z2 is always dense [B, v_out, C]
     using V = Vec<BF16, VEC>;
     // XCD-aware block order: hardware block i runs on XCD i % 8 (each XCD has a private 4 MiB L2).
     // Remap so that every XCD walks ONE contiguous range of (batch group, row block) pairs: the
@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit(
         for (int j = 0; j < VEC; ++j) o[j] = alpha * acc[i][j];
         if (Z != nullptr) {
             float z[VEC];
-            if (xcd_swizzle & 2) V::load_nt(Z, off, z); else V::load(Z, off, z);
+            const size_t offz = ((size_t)(b0 + i) * v_out + row) * (size_t)ldz + c0;
+            if (xcd_swizzle & 2) V::load_nt(Z, offz, z); else V::load(Z, offz, z);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) o[j] = fmaf(beta, z[j], o[j]);
         }
@@ -286,7 +287,7 @@ int launch_tiled(const int* rowptr, const int* colind, const float* vals, const 
 template <bool BF16, int VEC, int NB>
 int launch_rowsplit(const int* rowptr, const int* colind, const float* vals, const void* X, void* Y,
                     const void* Z, const void* Z2, float alpha, float beta, float gamma, int v_out,
-                    int v_in, int C, int B, hipStream_t stream, int hints = 0, int ldx = 0, int ldy = 0) {
+                    int v_in, int C, int B, hipStream_t stream, int hints = 0, int ldx = 0, int ldy = 0, int ldz = 0) {
     const int cpr = C / VEC;
     const long threads = (long)v_out * cpr;
     static const char* bs_env = dsw_diag_env("DSW_SPMM_BLOCK");   // diagnostics: threads per block (64..1024)
@@ -299,7 +300,7 @@ int launch_rowsplit(const int* rowptr, const int* colind, const float* vals, con
     dim3 grid((unsigned)(row_blocks * bgroups));
     hipLaunchKernelGGL((spmm_csr_rowsplit<BF16, VEC, NB>), grid, dim3(bs), 0, stream, rowptr, colind,
                        vals, X, Y, Z, Z2, alpha, beta, gamma, v_out, v_in, C, cpr, B, row_blocks, swz, ldx > 0 ? ldx : C,
-                       ldy > 0 ? ldy : C);
+                       ldy > 0 ? ldy : C, ldz > 0 ? ldz : C);
     return dsw_check_launch();
 }
 
@@ -308,17 +309,18 @@ int launch_rowsplit(const int* rowptr, const int* colind, const float* vals, con
 // Internal C++ entry used by dsw_api.hip
 int dsw_spmm_launch_ld(const int* rowptr, const int* colind, const float* vals, int64_t v_out, int64_t v_in,
                        const void* X, int64_t ldx_, void* Y, int64_t ldy_, int64_t B, int64_t C, float alpha, const void* Z,
-                       float beta, const void* Z2, float gamma, int dtype, hipStream_t stream, int hints) {
-    if (ldx_ < C || ldy_ < C || ldx_ > INT32_MAX || ldy_ > INT32_MAX) return DSW_ERR_BAD_ARG;
-    const int ldx = (int)ldx_, ldy = (int)ldy_;
-    const bool dense = ldx == C && ldy == C;
+                       float beta, const void* Z2, float gamma, int dtype, hipStream_t stream, int hints, int64_t ldz_) {
+    if (ldz_ <= 0) ldz_ = C;
+    if (ldx_ < C || ldy_ < C || ldz_ < C || ldx_ > INT32_MAX || ldy_ > INT32_MAX || ldz_ > INT32_MAX) return DSW_ERR_BAD_ARG;
+    const int ldx = (int)ldx_, ldy = (int)ldy_, ldz = (int)ldz_;
+    const bool dense = ldx == C && ldy == C && ldz == C;
     if (v_out <= 0 || v_in <= 0 || B <= 0 || C <= 0) return (v_out == 0 || B == 0) ? DSW_OK : DSW_ERR_BAD_ARG;
     if (v_out > INT32_MAX || v_in > INT32_MAX || C > INT32_MAX || B > 65535 * 4) return DSW_ERR_BAD_ARG;
     if (Z == nullptr) beta = 0.f;
     if (Z2 == nullptr) gamma = 0.f;
     const int vec_ = dtype == DSW_BF16 ? 8 : 4;
     const bool al = dsw_aligned16(X) && dsw_aligned16(Y) && (Z == nullptr || dsw_aligned16(Z)) &&
-                    (Z2 == nullptr || dsw_aligned16(Z2)) && ldx % vec_ == 0 && ldy % vec_ == 0;
+                    (Z2 == nullptr || dsw_aligned16(Z2)) && ldx % vec_ == 0 && ldy % vec_ == 0 && ldz % vec_ == 0;
     const int vo = (int)v_out, vi = (int)v_in, c = (int)C, b = (int)B;
     // kernel choice: LDS-tiled when a >=64-row tile of one sample fits 32 KiB and lanes divide evenly
     static const char* force = dsw_diag_env("DSW_SPMM_KERNEL");  // "rowsplit" | "tiled" (diagnostics only)
@@ -345,22 +347,22 @@ int dsw_spmm_launch_ld(const int* rowptr, const int* colind, const float* vals, 
     const int nbf = nbs ? atoi(nbs) : 0;
     if (dtype == DSW_F32) {
         if (al && c % 4 == 0) {
-            if (nbf == 1) return launch_rowsplit<false, 4, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
-            if (nbf == 2) return launch_rowsplit<false, 4, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
-            if (b >= 4) return launch_rowsplit<false, 4, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
-            if (b >= 2) return launch_rowsplit<false, 4, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
-            return launch_rowsplit<false, 4, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
+            if (nbf == 1) return launch_rowsplit<false, 4, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
+            if (nbf == 2) return launch_rowsplit<false, 4, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
+            if (b >= 4) return launch_rowsplit<false, 4, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
+            if (b >= 2) return launch_rowsplit<false, 4, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
+            return launch_rowsplit<false, 4, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
         }
-        if (b >= 4) return launch_rowsplit<false, 1, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
-        return launch_rowsplit<false, 1, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
+        if (b >= 4) return launch_rowsplit<false, 1, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
+        return launch_rowsplit<false, 1, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
     }
     if (dtype == DSW_BF16) {
         if (al && c % 8 == 0) {
-            if (b >= 2) return launch_rowsplit<true, 8, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
-            return launch_rowsplit<true, 8, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
+            if (b >= 2) return launch_rowsplit<true, 8, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
+            return launch_rowsplit<true, 8, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
         }
-        if (b >= 4) return launch_rowsplit<true, 1, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
-        return launch_rowsplit<true, 1, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy);
+        if (b >= 4) return launch_rowsplit<true, 1, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
+        return launch_rowsplit<true, 1, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
     }
     return DSW_ERR_BAD_DTYPE;
 }
@@ -369,5 +371,5 @@ int dsw_spmm_launch(const int* rowptr, const int* colind, const float* vals, int
                     const void* X, void* Y, int64_t B, int64_t C, float alpha, const void* Z, float beta,
                     const void* Z2, float gamma, int dtype, hipStream_t stream, int hints) {
     return dsw_spmm_launch_ld(rowptr, colind, vals, v_out, v_in, X, C, Y, C, B, C, alpha, Z, beta, Z2, gamma, dtype, stream,
-                              hints);
+                              hints, C);
 }

@@ -32,7 +32,7 @@ SIGNATURES = {
     ),
     "dsw_spmm_csr_ld": (
         _int,
-        [_i32p, _i32p, _f32p, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _f32, _vp, _f32, _vp, _f32, _int, _vp],
+        [_i32p, _i32p, _f32p, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _f32, _vp, _i64, _f32, _vp, _f32, _int, _vp],
     ),
     "dsw_spmm2_fused": (
         _int,

@@ -250,15 +250,17 @@ class _HipBackend:
     name = "hip"
 
     def spmm(self, op, x, alpha=1.0, z=None, beta=0.0, z2=None, gamma=0.0, out=None):
-        """``x`` / ``out``: dense ``[B, V, C]`` or row-strided channel slices of wider tensors (see ``row_stride``)."""
+        """``x`` / ``out`` / ``z``: dense ``[B, V, C]`` or row-strided channel slices of wider tensors (see ``row_stride``)."""
         lib = _native.load()
         B, v_in, C = x.shape
         assert v_in == op.shape[1]
         y = out if out is not None else torch.empty((B, op.shape[0], C), dtype=x.dtype, device=x.device)
         ldx, ldy = row_stride(x), row_stride(y)
-        assert ldx is not None and ldy is not None and y.shape == (B, op.shape[0], C)
+        ldz = C if z is None else row_stride(z)
+        assert ldx is not None and ldy is not None and ldz is not None and y.shape == (B, op.shape[0], C)
+        assert z is None or z.shape == y.shape
         with torch.cuda.device(x.device):
-            if ldx == C and ldy == C:
+            if ldx == C and ldy == C and ldz == C:
                 rc = lib.dsw_spmm_csr(
                     op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), op.shape[0], op.shape[1],
                     op.nnz, x.data_ptr(), y.data_ptr(), B, C, alpha, _ptr(z), beta, _ptr(z2), gamma,
@@ -267,7 +269,7 @@ class _HipBackend:
             else:
                 rc = lib.dsw_spmm_csr_ld(
                     op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), op.shape[0], op.shape[1],
-                    op.nnz, x.data_ptr(), ldx, y.data_ptr(), ldy, B, C, alpha, _ptr(z), beta, _ptr(z2), gamma,
+                    op.nnz, x.data_ptr(), ldx, y.data_ptr(), ldy, B, C, alpha, _ptr(z), ldz, beta, _ptr(z2), gamma,
                     _DTYPES[x.dtype], _stream(x),
                 )
         _native.check(rc, "dsw_spmm_csr")
@@ -556,6 +558,30 @@ class _RemapFn(torch.autograd.Function):
         return ctx.be.spmm(ctx.op.transpose(), dy if _rows_ok(dy) else dy.contiguous()), None, None
 
 
+class _RemapForkFn(torch.autograd.Function):
+    """``(x, M x)`` for a tensor with a second consumer (the U-Net's skip tensors feed the pooling AND the decoder's
+    concatenation): autograd delivers the second consumer's gradient here, and the transposed product adds it in its
+    epilogue (``dX = g_other + M^T dY``, one pass) instead of a separate read-read-write ``add`` over the tensor."""
+
+    @staticmethod
+    def forward(ctx, x, op):
+        be = _backend_for(x)
+        ctx.op = op
+        ctx.be = be
+        return x.view_as(x), be.spmm(op, x if _rows_ok(x) else x.contiguous())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_x, dy):
+        if dy is None:
+            return g_x, None
+        dy = dy if _rows_ok(dy) else dy.contiguous()
+        if g_x is None:
+            return ctx.be.spmm(ctx.op.transpose(), dy), None
+        g_x = g_x if _rows_ok(g_x) else g_x.contiguous()
+        return ctx.be.spmm(ctx.op.transpose(), dy, z=g_x, beta=1.0), None
+
+
 class _ConcatInPlaceFn(torch.autograd.Function):
     """``torch.cat((left, right), dim=2)`` when ``left`` and ``right`` already ARE the two channel slices of ``buf``:
     no data moves forward, backward hands out the two slices of the gradient."""
@@ -691,6 +717,18 @@ def sparse_remap(op: CsrOperator, x: torch.Tensor, out: torch.Tensor = None) -> 
         raise ValueError(f"remap matrix has {op.shape[1]} source nodes, input has {x.shape[1]}")
     _check_dtype(x)
     return _RemapFn.apply(x, op, _check_out(out, (x.shape[0], op.shape[0], x.shape[2]), x))
+
+
+def sparse_remap_fork(op: CsrOperator, x: torch.Tensor):
+    """``(x_again, sparse_remap(op, x))``.  Give ``x_again`` to every OTHER consumer of ``x``: same values and storage,
+    and the gradient those consumers send back is added inside the backward product of the remap instead of by an
+    ``add`` of autograd's gradient accumulation (the skip tensors of the U-Net: my_models_graph.py:504-545)."""
+    if x.dim() != 3:
+        raise ValueError("expected input [B, V, F]")
+    if x.shape[1] != op.shape[1]:
+        raise ValueError(f"remap matrix has {op.shape[1]} source nodes, input has {x.shape[1]}")
+    _check_dtype(x)
+    return _RemapForkFn.apply(x, op)
 
 
 def _alias(t: torch.Tensor, offset: int, size, stride) -> torch.Tensor:

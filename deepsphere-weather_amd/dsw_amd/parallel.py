@@ -81,6 +81,19 @@ def broadcast_module_state(module, src: int = 0, group=None):
     return module
 
 
+def _is_permuted_dense(t: torch.Tensor) -> bool:
+    """True when `t` covers `t.numel()` consecutive elements of its storage in some dimension order (a transposed /
+    permuted contiguous tensor)."""
+    expect = 1
+    for size, stride in sorted(zip(t.shape, t.stride()), key=lambda ss: ss[1]):
+        if size == 1:
+            continue
+        if stride != expect:
+            return False
+        expect *= size
+    return True
+
+
 class GradBucket:
     """The parameter gradients of one replica as ONE flat HBM buffer, averaged across ranks in place.
 
@@ -114,7 +127,11 @@ class GradBucket:
         off = start = 0
         members = []
         for p in order:
-            self.views[p] = self.bucket[off:off + p.numel()].view_as(p)
+            seg = self.bucket[off:off + p.numel()]
+            # the gradient view has the parameter's own (dense) strides, e.g. the column-major residual-branch weights:
+            # autograd then accumulates into it without a layout change
+            dense = not p.is_contiguous() and _is_permuted_dense(p)
+            self.views[p] = seg.as_strided(p.shape, p.stride()) if dense else seg.view_as(p)
             off += p.numel()
             members.append(p)
             if (off - start) * self.bucket.element_size() >= chunk_bytes:

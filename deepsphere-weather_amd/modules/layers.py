@@ -279,15 +279,28 @@ class RemapBlock(_Fp32OperatorMixin, torch.nn.Module):
         """``out`` (extension): a preallocated ``[B, V_dst, F]`` channel slice of a wider tensor to write into."""
         return _F.sparse_remap(_F.get_operator(self.remap_matrix), x, out=out)
 
+    def forward_fork(self, x):
+        """``(x_again, forward(x))`` (extension) for an input that has a second consumer, e.g. the skip connection of a
+        U-Net: hand ``x_again`` to that consumer and its gradient is added inside this layer's backward product."""
+        return _F.sparse_remap_fork(_F.get_operator(self.remap_matrix), x)
+
     def process_remap_matrix(self, mat):
         return convert_to_torch_sparse(mat)
 
 
-class GeneralAvgPool(RemapBlock):
-    """Interpolation (area-average) pooling; returns ``(x, None)`` (no source indices)."""
+class _IndexlessPool(RemapBlock):
+    """Pooling layers of the remap family return ``(x, None)`` (there are no source indices to hand to the unpooling)."""
 
     def forward(self, x, *args, **kwargs):
         return super().forward(x, *args, **kwargs), None
+
+    def forward_fork(self, x):
+        x_again, y = super().forward_fork(x)
+        return x_again, (y, None)
+
+
+class GeneralAvgPool(_IndexlessPool):
+    """Interpolation (area-average) pooling; returns ``(x, None)`` (no source indices)."""
 
 
 class GeneralAvgUnpool(RemapBlock):
@@ -313,11 +326,8 @@ def _argmax_selector(mat, axis):
     return sel.coalesce()
 
 
-class GeneralMaxAreaPool(RemapBlock):
+class GeneralMaxAreaPool(_IndexlessPool):
     """Pooling that copies, per coarse cell, the fine cell with the largest overlap area."""
-
-    def forward(self, x, *args, **kwargs):
-        return super().forward(x, *args, **kwargs), None
 
     def process_remap_matrix(self, mat):
         return _argmax_selector(mat, axis=1)
@@ -339,6 +349,7 @@ class GeneralMaxValPool(RemapBlock):
     the size; :meth:`reference_index` converts, and :class:`GeneralMaxValUnpool` accepts either form."""
 
     supports_out = False
+    forward_fork = None    # the selection gradient is a scatter, not a product with an epilogue
 
     def forward(self, x, *args, **kwargs):
         return _F.maxval_pool(_F.get_operator(self.remap_matrix), x)

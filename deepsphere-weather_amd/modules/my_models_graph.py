@@ -86,8 +86,26 @@ class ConvBlock(GeneralConvBlock):
 
 
 class _NodeLinear(Linear):
-    """``torch.nn.Linear`` (same parameters / state_dict entries) whose per-node map runs on the path's own
-    MFMA GEMM kernels (the K = 1 channel mix) instead of a rocBLAS call."""
+    """``torch.nn.Linear`` (same parameters / state_dict entries, same initial values) whose per-node map runs on the
+    path's own MFMA GEMM kernels (the K = 1 channel mix) instead of a rocBLAS call.
+
+    ``weight`` keeps ``Linear``'s shape ``[out, in]`` but is laid out column-major (strides ``(1, out)``): the kernels read
+    ``weight.t()`` = a dense ``[in, out]`` matrix, and the gradient they produce already has the parameter's strides, so
+    neither direction launches a transpose copy (two 5 us launches per residual block and step otherwise)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._lay_out_weight()
+
+    def _lay_out_weight(self):
+        w = self.weight
+        if w.dim() == 2 and w.stride() != (1, w.shape[0]):
+            self.weight = torch.nn.Parameter(w.detach().t().contiguous().t(), requires_grad=w.requires_grad)
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)     # .to() / .cuda() keep dense strides; anything that did not is re-laid
+        self._lay_out_weight()
+        return out
 
     def forward(self, x):
         return dsw_functional.dense_mix(x, self.weight.t(), self.bias)   # raises on CPU tensors like every layer here
@@ -230,11 +248,21 @@ class UNetSpherical(UNet, torch.nn.Module):
         # the skip tensors are born inside the decoder's concatenation buffers (their right-hand channel slice; the
         # unpooling fills the left one in `decode`): no `torch.cat` copy forward, no slice copies backward
         x_enc1 = self.conv1(x, out=self._skip_slot(x, self.unpool1, self.uconv1, self.conv1))
-        x_enc2_ini, idx1 = self.pool1(x_enc1)
+        x_enc1, (x_enc2_ini, idx1) = self._pool_and_skip(self.pool1, x_enc1)
         x_enc2 = self.conv2(x_enc2_ini, out=self._skip_slot(x_enc2_ini, self.unpool2, self.uconv2, self.conv2))
-        x_enc3_ini, idx2 = self.pool2(x_enc2)
+        x_enc2, (x_enc3_ini, idx2) = self._pool_and_skip(self.pool2, x_enc2)
         x_enc3 = self.conv3(x_enc3_ini)
         return x_enc3, x_enc2, x_enc1, idx2, idx1, x_last_timestep
+
+    @staticmethod
+    def _pool_and_skip(pool, x):
+        """``(x for the skip connection, pool(x))``.  The tensor has two consumers; pooling layers with ``forward_fork``
+        add the skip connection's gradient inside their own backward product instead of leaving it to an autograd
+        ``add`` (same values; the sum is formed in the other order)."""
+        fork = getattr(pool, "forward_fork", None)
+        if fork is not None and x.requires_grad and torch.is_grad_enabled():
+            return fork(x)
+        return x, pool(x)
 
     concat_in_place = True   # False: skip tensors are ordinary tensors and the decoder calls torch.cat (A/B runs)
 

@@ -78,14 +78,16 @@ int dsw_spmm_csr(const int32_t* rowptr, const int32_t* colind, const float* vals
                  float alpha, const void* Z, float beta, const void* Z2, float gamma,
                  int dtype, dsw_stream_t stream);
 
-/* The same product on channel SLICES of wider node-major tensors: ldx / ldy = elements between consecutive rows of
- * X / Y (>= C; Z and Z2 stay dense [B, v_out, C]).  The U-Net decoder's `torch.cat((unpooled, skip), dim=2)`
- * (my_models_graph.py:528-545) disappears with it: the unpooling writes the left half of the concatenation buffer
- * (ldy = its width), the encoder block wrote the right half (dsw_rezero_residual_fwd_ld), the pooling reads that half
- * (ldx), and the backward of the unpooling reads its half of the buffer's gradient (ldx). */
+/* The same product on channel SLICES of wider node-major tensors: ldx / ldy / ldz = elements between consecutive rows
+ * of X / Y / Z (>= C; Z2 stays dense [B, v_out, C]; ldz is ignored when Z is NULL).  The U-Net decoder's
+ * `torch.cat((unpooled, skip), dim=2)` (my_models_graph.py:528-545) disappears with it: the unpooling writes the left
+ * half of the concatenation buffer (ldy = its width), the encoder block wrote the right half
+ * (dsw_rezero_residual_fwd_ld), the pooling reads that half (ldx), the backward of the unpooling reads its half of the
+ * buffer's gradient (ldx), and the backward of the pooling adds the skip half of that gradient in its epilogue
+ * (Z with ldz, beta = 1: the gradient accumulation of a tensor with two consumers without a separate add pass). */
 int dsw_spmm_csr_ld(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t v_out, int64_t v_in,
                     int64_t nnz, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t B, int64_t C, float alpha,
-                    const void* Z, float beta, const void* Z2, float gamma, int dtype, dsw_stream_t stream);
+                    const void* Z, int64_t ldz, float beta, const void* Z2, float gamma, int dtype, dsw_stream_t stream);
 
 /* Two applications of one square operator A (V x V) in a single launch, per sample:
  *     Y1 = a1 * (A U)  + b1 * Z1 + d1 * Z1b

@@ -138,7 +138,10 @@ def _bucket_worker(rank, world, port, out):
     model = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(),
                                 torch.nn.Linear(16, 3))
     model[4].bias.requires_grad_(False)                       # a frozen parameter stays out of the bucket
+    # a column-major weight, like the residual-branch maps of the U-Net: its gradient view must have its strides
+    model[0].weight = torch.nn.Parameter(model[0].weight.detach().t().contiguous().t())
     bucket = GradBucket(model.parameters(), chunk_bytes=200, overlap=True)   # 5 params -> three chunks
+    assert bucket.views[model[0].weight].stride() == model[0].weight.stride() == (1, 16)
     n_chunks = len(bucket.chunks)
     opt = torch.optim.SGD(model.parameters(), lr=0.1)
     launched_in_backward = []

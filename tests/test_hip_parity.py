@@ -838,6 +838,48 @@ def test_concat_in_place_strided_kernels(dt):
     check_concat_in_place(DEV, dt, TOL_F64 if dt == torch.float32 else TOL_BF16)
 
 
+@pytest.mark.parametrize("dt,C,width", [(torch.float32, 32, 96), (torch.float32, 20, 20), (torch.bfloat16, 64, 192),
+                                        (torch.float32, 6, 10)])
+def test_remap_fork_adds_the_other_consumers_gradient_in_the_product(dt, C, width):
+    """`sparse_remap_fork`: forward = plain remap, backward dX = g_other + M^T dY with g_other a channel slice of a wider
+    gradient tensor (strided Z operand of dsw_spmm_csr_ld; C = 6 of 10 floats: a slice the strided entry point does not take, copied first) -
+    against fp64."""
+    from dsw_amd import functional as F_
+
+    Vs, Vd, B = 768, 192, 3
+    from scipy import sparse as sp
+    rng = np.random.default_rng(4)
+    dense = (rng.random((Vd, Vs)) < 0.02) * rng.random((Vd, Vs))
+    dense[np.arange(Vd), rng.integers(0, Vs, Vd)] += 0.5             # no empty rows; a few source nodes stay unused
+    pool_mat = sp.csr_matrix(dense.astype(np.float32))
+    from modules.layers import convert_to_torch_sparse
+    op = F_.get_operator(convert_to_torch_sparse(pool_mat).to(DEV))
+    x = torch.from_numpy(recipes.rand(81, (B, Vs, C))).to(DEV).to(dt).requires_grad_(True)
+    wide = torch.from_numpy(recipes.rand(82, (B, Vs, width))).to(DEV).to(dt)
+    g_other = wide[..., width - C:]                                   # what a concatenation's backward hands out
+    gy = torch.from_numpy(recipes.rand(83, (B, Vd, C))).to(DEV).to(dt)
+    x_again, y = F_.sparse_remap_fork(op, x)
+    assert x_again.data_ptr() == x.data_ptr() and x_again.stride() == x.stride()
+    torch.autograd.backward([x_again, y], [g_other, gy])
+    M = pool_mat.astype(np.float64)
+    x64 = x.detach().float().cpu().numpy().astype(np.float64)
+    y64 = np.stack([M @ x64[b] for b in range(B)])
+    dx64 = g_other.float().cpu().numpy().astype(np.float64) + np.stack(
+        [M.T @ gy[b].float().cpu().numpy().astype(np.float64) for b in range(B)])
+    tol = TOL_F64 if dt == torch.float32 else TOL_BF16
+    assert orc.max_rel_err(y.float(), y64) <= tol
+    assert orc.max_rel_err(x.grad.float(), dx64) <= tol
+    # only one of the two consumers sends a gradient
+    x.grad = None
+    x_again, y = F_.sparse_remap_fork(op, x)
+    y.backward(gy)
+    assert orc.max_rel_err(x.grad.float(), dx64 - g_other.float().cpu().numpy()) <= tol
+    x.grad = None
+    x_again, y = F_.sparse_remap_fork(op, x)
+    x_again.backward(g_other)
+    assert torch.equal(x.grad, g_other)
+
+
 def test_strided_entry_points_reject_bad_strides():
     from dsw_amd import functional as F_, _native
 

@@ -601,6 +601,29 @@ def test_skip_slot_is_used_by_the_unet_and_only_once(oracle_backend):
     assert orc.max_rel_err(y2.detach(), keep.numpy()) <= 1e-6
 
 
+def test_residual_branch_linear_is_a_drop_in_for_nn_linear():
+    """`_NodeLinear` keeps torch.nn.Linear's parameter names, shapes, initial values and state_dict round trip; only the
+    weight's memory order differs (column-major, so that neither pass needs a transpose copy)."""
+    from modules.my_models_graph import _NodeLinear
+    torch.manual_seed(3)
+    mine = _NodeLinear(6, 4)
+    torch.manual_seed(3)
+    ref = torch.nn.Linear(6, 4)
+    assert [k for k, _ in mine.named_parameters()] == [k for k, _ in ref.named_parameters()]
+    assert torch.equal(mine.weight, ref.weight) and torch.equal(mine.bias, ref.bias)
+    assert mine.weight.shape == ref.weight.shape and mine.weight.t().is_contiguous() and mine.weight.is_leaf
+    ref2 = torch.nn.Linear(6, 4)
+    mine.load_state_dict(ref2.state_dict())
+    assert torch.equal(mine.weight, ref2.weight) and mine.weight.t().is_contiguous()
+    ref.load_state_dict(mine.state_dict())
+    assert torch.equal(ref.weight, ref2.weight) and ref.weight.is_contiguous()
+    half = mine.to(torch.bfloat16)
+    assert half.weight.t().is_contiguous() and half.weight.dtype == torch.bfloat16
+    mine = mine.float()
+    (torch.randn(5, 6) @ mine.weight.t()).sum().backward()
+    assert mine.weight.grad.stride() == mine.weight.stride()        # what autograd hands the optimizer needs no re-layout
+
+
 def test_cluster_tiles_random_graphs_property():
     """Random sparse graphs (isolated nodes, hubs, several components, asymmetric patterns): `cluster_tiles` always returns
     a partition into tiles of 1..R rows, with or without neighbourhood caps, and the plan built on it reproduces two
