@@ -24,6 +24,17 @@
 #include "../../include/dsw_hip.h"
 
 namespace {
+// tile-row operands are touched once per launch (Z2 read, Y1 / Y2 written): nontemporal; the gathered operands (U on
+// the 2-ring, Z1 on the 1-ring) are shared by neighbouring tiles and stay on the cached path
+typedef unsigned u32x4_nt __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ void st16(char* p, const uint4& v) {
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, v), reinterpret_cast<u32x4_nt*>(p));
+}
+template <typename T4>
+static __device__ __forceinline__ T4 ld16_once(const char* p) {
+    return __builtin_bit_cast(T4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p)));
+}
+
 
 constexpr int NTHREADS = 512;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in VGPRs
@@ -303,7 +314,7 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && HZB && NS1 > 2) ? 2 : 4)) void s
         }
         if constexpr (HZ2) {
 #pragma unroll
-            for (int k = 0; k < NS2; ++k) cz2[k] = *reinterpret_cast<const u32x4*>(P.Z2 + sample + offZ2[k]);
+            for (int k = 0; k < NS2; ++k) cz2[k] = ld16_once<u32x4>(P.Z2 + sample + offZ2[k]);
         }
         {
             const size_t sb = vbase(b + 1 < b_end ? b + 1 : b);   // tail: harmless re-read
@@ -338,7 +349,7 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && HZB && NS1 > 2) ? 2 : 4)) void s
                 const uint4 packed = R::pack(o);
                 *reinterpret_cast<uint4*>(bufT + (size_t)i * P.row_bytes + cb) = packed;
                 if (k < NS2 && P.Y1 != nullptr && i < rt)
-                    *reinterpret_cast<uint4*>(P.Y1 + sample + offZ2[k < NS2 ? k : 0]) = packed;
+                    st16(P.Y1 + sample + offZ2[k < NS2 ? k : 0], packed);
             }
         }
         __syncthreads();
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && HZB && NS1 > 2) ? 2 : 4)) void s
 #pragma unroll
                     for (int j = 0; j < N; ++j) o[j] = fmav(R::splat(P.c2), z[j], o[j]);
                 }
-                *reinterpret_cast<uint4*>(P.Y2 + sample + offZ2[k]) = R::pack(o);
+                st16(P.Y2 + sample + offZ2[k], R::pack(o));
             }
         }
         // double-buffered: no barrier here - the next iteration writes the OTHER bufX, and its barrier orders bufT reuse

@@ -32,7 +32,7 @@ static __device__ __forceinline__ float trunc_bf16(float f) {
     return __uint_as_float(__float_as_uint(f) & 0xffff0000u);
 }
 
-template <bool BF16IO>
+template <bool BF16IO, bool NT = false>
 static __device__ __forceinline__ f32x4 load4(const void* p, size_t i) {
     if constexpr (BF16IO) {
         const u32x2 t = *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(p) + i);
@@ -41,6 +41,7 @@ static __device__ __forceinline__ f32x4 load4(const void* p, size_t i) {
         v[2] = __uint_as_float(t[1] << 16); v[3] = __uint_as_float(t[1] & 0xffff0000u);
         return v;
     } else {
+        if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(static_cast<const float*>(p) + i));
         return *reinterpret_cast<const f32x4*>(static_cast<const float*>(p) + i);
     }
 }
@@ -157,12 +158,12 @@ __global__ __launch_bounds__(64 * NW, FUSE ? 2 : 1) void cheb_wgrad_x3_kernel(co
     auto fetch = [&](long n0, f32x4 (&drt)[4], f32x4 (&drd)[RD]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            drt[i] = load4<BF16IO>(A, abase + (size_t)(n0 + tr + 8 * i) * P.Fin + f0 + tc4);
+            drt[i] = load4<BF16IO, FUSE>(A, abase + (size_t)(n0 + tr + 8 * i) * P.Fin + f0 + tc4);   // FUSE: every row is read by exactly one workgroup - nontemporal (NS step -2.7 % same-box)
 #pragma unroll
         for (int i = 0; i < RD; ++i) {
             int e = tid + NT_ * i;
             if (DV % NT_ != 0) e = e < DV ? e : DV - 1;
-            drd[i] = load4<BF16IO>(dYp, dybase + (size_t)(n0 + e / CQ) * P.Fout + o0 + (e % CQ) * 4);
+            drd[i] = load4<BF16IO, FUSE>(dYp, dybase + (size_t)(n0 + e / CQ) * P.Fout + o0 + (e % CQ) * 4);
         }
     };
 
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(64 * NW, FUSE ? 2 : 1) void cheb_wgrad_x3_kernel(co
                 const long nrow = n_begin + ci * WR + 4 * half;
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    Gp[(size_t)(nrow + (i & 3) + 8 * (i >> 2)) * P.Fin + f0 + l31] = g[i];
+                    __builtin_nontemporal_store(g[i], &Gp[(size_t)(nrow + (i & 3) + 8 * (i >> 2)) * P.Fin + f0 + l31]);
             }
         }
     };
