@@ -265,7 +265,8 @@ __global__ __launch_bounds__(64 * NW, FUSE ? 2 : 1) void cheb_wgrad_x3_kernel(co
                 const long nrow = n_begin + ci * WR + 4 * half;
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    __builtin_nontemporal_store(g[i], &Gp[(size_t)(nrow + (i & 3) + 8 * (i >> 2)) * P.Fin + f0 + l31]);
+                    // plain stores: the adjoint pair reads these planes next, partly out of the Infinity Cache
+                    Gp[(size_t)(nrow + (i & 3) + 8 * (i >> 2)) * P.Fin + f0 + l31] = g[i];
             }
         }
     };
