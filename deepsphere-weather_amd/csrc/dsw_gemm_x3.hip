@@ -4,6 +4,16 @@
 using namespace dsw_gemm;
 
 namespace {
+// STREAM variants (IO bit 3): the A operand is larger than half of the 256 MB Infinity Cache - its rows are read with
+// nontemporal loads (they cannot stay resident anyway, and streaming them past the caches leaves those to the W panel
+// and to what the neighbouring kernels exchange).  Same-box: C3 -1.8 %, C5 -1.7 %, k = 20 north-star -2.3 %; the UNet's
+// layers (A <= 75 MB, re-read by up to three column tiles out of L2) keep cached loads (+0.3 % with nontemporal ones).
+template <bool NT>
+static __device__ __forceinline__ f32x4 lda16(const void* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return *reinterpret_cast<const f32x4*>(p);
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // fp32 contraction on the bf16 matrix pipe ("x3 split"): the fp32 MFMA runs at the VALU rate
@@ -49,6 +59,7 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3_kernel(const TsGemmParams
     constexpr bool BF16IO = (IO & 1) != 0;
     constexpr bool WIDE = (IO & 2) != 0;
     constexpr bool EPI = (IO & 4) != 0;
+    constexpr bool STREAM = (IO & 8) != 0;
     static_assert(!EPI || (BF16IO && NT % 2 == 0), "packed epilogue: bf16 rows, tile pairs");
     constexpr int BK = WIDE ? 64 : dsw_gemm::BK;     // reduction elements per chunk (shadows the namespace constant)
     constexpr int BNT = 32 * NT;
@@ -131,7 +142,7 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3_kernel(const TsGemmParams
             r = r < P.M ? r : P.M - 1;
             const size_t off = abase + (size_t)r * P.lda + k0 + (WIDE ? 2 * ac4 : ac4);
             if constexpr (WIDE) {
-                dra[i] = *reinterpret_cast<const f32x4*>(static_cast<const uint16_t*>(A) + off);   // 8 raw bf16
+                dra[i] = lda16<STREAM>(static_cast<const uint16_t*>(A) + off);   // 8 raw bf16
             } else if constexpr (BF16IO) {
                 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                 const u32x2 t = *reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(A) + off);
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3_kernel(const TsGemmParams
                 v[2] = __uint_as_float(t[1] << 16); v[3] = __uint_as_float(t[1] & 0xffff0000u);
                 dra[i] = v;
             } else {
-                dra[i] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(A) + off);
+                dra[i] = lda16<STREAM>(static_cast<const float*>(A) + off);
             }
         }
     };
@@ -327,13 +338,15 @@ int dsw_ts_gemm_x3_try_launch(const TsGemmParams& P, int nt, int col_tiles, int 
     // one workgroup per CU only -> 8-wave workgroups (256-row tiles) if they still fit
     const bool big = 2 * lds > 160 * 1024 && (size_t)2 * BM * LDA * 4 + panel <= 160 * 1024;
     if (big) lds = (size_t)2 * BM * LDA * 4 + panel;
+    const size_t a_bytes = (size_t)P.M * (size_t)P.n_planes_a * P.kd_per_plane * (bf16 ? 2 : 4);
+    const bool strm = a_bytes >= ((size_t)128 << 20);
+#define DSW_X3_L(NT_, NS_, IO_, NWV_)                                                      \
+    (strm ? launch_x3<NT_, NS_, (IO_) | 8, NWV_>(P, col_tiles, lds, stream)               \
+          : launch_x3<NT_, NS_, IO_, NWV_>(P, col_tiles, lds, stream))
 #define DSW_X3_IO(NT_, NWV_)                                                               \
-    (wide ? launch_x3<NT_, 1, 3, NWV_>(P, col_tiles, lds, stream)                          \
-          : bf16 ? launch_x3<NT_, 1, 1, NWV_>(P, col_tiles, lds, stream)                   \
-                 : launch_x3<NT_, 3, 0, NWV_>(P, col_tiles, lds, stream))
+    (wide ? DSW_X3_L(NT_, 1, 3, NWV_) : bf16 ? DSW_X3_L(NT_, 1, 1, NWV_) : DSW_X3_L(NT_, 3, 0, NWV_))
 #define DSW_X3_EPI(NT_, NWV_)                                                              \
-    (wide ? launch_x3<NT_, 1, 7, NWV_>(P, col_tiles, lds, stream)                          \
-          : launch_x3<NT_, 1, 5, NWV_>(P, col_tiles, lds, stream))
+    (wide ? DSW_X3_L(NT_, 1, 7, NWV_) : DSW_X3_L(NT_, 1, 5, NWV_))
 #define DSW_X3_CASE(NT_)                                                                   \
     case NT_:                                                                              \
         *rc = big ? DSW_X3_IO(NT_, 8) : DSW_X3_IO(NT_, 4);                                 \
@@ -347,6 +360,7 @@ int dsw_ts_gemm_x3_try_launch(const TsGemmParams& P, int nt, int col_tiles, int 
         DSW_X3_CASE(1) DSW_X3_CASE_E(2) DSW_X3_CASE(3) DSW_X3_CASE_E(4)
     }
 #undef DSW_X3_EPI
+#undef DSW_X3_L
 #undef DSW_X3_CASE_E
 #undef DSW_X3_IO
 #undef DSW_X3_CASE
