@@ -172,25 +172,27 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None):
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream()
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0.record(stream)
-    for _ in range(steps):
-        launches()
-    t1.record(stream)
-    torch.cuda.synchronize()
+
+    def timed(fn):   # median of three HIP-event regions of `steps` calls each (seconds per call)
+        reps = []
+        for _ in range(3):
+            t0.record(stream)
+            for _ in range(steps):
+                fn()
+            t1.record(stream)
+            torch.cuda.synchronize()
+            reps.append(t0.elapsed_time(t1) * 1e-3 / steps)
+        return sorted(reps)[1]
+
     hops = 2 * (K - 1)                      # operator applications per step (forward + adjoint)
     pairs = (K - 1 + 1) // 2                # launches of a pairwise-fused recurrence
     n_launch = ((K - 1) if pp is None else pairs) + ((K - 1) if ppt is None else pairs)
-    avg_s = t0.elapsed_time(t1) * 1e-3 / (steps * n_launch)
+    avg_s = timed(launches) / n_launch
     fwd_b, bwd_b = spmm_algorithmic_bytes(E, Lb, K)
     bytes_per_launch = (fwd_b + bwd_b) / n_launch
     achieved = bytes_per_launch / avg_s / 1e9
     # forward recurrence alone (the north-star gate)
-    t0.record(stream)
-    for _ in range(steps):
-        fwd()
-    t1.record(stream)
-    torch.cuda.synchronize()
-    fwd_s = t0.elapsed_time(t1) * 1e-3 / steps
+    fwd_s = timed(fwd)
     traffic = None   # HBM bytes per launch from the PMC passes (tools/prof_pmc.sh + tools/make_traffic_json.py)
     tpath = os.path.join(REPO, "profiles", "spmm_traffic.json")
     if traffic_key and os.path.exists(tpath):
@@ -240,6 +242,7 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None):
                            "(2 x FETCH_SIZE + WRITE_SIZE, tools/prof_pmc.sh); a committed measurement, not read in this run"),
         "real_traffic_GBs": (None if traffic is None else round(traffic / avg_s / 1e9, 1)),
         "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 2),
+        "launch_timing": "HIP events on the launch stream; median of 3 regions of %d back-to-back calls" % steps,
         "fwd_recurrence_us": round(fwd_s * 1e6, 2),
         "fwd_recurrence_frac": round(fwd_b / fwd_s / 1e9 / HBM_PEAK_GBS, 4),
         "mfma": out_mfma,
