@@ -88,13 +88,115 @@ struct Vec<true, 1> {
     static __device__ __forceinline__ void store_nt(void* b, size_t e, const float (&v)[1]) { store(b, e, v); }
 };
 
+// Long rows of spmm_csr_rowsplit: one WAVE per (row, NB samples).  Lane = (channel chunk c = lane % cpr, part p = lane / cpr);
+// part p takes entries p, p + parts, ..; the parts of a chunk are added up by xor-shuffles and part 0 runs the epilogue.
+// The waves first scan the row lengths 64 rows at a time (ballot; row r belongs to wave r % n_waves), so a launch without
+// long rows pays a few microseconds of a handful of extra blocks.  cpr is a power of two <= 64 (checked by the launcher).
+template <bool BF16, int VEC, int NB>
+static __device__ __forceinline__ void spmm_long_rows(
+    const int* __restrict__ rowptr, const int* __restrict__ colind, const float* __restrict__ vals,
+    const void* __restrict__ X, void* Y, const void* Z, const void* Z2, float alpha, float beta, float gamma,
+    int v_out, int v_in, int C, int cpr, int B, int flags, int ldx, int ldy, int ldz, int long_thr, long lblock,
+    long lblocks) {
+    using V = Vec<BF16, VEC>;
+    const int lane = threadIdx.x & 63;
+    const long wave = lblock * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long n_waves = lblocks * (blockDim.x >> 6);
+    const int c0 = (lane & (cpr - 1)) * VEC;
+    const int part = lane / cpr, parts = 64 / cpr;
+    const size_t xs = (size_t)v_in * ldx;
+    const int bgroups = (B + NB - 1) / NB;
+    // row r belongs to wave r % n_waves: neighbouring long rows (the cells around a pole) go to different waves
+    for (long kb = 0; kb * n_waves < v_out; kb += 64) {
+        const long r = (kb + lane) * n_waves + wave;
+        const int len = r < v_out ? rowptr[r + 1] - rowptr[r] : 0;
+        unsigned long long todo = __ballot(len > long_thr);
+        while (todo) {
+            const int j = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int row = (int)((kb + j) * n_waves + wave);
+            const int s = rowptr[row], e = rowptr[row + 1];
+            for (int bg = 0; bg < bgroups; ++bg) {
+                const int b0 = bg * NB;
+                float acc[NB][VEC];
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < VEC; ++jj) acc[i][jj] = 0.f;
+                int q = s + part;
+                for (; q + parts < e; q += 2 * parts) {          // two entries per step: 2 NB gathers in flight
+                    const int col0 = colind[q], col1 = colind[q + parts];
+                    const float a0 = vals[q], a1 = vals[q + parts];
+                    float x0[NB][VEC], x1[NB][VEC];
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        const int b = (b0 + i < B) ? b0 + i : B - 1;
+                        V::load(X, (size_t)b * xs + (size_t)col0 * ldx + c0, x0[i]);
+                        V::load(X, (size_t)b * xs + (size_t)col1 * ldx + c0, x1[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NB; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < VEC; ++jj) {
+                            acc[i][jj] = fmaf(a0, x0[i][jj], acc[i][jj]);
+                            acc[i][jj] = fmaf(a1, x1[i][jj], acc[i][jj]);
+                        }
+                }
+                if (q < e) {
+                    const int col = colind[q];
+                    const float a = vals[q];
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        const int b = (b0 + i < B) ? b0 + i : B - 1;
+                        float x[VEC];
+                        V::load(X, (size_t)b * xs + (size_t)col * ldx + c0, x);
+#pragma unroll
+                        for (int jj = 0; jj < VEC; ++jj) acc[i][jj] = fmaf(a, x[jj], acc[i][jj]);
+                    }
+                }
+                for (int m = cpr; m < 64; m <<= 1) {
+#pragma unroll
+                    for (int i = 0; i < NB; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < VEC; ++jj) acc[i][jj] += __shfl_xor(acc[i][jj], m, 64);
+                }
+                if (part == 0) {
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        if (b0 + i >= B) break;
+                        const size_t off = ((size_t)(b0 + i) * v_out + row) * (size_t)C + c0;
+                        const size_t offy = ((size_t)(b0 + i) * v_out + row) * (size_t)ldy + c0;
+                        float o[VEC];
+#pragma unroll
+                        for (int jj = 0; jj < VEC; ++jj) o[jj] = alpha * acc[i][jj];
+                        if (Z != nullptr) {
+                            float z[VEC];
+                            V::load(Z, ((size_t)(b0 + i) * v_out + row) * (size_t)ldz + c0, z);
+#pragma unroll
+                            for (int jj = 0; jj < VEC; ++jj) o[jj] = fmaf(beta, z[jj], o[jj]);
+                        }
+                        if (Z2 != nullptr) {
+                            float z[VEC];
+                            V::load(Z2, off, z);
+#pragma unroll
+                            for (int jj = 0; jj < VEC; ++jj) o[jj] = fmaf(gamma, z[jj], o[jj]);
+                        }
+                        V::store(Y, offy, o);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // One thread = (row, VEC-wide channel chunk) x NB samples.
 template <bool BF16, int VEC, int NB>
 __global__ __launch_bounds__(256) void spmm_csr_rowsplit(
     const int* __restrict__ rowptr, const int* __restrict__ colind, const float* __restrict__ vals,
     const void* __restrict__ X, void* Y, const void* Z, const void* Z2,
     float alpha, float beta, float gamma,
-    int v_out, int v_in, int C, int cpr, int B, long row_blocks, int xcd_swizzle, int ldx, int ldy, int ldz) {
+    int v_out, int v_in, int C, int cpr, int B, long row_blocks, int xcd_swizzle, int ldx, int ldy, int ldz,
+    int long_thr, long main_blocks) {
     // ldx / ldy: elements between consecutive rows of X / Y (>= C: a channel slice of a wider node-major tensor, e.g.
     // one half of the decoder's concatenation buffer); ldz: the same for Z; Z2 is always dense [B, v_out, C]
     using V = Vec<BF16, VEC>;
@@ -102,8 +204,17 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit(
     // Remap so that every XCD walks ONE contiguous range of (batch group, row block) pairs: the
     // neighbour rows a block gathers were then fetched into the same L2 by its predecessors,
     // instead of every XCD pulling its own copy of every halo row from HBM / Infinity Cache.
-    const long nwg = gridDim.x;
-    const long orig = blockIdx.x;
+    // Rows longer than long_thr entries (0: none are treated specially) are left to the blocks in front of the main ones, which
+    // give each such row a whole wave: with one lane group per row a 300-entry row (the polar cells of a cross-sampling
+    // pooling matrix) is a 300-step dependent chain that the rest of the launch waits for.
+    const long lblocks = (long)gridDim.x - main_blocks;   // they come FIRST in the grid (a multiple of 8: the XCD phase stays)
+    if ((long)blockIdx.x < lblocks) {
+        spmm_long_rows<BF16, VEC, NB>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, v_out, v_in, C, cpr, B,
+                                      xcd_swizzle, ldx, ldy, ldz, long_thr, (long)blockIdx.x, lblocks);
+        return;
+    }
+    const long nwg = main_blocks;
+    const long orig = (long)blockIdx.x - lblocks;
     long wg = orig;
     if (xcd_swizzle & 1) {
         const long q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
@@ -125,6 +236,7 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit(
 
     const size_t xs = (size_t)v_in * ldx;  // sample stride of X
     const int s = rowptr[row], e = rowptr[row + 1];
+    if (long_thr > 0 && e - s > long_thr) return;   // a wave of the trailing blocks owns this row
     int p = s;
     for (; p + 2 <= e; p += 2) {
         const int col0 = colind[p], col1 = colind[p + 1];
@@ -297,10 +409,17 @@ int launch_rowsplit(const int* rowptr, const int* colind, const float* vals, con
     static const char* sw = dsw_diag_env("DSW_SPMM_XCD");  // "0" disables the XCD-aware block order (diagnostics)
     // bit0: XCD block order, bit1: nt loads of Z/Z2, bit2: nt stores of Y (env overrides the caller's hints)
     const int swz = sw ? atoi(sw) : (1 | (hints & 6));
-    dim3 grid((unsigned)(row_blocks * bgroups));
+    // long rows (see spmm_long_rows): a few trailing blocks scan for them and give each a whole wave
+    const bool lr = (cpr & (cpr - 1)) == 0 && cpr <= 64 && bs % 64 == 0;
+    const int long_thr = lr ? 64 : 0;
+    long lblocks = lr ? (((long)v_out / 256 + 7) & ~7L) : 0;   // one wave per ~64 rows: a single scan step each
+    if (lblocks > 256) lblocks = 256;
+    if (lr && lblocks < 8) lblocks = 8;
+    const long main_blocks = row_blocks * bgroups;
+    dim3 grid((unsigned)(main_blocks + lblocks));
     hipLaunchKernelGGL((spmm_csr_rowsplit<BF16, VEC, NB>), grid, dim3(bs), 0, stream, rowptr, colind,
                        vals, X, Y, Z, Z2, alpha, beta, gamma, v_out, v_in, C, cpr, B, row_blocks, swz, ldx > 0 ? ldx : C,
-                       ldy > 0 ? ldy : C, ldz > 0 ? ldz : C);
+                       ldy > 0 ? ldy : C, ldz > 0 ? ldz : C, long_thr, main_blocks);
     return dsw_check_launch();
 }
 

@@ -275,6 +275,50 @@ def test_spmm_axpby_and_rectangular():
         assert orc.max_rel_err(yt, ref_t) <= TOL_F64
 
 
+@pytest.mark.parametrize("dt,C,B", [(torch.float32, 32, 8), (torch.float32, 8, 5), (torch.float32, 128, 1),
+                                      (torch.float32, 33, 3), (torch.float32, 256, 2), (torch.bfloat16, 64, 9)])
+def test_spmm_rows_with_hundreds_of_entries(dt, C, B):
+    """Cross-sampling pooling matrices have rows with hundreds of entries next to rows with a handful (polar cells): rows
+    beyond 64 entries are summed by a whole wave (dsw_spmm.hip, spmm_long_rows) - exactly 64 / 65 entries, empty rows,
+    the epilogue operands, in-place output and the transpose (every column short) against fp64."""
+    from scipy import sparse
+    from dsw_amd import functional as F_
+
+    rng = np.random.default_rng(11)
+    vo, vi = 333, 4000
+    lens = rng.integers(0, 20, vo)
+    lens[[0, 7, 100, 101, 332]] = [303, 64, 65, 1200, 97]
+    lens[[5, 6]] = 0
+    rows = np.repeat(np.arange(vo), lens)
+    cols = np.concatenate([rng.choice(vi, n, replace=False) for n in lens])
+    m = sparse.csr_matrix((rng.standard_normal(len(rows)).astype(np.float32), (rows, cols)), shape=(vo, vi))
+    m.sort_indices()
+    op = F_.CsrOperator.from_sparse_coo(orc.coo_from_scipy(m).float().to(DEV))
+    tol = TOL_F64 if dt == torch.float32 else TOL_BF16
+    x = torch.from_numpy(recipes.rand(1, (B, vi, C))).to(DEV).to(dt)
+    z = torch.from_numpy(recipes.rand(2, (B, vo, C))).to(DEV).to(dt)
+    z2 = torch.from_numpy(recipes.rand(3, (B, vo, C))).to(DEV).to(dt)
+    f64 = lambda t: t.float().cpu().double().numpy()
+    ref = 2.0 * orc.remap_f64(m.indptr, m.indices, m.data, (vo, vi), x.float().cpu().numpy()) - f64(z) + 0.5 * f64(z2)
+    y = F_._HIP.spmm(op, x, 2.0, z, -1.0, z2, 0.5)
+    assert orc.max_rel_err(y.float(), ref) <= tol
+    zc = z.clone()
+    F_._HIP.spmm(op, x, 2.0, zc, -1.0, z2, 0.5, out=zc)       # in place (Y aliases Z)
+    assert torch.equal(zc, y)
+    assert torch.equal(F_._HIP.spmm(op, x, 2.0, z, -1.0, z2, 0.5), y)   # deterministic
+    xt = torch.from_numpy(recipes.rand(4, (B, vo, C))).to(DEV).to(dt)
+    yt = F_._HIP.spmm(op.transpose(), xt)
+    ref_t = orc.remap_backward_f64(m.indptr, m.indices, m.data, (vo, vi), xt.float().cpu().numpy())
+    assert orc.max_rel_err(yt.float(), ref_t) <= tol
+    if C % 8 == 0 and dt == torch.float32:                     # channel slices of wider tensors (row strides)
+        wide_x = torch.from_numpy(recipes.rand(5, (B, vi, C + 8))).to(DEV)
+        wide_y = torch.zeros(B, vo, C + 16, device=DEV)
+        F_._HIP.spmm(op, wide_x[..., 8:], out=wide_y[..., 4:4 + C])
+        ref_s = orc.remap_f64(m.indptr, m.indices, m.data, (vo, vi), wide_x[..., 8:].cpu().numpy())
+        assert orc.max_rel_err(wide_y[..., 4:4 + C], ref_s) <= tol
+        assert float(wide_y[..., :4].abs().max()) == 0.0 and float(wide_y[..., 4 + C:].abs().max()) == 0.0
+
+
 def test_empty_batch_and_determinism():
     from modules.layers import ConvCheb
 
