@@ -730,7 +730,7 @@ static int dsw_wgrad_launch_impl(const void* X, const void* T, const void* dY, v
         // waves per workgroup: spread the (k, f) tiles evenly over the fewest groups of <= 4
         const int groups = (ntiles + 3) / 4;
         const int nw = (ntiles + groups - 1) / groups;
-        const bool aligned = dy_planes <= 1 && P.t_vec && P.dy_vec && (Fin % 32 == 0) && (Fout % BN == 0) && (N % WR == 0);
+        const bool aligned = dy_planes <= 1 && P.t_vec && P.dy_vec && (Fin % 32 == 0) && (Fout % (dtype == DSW_F32 ? 32 : BN) == 0) && (N % WR == 0);
         const int64_t otiles = (Fout + BN - 1) / BN;
         {   // bf16 matrix pipe (3-way split for fp32 storage) when the problem is aligned
             int rc3 = DSW_OK;
@@ -824,7 +824,7 @@ int dsw_wgrad_mixfirst_launch(const void* X, const void* dY, const void* D, void
         P.dY1 = D; P.dy_plane_stride = (size_t)N * Fout; P.dy_planes = (int)K;
         P.t_vec = (Fin % 4 == 0) && (((uintptr_t)X & am) == 0);
         P.dy_vec = (Fout % 4 == 0) && (((uintptr_t)dY & am) == 0) && (((uintptr_t)D & am) == 0);
-        const bool aligned = P.t_vec && P.dy_vec && (Fin % 32 == 0) && (Fout % BN == 0) && (N % WR == 0);
+        const bool aligned = P.t_vec && P.dy_vec && (Fin % 32 == 0) && (Fout % (dtype == DSW_F32 ? 32 : BN) == 0) && (N % WR == 0);
         int rc3 = DSW_OK;
         int64_t S3 = 0;
         if (aligned && dsw_wgrad_x3_try_launch(P, dtype == DSW_BF16 ? 1 : 0, wgrad_max_slabs(Fin, Fout, K), &S3, stream,
@@ -866,7 +866,7 @@ int dsw_bwd_gemm_fused_try(const void* X, const void* T, const void* W, const vo
     const uintptr_t am = 15;
     P.t_vec = (Fin % 4 == 0) && (((uintptr_t)X & am) == 0) && (K == 1 || ((uintptr_t)T & am) == 0);
     P.dy_vec = (Fout % 4 == 0) && (((uintptr_t)dY & am) == 0);
-    const bool aligned = P.t_vec && P.dy_vec && (Fin % 32 == 0) && (Fout % BN == 0) && (N % WR == 0) &&
+    const bool aligned = P.t_vec && P.dy_vec && (Fin % 32 == 0) && (Fout % (dtype == DSW_F32 ? 32 : BN) == 0) && (N % WR == 0) &&
                          (((uintptr_t)G0 & am) == 0) && (K == 1 || ((uintptr_t)Grest & am) == 0);
     if (!aligned || (dtype == DSW_BF16 && (Fin % 8 != 0 || P.plane_stride % 8 != 0))) return 0;
     int64_t S = 0;

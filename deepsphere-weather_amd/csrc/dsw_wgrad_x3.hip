@@ -588,7 +588,21 @@ int dsw_wgrad_x3_try_launch(WgradParams& P, int bf16, int64_t max_slabs, int64_t
     const int groups = (ntiles + 7) / 8;
     const int nw = (ntiles + groups - 1) / groups;
     const bool wide = P.Fout % 128 == 0 && nw >= 3;   // few waves: the 128-column dY tile would not fit their registers
-    const int otiles = wide ? P.Fout / 128 : P.Fout / 64;
+    const bool slim = !bf16 && P.Fout % 64 != 0;       // fp32, Fout = 32 (mod 64): 32-column o-tiles
+    if (P.Fout % (slim ? 32 : 64) != 0) return 0;
+    const int otiles = wide ? P.Fout / 128 : slim ? P.Fout / 32 : P.Fout / 64;
+    if (slim) {
+#define DSW_WX3_SLIM(NW_)                                                                                         \
+    case NW_:                                                                                                     \
+        *rc = launch_wx3<false, 3, NW_, 1>(P, groups, otiles, max_slabs, S_out, stream);                            \
+        return 1;
+        switch (nw) {
+            DSW_WX3_SLIM(1) DSW_WX3_SLIM(2) DSW_WX3_SLIM(3) DSW_WX3_SLIM(4) DSW_WX3_SLIM(5) DSW_WX3_SLIM(6) DSW_WX3_SLIM(7)
+            DSW_WX3_SLIM(8)
+        }
+#undef DSW_WX3_SLIM
+        return 0;
+    }
     // bf16 storage, whole 64-row chunks, 16-byte aligned 8-channel groups: raw-copy staging kernel
     const bool raw = bf16 && P.N % 64 == 0 && P.Fin % 8 == 0 && P.Fout % 8 == 0 && dsw_aligned16(P.X) &&
                      (P.K == 1 || dsw_aligned16(P.T)) && dsw_aligned16(P.dY) && P.plane_stride % 8 == 0 &&
@@ -655,10 +669,11 @@ int dsw_wgrad_dgrad_fused_try_launch(WgradParams& P, int bf16, int64_t max_slabs
         return 0;
     }
     if (ntiles < 3 || ntiles > 4) return 0;               // fp32: 1-2 wave workgroups would spill registers
-    if (P.Fout != 64) return 0;                          // one 64-column o-tile (128 would need 2x the panel and registers)
+    if (P.Fout != 64 && P.Fout != 32) return 0;          // one 64- or 32-column o-tile (128 would need 2x the panel and registers)
 #define DSW_WF(NW_)                                                                                        \
     case NW_:                                                                                              \
-        *rc = launch_wx3<false, 3, NW_, 2, true>(P, 1, 1, max_slabs, S_out, stream);                       \
+        *rc = P.Fout == 64 ? launch_wx3<false, 3, NW_, 2, true>(P, 1, 1, max_slabs, S_out, stream)         \
+                           : launch_wx3<false, 3, NW_, 1, true>(P, 1, 1, max_slabs, S_out, stream);        \
         return 1;
     switch (ntiles) {
         DSW_WF(3) DSW_WF(4)

@@ -193,6 +193,11 @@ CASES = [
     (768, 2, 64, 64, 2, False, "healpix"),
     (1000, 3, 32, 64, 3, True, "irregular"),  # N % 32 != 0 -> falls back to the separate kernels; same answer
     (1024, 2, 32, 64, 3, True, "irregular"),
+    # ... and with 32-column o-tiles (fp32, Fout = 32 mod 64): the equiangular block of bench workload c5
+    (768, 3, 32, 32, 3, True, "healpix"),     # fused pass, 3 tiles
+    (192, 2, 32, 32, 4, False, "healpix"),    # fused pass, 4 tiles
+    (768, 2, 96, 96, 2, True, "healpix"),     # separate wgrad: 6 (k, f) tiles x 3 o-tiles of 32
+    (1024, 5, 64, 32, 1, True, "irregular"),  # K = 1
     # narrow outputs (K * Fout <= 16): vector-ALU kernels of dsw_narrow.hip, forward / dgrad / wgrad
     (768, 2, 128, 4, 3, True, "healpix"),
     (192, 3, 32, 5, 2, False, "healpix"),
