@@ -88,11 +88,11 @@ struct Vec<true, 1> {
     static __device__ __forceinline__ void store_nt(void* b, size_t e, const float (&v)[1]) { store(b, e, v); }
 };
 
-// Long rows of spmm_csr_rowsplit: one WAVE per (row, NB samples).  Lane = (channel chunk c = lane % cpr, part p = lane / cpr);
+// Long rows of spmm_csr_rowsplit: one WAVE per (row, sample).  Lane = (channel chunk c = lane % cpr, part p = lane / cpr);
 // part p takes entries p, p + parts, ..; the parts of a chunk are added up by xor-shuffles and part 0 runs the epilogue.
 // The waves first scan the row lengths 64 rows at a time (ballot; row r belongs to wave r % n_waves), so a launch without
 // long rows pays a few microseconds of a handful of extra blocks.  cpr is a power of two <= 64 (checked by the launcher).
-template <bool BF16, int VEC, int NB>
+template <bool BF16, int VEC>
 static __device__ __forceinline__ void spmm_long_rows(
     const int* __restrict__ rowptr, const int* __restrict__ colind, const float* __restrict__ vals,
     const void* __restrict__ X, void* Y, const void* Z, const void* Z2, float alpha, float beta, float gamma,
@@ -100,12 +100,19 @@ static __device__ __forceinline__ void spmm_long_rows(
     long lblocks) {
     using V = Vec<BF16, VEC>;
     const int lane = threadIdx.x & 63;
-    const long wave = lblock * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const long n_waves = lblocks * (blockDim.x >> 6);
+    // work item = (long row, sample): ONE sample per wave keeps this path within the registers of the main path (the
+    // kernel's allocation is the maximum of both) and gives B waves to every long row
+    const long all_waves = lblocks * (blockDim.x >> 6);
+    const long gwave = lblock * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int bsplit = (all_waves >= 2L * B) ? B : 1;
+    const long n_waves = all_waves / bsplit;
+    const long wave = gwave / bsplit;
+    const int b_first = bsplit > 1 ? (int)(gwave % bsplit) : 0;
+    const int b_step = bsplit > 1 ? B : 1;               // with bsplit > 1 the sample loop below runs once
+    if (wave >= n_waves) return;
     const int c0 = (lane & (cpr - 1)) * VEC;
     const int part = lane / cpr, parts = 64 / cpr;
     const size_t xs = (size_t)v_in * ldx;
-    const int bgroups = (B + NB - 1) / NB;
     // row r belongs to wave r % n_waves: neighbouring long rows (the cells around a pole) go to different waves
     for (long kb = 0; kb * n_waves < v_out; kb += 64) {
         const long r = (kb + lane) * n_waves + wave;
@@ -116,73 +123,53 @@ static __device__ __forceinline__ void spmm_long_rows(
             todo &= todo - 1;
             const int row = (int)((kb + j) * n_waves + wave);
             const int s = rowptr[row], e = rowptr[row + 1];
-            for (int bg = 0; bg < bgroups; ++bg) {
-                const int b0 = bg * NB;
-                float acc[NB][VEC];
+            for (int b = b_first; b < B; b += b_step) {
+                const size_t xb = (size_t)b * xs + c0;
+                float acc[VEC];
 #pragma unroll
-                for (int i = 0; i < NB; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < VEC; ++jj) acc[i][jj] = 0.f;
+                for (int jj = 0; jj < VEC; ++jj) acc[jj] = 0.f;
                 int q = s + part;
-                for (; q + parts < e; q += 2 * parts) {          // two entries per step: 2 NB gathers in flight
-                    const int col0 = colind[q], col1 = colind[q + parts];
-                    const float a0 = vals[q], a1 = vals[q + parts];
-                    float x0[NB][VEC], x1[NB][VEC];
+                for (; q + 3 * parts < e; q += 4 * parts) {      // four entries per step: four gathers in flight
+                    int col[4];
+                    float a[4], x[4][VEC];
 #pragma unroll
-                    for (int i = 0; i < NB; ++i) {
-                        const int b = (b0 + i < B) ? b0 + i : B - 1;
-                        V::load(X, (size_t)b * xs + (size_t)col0 * ldx + c0, x0[i]);
-                        V::load(X, (size_t)b * xs + (size_t)col1 * ldx + c0, x1[i]);
-                    }
+                    for (int u = 0; u < 4; ++u) { col[u] = colind[q + u * parts]; a[u] = vals[q + u * parts]; }
 #pragma unroll
-                    for (int i = 0; i < NB; ++i)
+                    for (int u = 0; u < 4; ++u) V::load(X, xb + (size_t)col[u] * ldx, x[u]);
 #pragma unroll
-                        for (int jj = 0; jj < VEC; ++jj) {
-                            acc[i][jj] = fmaf(a0, x0[i][jj], acc[i][jj]);
-                            acc[i][jj] = fmaf(a1, x1[i][jj], acc[i][jj]);
-                        }
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int jj = 0; jj < VEC; ++jj) acc[jj] = fmaf(a[u], x[u][jj], acc[jj]);
                 }
-                if (q < e) {
-                    const int col = colind[q];
+                for (; q < e; q += parts) {
+                    float x[VEC];
+                    V::load(X, xb + (size_t)colind[q] * ldx, x);
                     const float a = vals[q];
 #pragma unroll
-                    for (int i = 0; i < NB; ++i) {
-                        const int b = (b0 + i < B) ? b0 + i : B - 1;
-                        float x[VEC];
-                        V::load(X, (size_t)b * xs + (size_t)col * ldx + c0, x);
-#pragma unroll
-                        for (int jj = 0; jj < VEC; ++jj) acc[i][jj] = fmaf(a, x[jj], acc[i][jj]);
-                    }
+                    for (int jj = 0; jj < VEC; ++jj) acc[jj] = fmaf(a, x[jj], acc[jj]);
                 }
                 for (int m = cpr; m < 64; m <<= 1) {
 #pragma unroll
-                    for (int i = 0; i < NB; ++i)
-#pragma unroll
-                        for (int jj = 0; jj < VEC; ++jj) acc[i][jj] += __shfl_xor(acc[i][jj], m, 64);
+                    for (int jj = 0; jj < VEC; ++jj) acc[jj] += __shfl_xor(acc[jj], m, 64);
                 }
                 if (part == 0) {
+                    const size_t off = ((size_t)b * v_out + row) * (size_t)C + c0;
+                    float o[VEC];
 #pragma unroll
-                    for (int i = 0; i < NB; ++i) {
-                        if (b0 + i >= B) break;
-                        const size_t off = ((size_t)(b0 + i) * v_out + row) * (size_t)C + c0;
-                        const size_t offy = ((size_t)(b0 + i) * v_out + row) * (size_t)ldy + c0;
-                        float o[VEC];
+                    for (int jj = 0; jj < VEC; ++jj) o[jj] = alpha * acc[jj];
+                    if (Z != nullptr) {
+                        float z[VEC];
+                        V::load(Z, ((size_t)b * v_out + row) * (size_t)ldz + c0, z);
 #pragma unroll
-                        for (int jj = 0; jj < VEC; ++jj) o[jj] = alpha * acc[i][jj];
-                        if (Z != nullptr) {
-                            float z[VEC];
-                            V::load(Z, ((size_t)(b0 + i) * v_out + row) * (size_t)ldz + c0, z);
-#pragma unroll
-                            for (int jj = 0; jj < VEC; ++jj) o[jj] = fmaf(beta, z[jj], o[jj]);
-                        }
-                        if (Z2 != nullptr) {
-                            float z[VEC];
-                            V::load(Z2, off, z);
-#pragma unroll
-                            for (int jj = 0; jj < VEC; ++jj) o[jj] = fmaf(gamma, z[jj], o[jj]);
-                        }
-                        V::store(Y, offy, o);
+                        for (int jj = 0; jj < VEC; ++jj) o[jj] = fmaf(beta, z[jj], o[jj]);
                     }
+                    if (Z2 != nullptr) {
+                        float z[VEC];
+                        V::load(Z2, off, z);
+#pragma unroll
+                        for (int jj = 0; jj < VEC; ++jj) o[jj] = fmaf(gamma, z[jj], o[jj]);
+                    }
+                    V::store(Y, ((size_t)b * v_out + row) * (size_t)ldy + c0, o);
                 }
             }
         }
@@ -209,7 +196,7 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit(
     // pooling matrix) is a 300-step dependent chain that the rest of the launch waits for.
     const long lblocks = (long)gridDim.x - main_blocks;   // they come FIRST in the grid (a multiple of 8: the XCD phase stays)
     if ((long)blockIdx.x < lblocks) {
-        spmm_long_rows<BF16, VEC, NB>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, v_out, v_in, C, cpr, B,
+        spmm_long_rows<BF16, VEC>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, v_out, v_in, C, cpr, B,
                                       xcd_swizzle, ldx, ldy, ldz, long_thr, (long)blockIdx.x, lblocks);
         return;
     }
