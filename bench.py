@@ -94,7 +94,10 @@ class _C5Block(torch.nn.Module):
 
     def forward(self, x):
         y = self.conv_fine(x)
-        z, idx = self.pool(y)
+        if y.requires_grad:   # y has two consumers: its pooling's backward adds the other one's gradient in its epilogue
+            y, (z, idx) = self.pool.forward_fork(y)
+        else:
+            z, idx = self.pool(y)
         return y + self.unpool(self.conv_coarse(z), idx)
 
 
