@@ -601,6 +601,33 @@ def test_skip_slot_is_used_by_the_unet_and_only_once(oracle_backend):
     assert orc.max_rel_err(y2.detach(), keep.numpy()) <= 1e-6
 
 
+def test_pooling_fork_gives_the_gradients_of_the_plain_graph(oracle_backend):
+    """`forward_fork`: same outputs, and the input's gradient equals what autograd accumulates for the plain graph
+    (pooling + a second consumer), for the index-less pooling layers; max-value pooling declares no fork."""
+    from modules.layers import GeneralAvgPool, GeneralMaxAreaPool, GeneralMaxValPool
+    from scipy import sparse as sp
+
+    rng = np.random.default_rng(2)
+    dense = (rng.random((24, 96)) < 0.1) * rng.random((24, 96))
+    dense[np.arange(24), rng.integers(0, 96, 24)] += 0.5
+    mat = sp.csr_matrix(dense.astype(np.float32))
+    assert GeneralMaxValPool(mat).forward_fork is None
+    for cls in (GeneralAvgPool, GeneralMaxAreaPool):
+        pool = cls(mat)
+        x0 = torch.from_numpy(recipes.rand(5, (2, 96, 8)))
+        other_w = torch.from_numpy(recipes.rand(6, (2, 96, 8)))
+        gy = torch.from_numpy(recipes.rand(7, (2, 24, 8)))
+        xa = x0.clone().requires_grad_(True)
+        ya, none_a = pool(xa)
+        ((xa * other_w).sum() + (ya * gy).sum()).backward()
+        xb = x0.clone().requires_grad_(True)
+        x_again, (yb, none_b) = pool.forward_fork(xb)
+        assert none_a is None and none_b is None and x_again.data_ptr() == xb.data_ptr()
+        ((x_again * other_w).sum() + (yb * gy).sum()).backward()
+        assert torch.equal(ya, yb)
+        np.testing.assert_allclose(xb.grad.numpy(), xa.grad.numpy(), rtol=0, atol=1e-6)
+
+
 def test_residual_branch_linear_is_a_drop_in_for_nn_linear():
     """`_NodeLinear` keeps torch.nn.Linear's parameter names, shapes, initial values and state_dict round trip; only the
     weight's memory order differs (column-major, so that neither pass needs a transpose copy)."""
