@@ -13,6 +13,12 @@ Workloads
   c3    BASELINE configs[2]: nside=64, K=5, 64->128, B=16 per GPU, bf16 storage / fp32 accumulate
   unet  BASELINE configs[1]: UNetSpherical nside=32, K=3, B=8 per GPU, fp32, interp pooling
 
+Launch.  `python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks itself (it re-executes
+under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, one process per GPU,
+RCCL) and relays rank 0's line; started BY torchrun it checks that WORLD_SIZE is the N that was asked for.  With N > 1
+the gradient all-reduce is captured INTO the step graph (ten steps per graph, as on one GPU); the captured graph is
+validated against an eager step + all-reduce first, and any failure falls back to collectives issued after the replay.
+
 Rank 0 prints ONE JSON line.  At N=1 it also carries
   roofline      the SpMM kernel: algorithmic bytes per launch / mean launch duration (HIP events on
                 the launch stream) against the 8 TB/s HBM peak; "traffic" from profiles/ PMC data
@@ -49,7 +55,8 @@ WORKLOADS = {
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of this node (default: WORLD_SIZE of the torchrun environment, else 1)")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
@@ -233,11 +240,64 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None):
                "frac": round(wf_bytes / wf_s / 1e9 / HBM_PEAK_GBS, 4),
                "compulsory_bytes": int(E + (K - 1) * E + B * V * Fout * es),
                "note": "algorithmic = unfused pass count (SURVEY 8d); compulsory = X in, T_1.. out (kept for backward), Y out"}
+    # ---- the kernels that actually run inside a timed step, each against ITS OWN algorithmic bytes -------------------
+    # forward = dsw_cheb_fwd (above); backward = dsw_cheb_bwd = GEMM pass (dW partials + db, dgrad planes G_k; one fused
+    # launch where the shape allows, + the partial reduce) followed by the adjoint recurrence.  The adjoint launches are
+    # timed alone (dsw_cheb_basis_adj); the GEMM pass is the whole backward minus them.
+    in_step = None
+    if not mf:
+        dy = torch.randn((B, V, Fout), dtype=x.dtype, device=x.device)
+        dxb = torch.empty_like(x)
+        dwb = torch.empty_like(layer.weight)
+        dbb = torch.empty((Fout,), dtype=x.dtype, device=x.device)
+        nws = int(lib.dsw_cheb_bwd_workspace_bytes(B, V, C, Fout, K, dcode))
+        ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=x.device)
+
+        def whole_bwd():
+            rc = lib.dsw_cheb_bwd(opt.rowptr.data_ptr(), opt.colind.data_ptr(), opt.values.data_ptr(), V, opt.nnz,
+                                  x.data_ptr(), T.data_ptr(), layer.weight.data_ptr(), dy.data_ptr(), dxb.data_ptr(),
+                                  dwb.data_ptr(), dbb.data_ptr(), ws.data_ptr(), nws, B, C, Fout, K, dcode, st, ppt)
+            assert rc == 0
+
+        fwd()            # T = the basis of x (what the backward of a real step reads)
+        for _ in range(3):
+            whole_bwd()
+        torch.cuda.synchronize()
+        bwd_s = timed(whole_bwd)
+        adj_s = timed(adj)
+        gemm_s = max(bwd_s - adj_s, 1e-9)
+        yb_bytes = B * V * Fout * es
+        gemm_bytes = K * E + yb_bytes + K * E          # basis planes + dY read ONCE, K dgrad planes written
+        gemm_flops = 4.0 * B * V * C * K * Fout         # dW and dgrad
+
+        def entry(role, kernels, sec, nbytes, extra=None):
+            d = {"role": role, "kernels": kernels, "avg_us": round(sec * 1e6, 2), "algorithmic_bytes": int(nbytes),
+                 "achieved_GBs": round(nbytes / sec / 1e9, 1), "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4)}
+            d.update(extra or {})
+            return d
+
+        in_step = [
+            entry("forward (dsw_cheb_fwd)", "cheb3_fwd_fused: hops + channel mix + bias in ONE launch where the shape has "
+                  "it (fp32, K=3, 32-channel chunks), else spmm2_fused / spmm_csr hops + ts_gemm* mix", wf_s, wf_bytes,
+                  {"compulsory_bytes": out_fwd["compulsory_bytes"]}),
+            entry("backward GEMM pass (dsw_cheb_bwd minus its adjoint launches)",
+                  "cheb_wgrad_x3<FUSE> (dW partials + db + dgrad planes in one pass) or cheb_wgrad* + ts_gemm* dgrad, "
+                  "+ cheb_wgrad_reduce", gemm_s, gemm_bytes,
+                  {"flops": gemm_flops, "TFLOPs": round(gemm_flops / gemm_s / 1e12, 1),
+                   "bytes_note": "K basis planes + dY read once, K dgrad planes written (separate launches re-read dY)"}),
+            entry("adjoint recurrence (dsw_cheb_basis_adj)", "spmm2_fused adjoint pair(s)" if ppt is not None
+                  else "spmm_csr x%d" % (K - 1), adj_s, bwd_b),
+        ]
+        tot = wf_s + bwd_s
+        for d in in_step:
+            d["share_of_fwd_bwd"] = round(d["avg_us"] * 1e-6 / tot, 3)
     return {
         "bound": "hbm",
-        "kernel": ("SpMM recurrence: forward %s + adjoint %s, %d launches/step" % (
-            "spmm2_fused" if pp is not None else "spmm_csr x%d" % (K - 1),
-            "spmm2_fused" if ppt is not None else "spmm_csr x%d" % (K - 1), n_launch)),
+        "kernel": ("SpMM recurrence launches (the north-star gate): forward %s + adjoint %s, %d launches; the ADJOINT "
+                   "launches are in every timed step, the forward launches only where the one-launch forward does not "
+                   "apply - what a step really runs is listed under in_step" % (
+                       "spmm2_fused" if pp is not None else "spmm_csr x%d" % (K - 1),
+                       "spmm2_fused" if ppt is not None else "spmm_csr x%d" % (K - 1), n_launch)),
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "traffic_source": (None if traffic is None else
@@ -248,6 +308,7 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None):
         "launch_timing": "HIP events on the launch stream; median of 3 regions of %d back-to-back calls" % steps,
         "fwd_recurrence_us": round(fwd_s * 1e6, 2),
         "fwd_recurrence_frac": round(fwd_b / fwd_s / 1e9 / HBM_PEAK_GBS, 4),
+        "in_step": in_step,
         "mfma": out_mfma,
         "whole_forward": out_fwd,
     }
@@ -414,12 +475,86 @@ def cpu_baseline_c5(model, wl, V):
     }
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside torchrun: run the N ranks under torch.distributed.run and relay rank 0's line.
+    Attempts, each under a time limit and in its own process group (a hung attempt is killed as a whole):
+    graph-captured collectives -> collectives after the replay -> eager launches."""
+    import signal
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("DSW_DIST_BACKEND") != "gloo":
+        sys.exit("bench.py: --gpus %d, but %d ROCm device(s) are visible (RCCL needs one device per rank; "
+                 "DSW_DIST_BACKEND=gloo runs the N > 1 path with several ranks per device for tests)" % (n, have))
+    limit = float(os.environ.get("DSW_BENCH_TIMEOUT", "600"))
+    attempts = [("graph-captured collectives", {}),
+                ("collectives after the graph replay", {"DSW_BENCH_COLLECTIVES": "eager"}),
+                ("eager launches", {"DSW_BENCH_COLLECTIVES": "eager", "DSW_BENCH_NO_GRAPH": "1"})]
+    if os.environ.get("DSW_BENCH_COLLECTIVES") == "eager":
+        attempts = attempts[1:]
+    for i, (what, extra) in enumerate(attempts):
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+        env = dict(os.environ, **extra)
+        env["DSW_BENCH_LAUNCHER"] = "bench.py self-launch, attempt %d: %s" % (i + 1, what)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, _ = proc.communicate(timeout=limit)
+            rc = proc.returncode
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            out, _ = proc.communicate()
+            rc = -9
+        lines = [ln for ln in (out or "").splitlines() if ln.startswith("{") and '"metric"' in ln]
+        if rc == 0 and lines:
+            print(lines[-1], flush=True)
+            return 0
+        print("bench.py: attempt %d (%s) failed with exit code %s%s" % (
+            i + 1, what, rc, "" if i + 1 == len(attempts) else "; retrying: " + attempts[i + 1][0]), file=sys.stderr, flush=True)
+    return 1
+
+
+def _arm_watchdog(rank, world):
+    """A rank of an N > 1 run that is still alive after DSW_BENCH_TIMEOUT seconds (a collective that never completes)
+    exits with an error instead of holding the node: the launcher (ours, or torchrun) then tears the job down."""
+    import threading
+
+    limit = float(os.environ.get("DSW_BENCH_TIMEOUT", "600")) * 0.9
+
+    def bark():
+        print("bench.py: rank %d/%d still running after %.0f s - giving up" % (rank, world, limit), file=sys.stderr, flush=True)
+        os._exit(124)
+
+    t = threading.Timer(limit, bark)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus is None:
+        args.gpus = int(env_world) if env_world else 1
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if env_world is not None and int(env_world) != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %s rank(s) (WORLD_SIZE)" % (args.gpus, env_world))
+    if os.environ.get("DSW_BENCH_NO_GRAPH") == "1":
+        args.no_graph = True
     from dsw_amd import _native
     from dsw_amd.parallel import GradBucket, init_from_env
 
     rank, world, local = init_from_env()
+    assert world == args.gpus, (world, args.gpus)
+    if world > 1:
+        _arm_watchdog(rank, world)
     assert torch.cuda.is_available(), "bench.py measures the HIP path; a ROCm device is required"
     _native.load()
     local = local % torch.cuda.device_count()   # (gloo smoke runs of the N>1 path put two ranks on one device)
@@ -457,8 +592,9 @@ def main():
             x.grad = None
             model(x).backward(gy)
 
-    # N > 1: the parameter gradients live in one flat bucket (no pack / unpack copies around the collective); the step is
-    # replayed from a HIP graph, so the bucket's chunks are all-reduced right after the replay
+    # N > 1: the parameter gradients live in one flat bucket (no pack / unpack copies around the collective); RCCL averages
+    # it in place.  The exchange is part of the step: captured INTO the step graph when RCCL is the backend, issued
+    # right after the replay otherwise (gloo, or DSW_BENCH_COLLECTIVES=eager).
     bucket = GradBucket(model.parameters(), overlap=False, attach=False)
     if bucket.active():
         bucket.attach()
@@ -467,12 +603,23 @@ def main():
         def zero_grads():
             model.zero_grad(set_to_none=True)
     sync_grads = bucket.finish
+    want_captured = bucket.active() and bucket.graph_capturable and os.environ.get("DSW_BENCH_COLLECTIVES") != "eager"
+
+    def all_ranks_agree(ok):
+        """True only if `ok` on every rank (a capture that failed on ONE rank must send everybody down the fallback)."""
+        if world == 1 and not dist.is_initialized():
+            return bool(ok)
+        flag = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
 
     # The step is ~8 back-to-back kernels of 80-120 us each; launched eagerly from Python the GPU idles ~5 us between
-    # them.  Capture one fwd+bwd into a HIP graph and replay it (same kernels, same work, same buffers); the gradient
-    # all-reduce stays outside the graph.  Falls back to eager launches if capture is not possible.
-    graph = None
-    graph_multi = None
+    # them.  Capture fwd+bwd(+exchange) into a HIP graph and replay it (same kernels, same work, same buffers).  Falls
+    # back to eager launches if capture is not possible.
+    graph = None          # one step (without the exchange unless `captured_sync`)
+    graph_multi = None    # GRAPH_STEPS whole steps
+    captured_sync = False
+    capture_note = None
     if not args.no_graph:
         try:
             side = torch.cuda.Stream()
@@ -480,6 +627,7 @@ def main():
             with torch.cuda.stream(side):
                 for _ in range(3):
                     step()          # builds the operator caches / tile plans outside the capture
+                    sync_grads()    # (and RCCL's communicator, before anything is recorded)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -487,29 +635,69 @@ def main():
                 step()
             torch.cuda.synchronize()
             graph = g
+        except Exception as exc:  # noqa: BLE001 - any capture problem -> eager
+            if rank == 0:
+                print("bench: HIP graph capture unavailable (%s); running eagerly" % type(exc).__name__, file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+        if bucket.active() and not all_ranks_agree(graph is not None):
+            graph = None
+        if graph is not None and want_captured:
+            # reference result of ONE step + exchange, issued the proven way (replay, then collectives on the stream)
+            graph.replay()
+            sync_grads()
+            torch.cuda.synchronize()
+            want = bucket.bucket.clone()
+            g1 = gm = None
+            try:
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    step()
+                    sync_grads()
+                gm = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gm):
+                    for _ in range(GRAPH_STEPS):
+                        step()
+                        sync_grads()
+                torch.cuda.synchronize()
+                ok = True
+            except Exception as exc:  # noqa: BLE001
+                capture_note = "capture of the collectives failed on rank %d: %s" % (rank, type(exc).__name__)
+                ok = False
+                torch.cuda.synchronize()
+            if all_ranks_agree(ok):
+                # every rank replays the same collectives in the same order: validate what the graph computes
+                g1.replay()
+                torch.cuda.synchronize()
+                same = torch.equal(bucket.bucket, want) or bool(
+                    (bucket.bucket - want).abs().max() <= 1e-5 * want.abs().max().clamp_min(1e-30))
+                if all_ranks_agree(same):
+                    graph, graph_multi, captured_sync = g1, (gm if args.steps >= GRAPH_STEPS else None), True
+                else:
+                    capture_note = "captured exchange did not reproduce the eager result; collectives stay outside the graph"
+            if not captured_sync and rank == 0 and capture_note:
+                print("bench: " + capture_note, file=sys.stderr)
+        elif graph is not None and not bucket.active() and args.steps >= GRAPH_STEPS:
             # single GPU: consecutive graph launches leave the GPU idle for ~40 us (hipGraphLaunch latency), 8 % of
-            # this step; a second graph holding GRAPH_STEPS whole steps amortises it.  With N > 1 every step is
-            # followed by the gradient all-reduce, so steps stay one graph each.
-            if world == 1 and args.steps >= GRAPH_STEPS and os.environ.get("DSW_FORCE_GRAD_SYNC") != "1":
+            # this step; a second graph holding GRAPH_STEPS whole steps amortises it
+            try:
                 gm = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gm):
                     for _ in range(GRAPH_STEPS):
                         step()
                 torch.cuda.synchronize()
                 graph_multi = gm
-        except Exception as exc:  # noqa: BLE001 - any capture problem -> eager
-            if rank == 0:
-                print("bench: HIP graph capture unavailable (%s); running eagerly" % type(exc).__name__, file=sys.stderr)
-            graph = None
-            graph_multi = None
-            torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001
+                graph_multi = None
+                torch.cuda.synchronize()
 
     def full_step():
         if graph is not None:
             graph.replay()
         else:
             step()
-        sync_grads()
+        if not captured_sync:
+            sync_grads()
 
     def run_steps(n):
         """exactly n steps"""
@@ -571,11 +759,47 @@ def main():
             }[args.workload],
             "knn": 20 if args.workload == "c5" else args.knn if args.workload != "unet" else (args.knn if args.knn != 8 else 20),
             "batch_per_gpu": B, "global_batch": B * world, "nodes": V,
-            "parallelism": "dp%d (batch shards, flat-bucket RCCL grad all-reduce)" % world,
-            "launch": ("hip graph replay, %d steps per graph" % GRAPH_STEPS if graph_multi is not None
-                       else "hip graph replay of one fwd+bwd" if graph is not None else "eager"),
+            "parallelism": "dp%d (batch shards, flat-bucket %s grad all-reduce)" % (
+                world, "RCCL" if not dist.is_initialized() or dist.get_backend() == "nccl" else dist.get_backend()),
+            "launch": (("hip graph replay, %d steps per graph" % GRAPH_STEPS if graph_multi is not None
+                        else "hip graph replay of one fwd+bwd" if graph is not None else "eager")
+                       + ("" if not bucket.active() else
+                          ", gradient all-reduce captured in the graph" if captured_sync else
+                          ", gradient all-reduce issued after every replay")),
         },
     }
+    if os.environ.get("DSW_BENCH_LAUNCHER"):
+        out["config"]["launcher"] = os.environ["DSW_BENCH_LAUNCHER"]
+    if os.environ.get("DSW_HIP_LIB"):
+        out["config"]["DSW_HIP_LIB"] = os.environ["DSW_HIP_LIB"]   # an A/B build stands in for the product library
+    if bucket.active():
+        # the exchange alone (HIP events around bucket.finish() on the launch stream), and proof that it did its job:
+        # ranks hold different data (seed 1234 + rank), so their gradients agree only if the all-reduce ran
+        full_step()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+        for a, b in ev:
+            a.record()
+            sync_grads()
+            b.record()
+        torch.cuda.synchronize()
+        ar = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+        full_step()                      # a fresh, once-averaged gradient set for the comparison below
+        torch.cuda.synchronize()
+        mine = bucket.bucket.detach().clone()
+        if dist.get_backend() != "nccl":
+            mine = mine.cpu()            # gloo gathers host tensors
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        diff = max(float((t - gathered[0]).abs().max()) for t in gathered)
+        out["allreduce_us"] = round(ar[len(ar) // 2], 1)
+        out["allreduce"] = {"bytes": int(bucket.bucket.numel() * bucket.bucket.element_size()), "chunks": len(bucket.chunks),
+                            "median_us": round(ar[len(ar) // 2], 1), "min_us": round(ar[0], 1),
+                            "what": "bucket.finish() alone, eager, HIP events (in the timed steps it is %s)" % (
+                                "a node of the step graph" if captured_sync else "issued after each graph replay"),
+                            "note": capture_note}
+        out["grad_sync"] = {"max_abs_diff_across_ranks": diff, "identical": diff == 0.0,
+                            "grad_l2": float(mine.double().norm())}
     if rank == 0 and world == 1:
         # per-iteration HIP-event times (outside the timed region above): median and p10 / p90
         n_ev = 100
@@ -601,7 +825,7 @@ def main():
             rl_layer, rl_what, rl_x = model, None, x.detach()
         if not args.no_roofline:
             out["roofline"] = roofline_leg(rl_layer, rl_x, max(10, args.steps), 5,
-                                           traffic_key=(None if rl_what is not None else args.workload if args.knn == 8
+                                           traffic_key=(args.workload if (rl_what is not None or args.knn == 8)
                                                         else "ns_k20" if (args.workload == "ns" and args.knn == 20) else None))
             if rl_what is not None:
                 out["roofline"]["kernel"] += "; layer " + rl_what

@@ -121,8 +121,9 @@ class CsrOperator:
                     # be halved to respect the neighbourhood caps loses to a smaller one)
                     best = None
                     for rows in (64, 56, 48):
-                        if self.shape[0] < 8 * rows:
-                            continue    # a graph of a few tiles gains nothing from the fused path
+                        if self.shape[0] < MIN_CLUSTERED_TILES * rows:
+                            continue    # a graph of a few tiles gains nothing from the fused path (a launch of < 8
+                                        # workgroups per batch chunk; measured slower than one launch per hop)
                         cand = host_plan(rows, True)
                         if cand is None or cand.lds_bytes(row_bytes, single) > budget:
                             continue
@@ -158,6 +159,8 @@ class CsrOperator:
             self._t = shared
         return self._t
 
+
+MIN_CLUSTERED_TILES = 8   # performance choice only (tests lower it to run the fused path on tiny graphs as well)
 
 _op_cache: dict = {}
 _content_cache: dict = {}   # (device, shape, nnz) -> [weakref(CsrOperator)]: operators with equal content share ONE object
@@ -738,30 +741,38 @@ def _alias(t: torch.Tensor, offset: int, size, stride) -> torch.Tensor:
     return torch.empty(0, dtype=t.dtype, device=t.device).set_(t.untyped_storage(), offset, size, stride)
 
 
+_concat_buffers = weakref.WeakKeyDictionary()   # storage of a buffer made by skip_slot -> [B, V, width_left, width_skip, completed]
+
+
 def skip_slot(like: torch.Tensor, n_nodes: int, width_left: int, width_skip: int):
     """Channel slice ``[..., width_left:]`` of a fresh ``[B, n_nodes, width_left + width_skip]`` buffer: the place an
     encoder block writes its output to (``ResBlock(x, out=slot)``) so that the decoder's
     ``torch.cat((unpooled, skip), dim=2)`` (my_models_graph.py:528-545) needs no copy - the unpooling later fills
-    ``[..., :width_left]`` of the same buffer (``concat_in_place``).  None when the slices would not be 16-byte aligned."""
+    ``[..., :width_left]`` of the same buffer (``concat_in_place``).  None when the slices would not be 16-byte aligned.
+    The buffer's storage is REGISTERED as owned by this mechanism: ``skip_buffer`` only ever completes storages made
+    here, never a caller's tensor that merely has the same strides."""
     es = like.element_size()
     if (width_left * es) % 16 or (width_skip * es) % 16:
         return None
     width = width_left + width_skip
     buf = like.new_empty((like.shape[0], n_nodes, width))
+    _concat_buffers[buf.untyped_storage()] = [like.shape[0], n_nodes, width_left, width_skip, False]
     return _alias(buf, width_left, (like.shape[0], n_nodes, width_skip), (n_nodes * width, width, 1))
 
 
 def skip_buffer(skip: torch.Tensor, width_left: int):
-    """The ``[B, V, width_left + C]`` buffer whose right-hand channel slice ``skip`` is (``skip_slot``), or None when
-    ``skip`` is an ordinary tensor, or when the buffer was already completed once (a second concatenation with the same
-    skip tensor must not overwrite the first one's left half: it takes the copying path)."""
-    if skip.dim() != 3 or getattr(skip, "_dsw_concat_done", False):
+    """The ``[B, V, width_left + C]`` buffer whose right-hand channel slice ``skip`` is, or None when ``skip`` is an
+    ordinary tensor - i.e. its storage was not allocated by ``skip_slot`` with exactly this geometry, whatever its
+    strides look like - or when the buffer was already completed once (a second concatenation with the same skip tensor
+    must not overwrite the first one's left half: it takes the copying path)."""
+    if skip.dim() != 3:
         return None
+    entry = _concat_buffers.get(skip.untyped_storage())
     B, V, C = skip.shape
     width = width_left + C
-    if width_left <= 0 or skip.stride() != (V * width, width, 1) or skip.storage_offset() != width_left:
+    if entry is None or entry[4] or entry[:4] != [B, V, width_left, C]:
         return None
-    if skip.untyped_storage().nbytes() < B * V * width * skip.element_size():
+    if skip.stride() != (V * width, width, 1) or skip.storage_offset() != width_left:
         return None
     return _alias(skip, 0, (B, V, width), (V * width, width, 1))
 
@@ -780,7 +791,9 @@ def concat_in_place(left: torch.Tensor, skip: torch.Tensor, buf: torch.Tensor) -
     if (left.data_ptr() != buf.data_ptr() or skip.data_ptr() != buf.data_ptr() + w * es
             or left.stride() != buf.stride() or skip.stride() != buf.stride()):
         raise ValueError("left / skip are not the two channel slices of buf")
-    skip._dsw_concat_done = True
+    entry = _concat_buffers.get(buf.untyped_storage())
+    if entry is not None:
+        entry[4] = True        # completed: a second decode of the same encodings takes the copying path
     return _ConcatInPlaceFn.apply(left, skip, _Out(buf))
 
 

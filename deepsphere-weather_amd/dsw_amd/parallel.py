@@ -107,7 +107,13 @@ class GradBucket:
       the payload small, so a few MB-sized chunks (not per-tensor collectives) keep the collectives bandwidth- rather
       than latency-bound.
     * Hooks only fire when autograd runs: a step replayed from a HIP graph calls ``finish()`` after the replay and
-      the chunks go out back to back (``capturing`` suppresses launches while the graph is being recorded).
+      the chunks go out back to back (``capturing`` suppresses launches while the graph is being recorded) - or, with
+      RCCL, ``finish()`` is called INSIDE the capture (``graph_capturable``): the collectives become nodes of the step
+      graph, one replay = forward + backward + exchange, and several steps fit one graph.
+    * Contract: ONE ``backward()`` per ``finish()``.  A second backward that reaches a chunk whose all-reduce already
+      went out would add local-only gradients on top of averaged ones (replicas silently diverge), so the hook RAISES.
+      Gradient accumulation (several backwards, one exchange) goes inside ``no_sync()``: hooks only count, ``finish()``
+      after the block reduces the accumulated bucket.
     """
 
     def __init__(self, params, group=None, chunk_bytes=2 << 20, overlap=True, attach=True):
@@ -115,6 +121,7 @@ class GradBucket:
         self.group = group
         self.overlap = overlap
         self.capturing = False
+        self._defer = 0          # depth of no_sync() blocks: hooks count, nothing is launched before finish()
         if not self.params:
             raise ValueError("GradBucket needs at least one parameter that requires grad")
         order = list(reversed(self.params))
@@ -175,9 +182,35 @@ class GradBucket:
     # ---- the exchange
     def _ready(self, p):
         ci = self.chunk_of[p]
+        if self._launched[ci]:
+            raise RuntimeError(
+                "GradBucket: a second backward() produced gradients for a chunk whose all-reduce was already launched "
+                "(parameter of shape %s). One backward() per finish(); accumulate several backwards inside "
+                "`with bucket.no_sync():` and call finish() afterwards." % (tuple(p.shape),))
         self._pending[ci] -= 1
-        if self._pending[ci] == 0 and self.overlap and not self.capturing and self.active():
+        if self._pending[ci] == 0 and self.overlap and not self._defer and not self.capturing and self.active():
             self._launch(ci)
+
+    def no_sync(self):
+        """Context manager for gradient accumulation: backwards inside the block only accumulate into the bucket (no
+        collective is enqueued by the hooks); the next ``finish()`` averages the accumulated gradients in one go."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _block():
+            self._defer += 1
+            try:
+                yield self
+            finally:
+                self._defer -= 1
+
+        return _block()
+
+    @property
+    def graph_capturable(self):
+        """True when ``finish()`` may run inside a HIP graph capture: RCCL collectives are stream-ordered (enqueue +
+        event dependencies, no host wait), gloo's are host calls."""
+        return self.active() and self.attached and dist.get_backend(self.group) == "nccl"
 
     def _launch(self, ci):
         start, stop, _ = self.chunks[ci]

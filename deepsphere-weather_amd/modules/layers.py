@@ -202,16 +202,23 @@ class ConvCheb(_Fp32OperatorMixin, torch.nn.Module):
             self.in_channels, self.out_channels, self.kernel_size, self.bias is not None
         )
 
+    supports_fused_activation = True   # forward(x, activation="relu") (extension; ConvBlock uses it)
+
     def forward_activated(self, inputs, activation="relu"):
         """``activation(forward(inputs))`` with the activation applied in the epilogue of the channel-mix kernel
         (one pass less over the output than ``F.relu(conv(x))``, my_models_graph.py:108-114).  Only for the built-in
-        ``conv_cheb``; a custom ``conv=`` callable gets the plain two-step evaluation."""
+        ``conv_cheb``; a custom ``conv=`` callable gets the plain two-step evaluation.  Same as
+        ``self(inputs, activation=...)`` minus the module hooks."""
         if self._conv is conv_cheb and activation == "relu" and inputs.shape[2] == self.weight.shape[0]:
             return _F.cheb_conv(_F.get_operator(self.laplacian), inputs, self.weight, self.bias, activation="relu")
         return getattr(torch.nn.functional, activation)(self.forward(inputs))
 
-    def forward(self, inputs):
-        """``inputs``: n_signals x n_vertices x n_features."""
+    def forward(self, inputs, activation=None):
+        """``inputs``: n_signals x n_vertices x n_features.  ``activation`` (extension, default None = the reference's
+        signature): name of a ``torch.nn.functional`` activation applied to the result - "relu" rides in the
+        channel-mix epilogue."""
+        if activation is not None:
+            return self.forward_activated(inputs, activation)
         # weight / bias / laplacian are read by attribute on every call (SWAG re-assigns them)
         if self._conv is conv_cheb:
             # fused path: the bias add rides in the channel-mix epilogue (reference: layers.py:375)

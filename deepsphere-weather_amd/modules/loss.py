@@ -48,6 +48,9 @@ class WeightedMSELoss(nn.MSELoss):
         self.weights = weights
 
     def _node_weights(self, like, n_nodes):
+        """The node weights on ``like``'s device in THEIR OWN dtype (fp32 area fractions stay fp32 under bf16 / fp16
+        predictions, as in the reference: ``mse * weights`` then promotes, and the reduction and the returned loss are
+        fp32).  ``self.weights`` is never overwritten; the device copy is cached beside it."""
         w = self.weights
         if w is None:
             return torch.ones(n_nodes, dtype=like.dtype, device=like.device)
@@ -55,9 +58,12 @@ class WeightedMSELoss(nn.MSELoss):
             raise ValueError(
                 "The number of weights does not match the the number of pixels. {} != {}".format(len(w), n_nodes)
             )
-        if w.device != like.device or w.dtype != like.dtype:
-            w = self.weights = w.to(device=like.device, dtype=like.dtype)   # moved once: HIP-graph captures see a resident tensor
-        return w
+        if w.device == like.device:
+            return w
+        cached = getattr(self, "_weights_on_device", None)
+        if cached is None or cached[0] is not w or cached[1].device != like.device:
+            cached = self._weights_on_device = (w, w.to(device=like.device))   # moved once: graph captures see a resident tensor
+        return cached[1]
 
     def forward(self, pred, label):
         err2 = super().forward(pred, label)                  # element-wise (reduction="none" in the base class)

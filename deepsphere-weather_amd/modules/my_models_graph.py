@@ -72,8 +72,9 @@ class ConvBlock(GeneralConvBlock):
 
     def forward(self, x):
         if self.act and self.act_fun is F.relu and not (self.norm and self.bn_before_act) \
-                and hasattr(self.conv, "forward_activated"):
-            x = self.conv.forward_activated(x, "relu")      # conv + bias + relu in one epilogue
+                and getattr(self.conv, "supports_fused_activation", False):
+            x = self.conv(x, activation="relu")             # conv + bias + relu in one epilogue; through __call__, so
+                                                            # forward (pre-)hooks on the conv fire as on the plain path
         else:
             x = self.conv(x)
             if self.norm and self.bn_before_act:
@@ -98,9 +99,13 @@ class _NodeLinear(Linear):
         self._lay_out_weight()
 
     def _lay_out_weight(self):
-        w = self.weight
-        if w.dim() == 2 and w.stride() != (1, w.shape[0]):
-            self.weight = torch.nn.Parameter(w.detach().t().contiguous().t(), requires_grad=w.requires_grad)
+        # only a REGISTERED parameter is re-laid, and only in place of its data: SWAG (reference modules/swag.py:33-48)
+        # pops every entry of `_parameters` before `.to(device)` and later assigns plain tensors by attribute - there is
+        # nothing to lay out then, nothing may be re-registered, and `forward` reads whatever layout it is given.
+        # Swapping `.data` (not the Parameter object) keeps an optimizer's reference to the parameter valid.
+        w = self._parameters.get("weight")
+        if w is not None and w.dim() == 2 and w.stride() != (1, w.shape[0]):
+            w.data = w.data.t().contiguous().t()
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)     # .to() / .cuda() keep dense strides; anything that did not is re-laid
@@ -108,6 +113,8 @@ class _NodeLinear(Linear):
         return out
 
     def forward(self, x):
+        # `weight.t()` is dense [in, out] for the column-major parameter; a row-major tensor (SWAG sample, user
+        # assignment) is made contiguous inside dense_mix - same values either way
         return dsw_functional.dense_mix(x, self.weight.t(), self.bias)   # raises on CPU tensors like every layer here
 
 

@@ -114,7 +114,7 @@ class Trainer:
         self.model, self.x, self.targets, self.n_dyn, self.stack = model, x, targets, n_dyn, stack
         dim_names = dim_names or ["sample", "time", "node", "feature"]
         self.dim_info = {n: i for i, n in enumerate(dim_names)}
-        self.criterion = WeightedMSELoss(weights=None if weights is None else weights.to(x.device, x.dtype))
+        self.criterion = WeightedMSELoss(weights=None if weights is None else weights.to(x.device))   # fp32 area weights, as the reference
         self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized() \
             and torch.distributed.get_world_size() > 1
         # capturable: the step counter lives on the device, so optimizer.step() can sit inside a HIP graph
@@ -123,6 +123,7 @@ class Trainer:
         self.bucket = GradBucket(model.parameters(), overlap=True)
         self.loss = None
         self.graph = None
+        self.sync_in_graph = False
         self.launch = "eager" if not self.distributed else "eager, chunked all-reduce overlapped with backward"
         if use_graph and x.is_cuda:
             self._capture()
@@ -152,15 +153,22 @@ class Trainer:
         torch.cuda.synchronize()
         try:
             g = torch.cuda.CUDAGraph()
+            # RCCL collectives are stream-ordered and can be recorded: the exchange and the optimizer update then
+            # sit in the graph as well (N > 1: one replay = the whole step).  gloo's are host calls: they follow the replay.
+            self.sync_in_graph = self.distributed and self.bucket.graph_capturable
             self.bucket.capturing = True      # the hooks must not enqueue collectives into the recording
             with torch.cuda.graph(g):
                 self.loss = self._fwd_bwd()
-                if not self.distributed:
+                if self.sync_in_graph:
+                    self.bucket.finish()      # all chunks back to back, as nodes of the graph
+                if not self.distributed or self.sync_in_graph:
                     self.optimizer.step()
             self.bucket.capturing = False
-            self.bucket.finish()              # resets the hook counters of the recorded backward
+            if not self.sync_in_graph:
+                self.bucket.finish()          # resets the hook counters of the recorded backward
             self.graph = g
             self.launch = "hip graph: whole step" if not self.distributed else \
+                "hip graph: whole step incl. the RCCL gradient all-reduce" if self.sync_in_graph else \
                 "hip graph: fwd+bwd; chunked all-reduce + Adam eagerly after the replay"
         except Exception as exc:  # noqa: BLE001 - capture not possible: stay eager
             print("trainer: HIP graph capture unavailable (%s: %s); stepping eagerly" % (type(exc).__name__, exc),
@@ -180,7 +188,7 @@ class Trainer:
         if self.graph is None:
             return self._eager_step()
         self.graph.replay()
-        if self.distributed:
+        if self.distributed and not self.sync_in_graph:
             self.bucket.finish()
             self.optimizer.step()
         return self.loss

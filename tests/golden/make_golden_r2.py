@@ -91,6 +91,7 @@ def g8():
 
 
 G9_LR = 2e-4   # Adam moves every parameter by ~lr per step: 0.007 (the config default) blows this random model up
+G9_TIE = 1e-4  # pre-activations closer to zero than this have their ReLU decision RECORDED (see g9)
 
 
 def g9():
@@ -120,6 +121,27 @@ def g9():
     targets = [torch.from_numpy(recipes.rand(902 + i, (2, 1, V, 2))) for i in range(2)]   # ar_iterations = 1
     losses, grad_probes0, upd_l2, heads = [], None, None, None
     before = {n: params[n].detach().clone() for n in names}
+    # ReLU ties.  A step evaluates ~1.8 M pre-activations of unit scale: a few hundred lie within 1e-4 of zero and a
+    # handful within 1e-6 - no seed avoids that (expected minimum |z| ~ 1 / (2 N pdf(0)) ~ 3e-7).  On which side of zero
+    # such an element falls is decided by the fp32 summation order, and on the coarse levels (48 nodes) ONE flipped mask
+    # moves a weight-gradient fingerprint by ~1e-2.  The fixture therefore records the reference's decision for every
+    # pre-activation with |z| < G9_TIE (block, call number, flat index, sign): the parity test pins exactly these masks
+    # and nothing else, so the fixture no longer depends on the order in which a kernel sums a row.
+    tie_blocks = sorted(n for n, m in model.named_modules() if n.rsplit(".", 1)[-1].startswith("convblock") and m.act)
+    ties, calls, min_abs = [], {n: 0 for n in tie_blocks}, [np.inf]
+
+    def watch(name):
+        def hook(_m, _a, out):
+            z = out.detach().reshape(-1)
+            near = torch.nonzero(z.abs() < G9_TIE).reshape(-1)
+            for i in near.tolist():
+                ties.append((tie_blocks.index(name), calls[name], i, 1 if float(z[i]) > 0 else 0))
+            min_abs[0] = min(min_abs[0], float(z.abs().min()))
+            calls[name] += 1
+        return hook
+
+    for n in tie_blocks:
+        model.get_submodule(n).conv.register_forward_hook(watch(n))     # conv output (+ bias) = the ReLU's input
     for step in range(3):
         optimizer.zero_grad(set_to_none=True)
         x, loss = x0, 0.0
@@ -138,8 +160,14 @@ def g9():
             upd_l2 = np.array([float((params[n].detach() - before[n]).double().norm()) for n in names])
             heads = np.stack([np.resize(params[n].detach().numpy().ravel()[:32], 32) for n in names])
         losses.append(loss.item())
+    ties = np.array(ties, dtype=np.int64).reshape(-1, 4)
+    assert all(c == 6 for c in calls.values()), calls              # 3 steps x 2 forwards
+    assert len(ties) < 4000, len(ties)
+    print("G9: %d pre-activations within %.0e of zero over 3 steps (min |z| = %.2e); recorded" % (len(ties), G9_TIE, min_abs[0]))
     arrays = {"losses": np.array(losses), "grad_probes0": grad_probes0, "update_l2": upd_l2, "param_heads1": heads,
-              "param_names": np.array(names), "weights": weights.numpy(), "lr": np.array([G9_LR])}
+              "param_names": np.array(names), "weights": weights.numpy(), "lr": np.array([G9_LR]),
+              "tie_blocks": np.array(tie_blocks), "ties": ties, "tie_threshold": np.array([G9_TIE]),
+              "tie_min_abs": np.array([min_abs[0]])}
     for lvl, lap in enumerate(model.laplacians):
         rp, ci, va = csr_of(lap)
         arrays.update({f"lap{lvl}_rowptr": rp, f"lap{lvl}_colind": ci, f"lap{lvl}_values": va})

@@ -188,3 +188,60 @@ def test_two_rank_gloo_attached_overlapped_bucket():
     for p, q in zip(out[0][0], out[1][0]):
         assert torch.equal(p, q)
     assert torch.equal(out[0][1], out[1][1])
+
+
+def _accumulate_worker(rank, world, port, out):
+    for p in (os.path.join(REPO, "deepsphere-weather_amd"), REPO, os.path.join(REPO, "tests"), os.path.join(REPO, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from dsw_amd.parallel import GradBucket, init_from_env
+
+    init_from_env("gloo")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
+    bucket = GradBucket(model.parameters(), chunk_bytes=100, overlap=True)
+    g = torch.Generator().manual_seed(rank)
+    xs = [torch.randn(3, 6, generator=g) for _ in range(2)]
+    # (1) a second backward before finish(): the first one's chunks are already out -> loud error, not silent divergence
+    bucket.zero()
+    model(xs[0]).sum().backward()
+    raised = False
+    try:
+        model(xs[1]).sum().backward()
+    except RuntimeError as exc:
+        raised = "no_sync" in str(exc)
+    bucket.finish()
+    # (2) accumulation inside no_sync(): two backwards, ONE exchange of the accumulated bucket
+    bucket.zero()
+    with bucket.no_sync():
+        model(xs[0]).sum().backward()
+        model(xs[1]).sum().backward()
+        launched_inside = sum(bucket._launched)
+    bucket.finish()
+    out[rank] = (raised, launched_inside, [p.grad.clone() for p in model.parameters()])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_bucket_reentry_raises_and_no_sync_accumulates():
+    """with `overlap`, a second backward() before finish() used to average only the first one's
+    gradients.  Now it raises; `no_sync()` is the accumulation mode."""
+    world = 2
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_accumulate_worker, args=(world, port, out), nprocs=world, join=True)
+    torch.manual_seed(0)
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3)).double()
+    for rank in range(world):
+        g = torch.Generator().manual_seed(rank)
+        for _ in range(2):
+            (ref(torch.randn(3, 6, generator=g).double()).sum() / world).backward()
+    for r in range(world):
+        raised, launched_inside, grads = out[r]
+        assert raised and launched_inside == 0
+        for got, want in zip(grads, ref.parameters()):
+            np.testing.assert_allclose(got.numpy(), want.grad.numpy(), rtol=0, atol=2e-6)
+    for a, b in zip(out[0][2], out[1][2]):
+        assert torch.equal(a, b)

@@ -6,7 +6,7 @@ spare planes, the bf16 raw-copy wgrad, the UNet's wide layers at nside=32, the 8
 and compare EVERY element of y, dX, dW, db with the oracle (numpy fp64: seconds to a minute per case).
 
 Tolerances (normalised by max|ref|): fp32 <= 2e-6 (y, dX) / <= 1e-5 (dW, db: fp32 sums over 786 432
-rows); bf16 storage <= 3e-2.  Measured errors are appended to gpurun_out/parity_fullsize.json for DESIGN.md.
+rows); bf16 storage <= 1e-2.  Measured errors are appended to gpurun_out/parity_fullsize.json for DESIGN.md.
 """
 import json
 import os
@@ -94,7 +94,7 @@ def test_c3_full_size_forward_backward_vs_oracle():
     """BASELINE configs[2] (nside=64, K=5, 64->128, B=16, bf16 storage): fused pairs + spare planes, bf16 wgrad."""
     errs = _layer_case(_healpix_operator(64, 8), 16, 64, 128, 5, torch.bfloat16, seed=3100)
     _record("c3_k8_bf16", errs)
-    assert max(errs.values()) <= 3e-2
+    assert max(errs.values()) <= 1e-2     # measured 2.4e-3 .. 4.5e-3 (round 2)
 
 
 def test_c3_shape_fp32_full_size_vs_oracle():
@@ -225,11 +225,8 @@ def test_unet_nside32_batch8_vs_cpu_restatement():
     except OSError:
         pass
     assert errs["y"] <= 1e-5 and errs["loss"] <= 1e-5, errs
-    # gradients of a 22-layer network: every tensor must be at least as close to fp64 as the reference's own fp32 CPU
-    # path is (measured 1.2e-4 on its worst tensor), and within 1e-4 absolutely
-    assert errs["grad_weights_max"] <= 1e-4 and errs["grad_bias_rezero_max"] <= 1e-4, (worst_name, errs)
-    # (the worst tensors are sums of positive post-ReLU activations against zero-mean upstream gradients: both fp32
-    # paths land within 1 % of each other there - 3.96e-5 vs 3.98e-5 on conv2.convblock1.conv.weight - because the
-    # deviation is the fp32 STORAGE rounding of the inter-layer tensors, which the fp64-backed run does not share)
-    assert all(e_dev <= max(2e-5, 1.5 * e_t32) for e_dev, e_t32, _ in per_tensor), per_tensor[:6]
+    # gradients of a 22-layer network against the fp64-backed run of the same model.  Gates = ~5x the measured errors
+    # (round 2, profiles/r02_parity_fullsize.json: weight tensors 1.06e-6, ReZero scalars / biases 1.3e-5 - the latter
+    # are single fp32 sums of ~1e6 signed products); the reference's own fp32 CPU path is 1.2e-4 / 3.6e-5 off the same run
+    assert errs["grad_weights_max"] <= 5e-6 and errs["grad_bias_rezero_max"] <= 5e-5, (worst_name, errs)
     assert errs["y_vs_torch32"] <= 1e-5 and errs["grad_weights_max_vs_torch32"] <= 3e-4, errs   # the restatement's own fp32 error

@@ -2,7 +2,7 @@
 
 Tolerances (errors normalised by max|ref|):
   fp32: <= 1e-5 vs the reference's fp32 output (golden) and <= 2e-6 vs the fp64 closed form;
-  bf16 storage (fp32 operator + accumulation): <= 3e-2 vs fp64.
+  bf16 storage (fp32 operator + accumulation): <= 1e-2 vs fp64.
 """
 import os
 
@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 TOL_GOLD = 1e-5
 TOL_F64 = 2e-6
-TOL_BF16 = 3e-2
+TOL_BF16 = 1e-2    # measured 2e-3 .. 5e-3 (SURVEY 8c proposed 3e-2: the reference's OWN bf16 CPU path is 1.1e-2 .. 2.6e-2 off)
 DEV = "cuda:0"
 
 
@@ -125,6 +125,11 @@ def test_remap_golden(tag):
     y.backward(torch.from_numpy(g[f"{tag}_gyp"]).to(DEV))
     assert orc.max_rel_err(y, g[f"{tag}_yp"]) <= TOL_GOLD
     assert orc.max_rel_err(x.grad, g[f"{tag}_dxp"]) <= TOL_GOLD
+    # WAIVED on purpose: the reference hands out a permuted view of its internal [V, F, B] product (strides recorded in
+    # the fixture, reproduced by the oracle restatement); the HIP path computes in the callers' [B, V, F] layout and
+    # returns it contiguous - same shape and values, and every consumer in the reference (ConvCheb.forward: layers.py:158
+    # makes its input contiguous; torch.cat) accepts either
+    assert tuple(g[f"{tag}_yp_strides"]) != tuple(y.stride()) and y.is_contiguous()
     xu = torch.from_numpy(g[f"{tag}_xu"]).to(DEV).requires_grad_(True)
     yu = unpool(xu, None)
     yu.backward(torch.from_numpy(g[f"{tag}_gyu"]).to(DEV))
@@ -238,8 +243,8 @@ def test_conv_vs_oracle_bf16(V, B, Fin, Fout, K):
     layer = ConvCheb(Fin, Fout, K, laplacian=lap, bias=True)
     layer.set_parameters(wq.float(), bq.float())
     layer = layer.to(DEV).to(torch.bfloat16)
-    # the module cast also rounds the operator buffer to bf16 (as the reference does); the kernels
-    # widen it back to fp32, so the oracle must see the same rounded operator
+    # the module cast leaves the operator buffer at fp32 (_Fp32OperatorMixin; the reference rounds it to bf16): the
+    # oracle reads back exactly the values the kernels use
     va_q = layer.laplacian.coalesce().values().float().cpu().numpy()
     y, dx, dw, db = _run_layer(layer, xq.to(DEV), gyq.to(DEV))
     assert y.dtype == torch.bfloat16 and dx.dtype == torch.bfloat16 and dw.dtype == torch.bfloat16
@@ -762,18 +767,39 @@ def test_rezero_residual_unaligned_views():
     assert abs(float(w.grad) - float((g.double() * c.detach().double()).sum())) <= 1e-4
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_ar_training_steps_golden_g9(use_graph):
+@pytest.mark.parametrize("use_graph,min_tiles", [(False, None), (True, None), (False, 1)])
+def test_ar_training_steps_golden_g9(use_graph, min_tiles):
     """Three autoregressive optimisation steps of the training driver (UNetSpherical nside=8, WeightedMSELoss, Adam
     eps=1e-7; two forwards per step) against the reference run of fixture G9 - launched eagerly and as a replayed HIP
-    graph of the whole step (zero_grad + forwards + backward + Adam)."""
-    from test_host_logic import build_g9_trainer, check_g9
+    graph of the whole step (zero_grad + forwards + backward + Adam).
 
-    trainer, g, names = build_g9_trainer(DEV, use_graph=use_graph)
-    if use_graph:
-        assert trainer.graph is not None and trainer.launch.startswith("hip graph"), trainer.launch
-    losses = check_g9(trainer, g, names)
-    print("G9 losses", losses, "reference", g["losses"])
+    The eager runs compare gradient fingerprints, which on the 48-node level react to a single ReLU mask: the ~400
+    pre-activations the reference found within 1e-4 of zero get the reference's recorded mask (`pin_g9_ties`), so the
+    comparison does not depend on the order in which a kernel sums a row.  `min_tiles = 1` proves it: the fused two-hop
+    kernels (another summation order) then also run the 192- and 48-node levels, which the product keeps on one launch
+    per hop for speed - the fixture no longer constrains that choice."""
+    from dsw_amd import functional as F_
+    from test_host_logic import build_g9_trainer, check_g9, pin_g9_ties
+
+    keep = F_.MIN_CLUSTERED_TILES
+    try:
+        if min_tiles is not None:
+            F_.MIN_CLUSTERED_TILES = min_tiles
+            F_.invalidate_operator_caches()
+        trainer, g, names = build_g9_trainer(DEV, use_graph=use_graph)
+        flipped = None
+        if use_graph:
+            assert trainer.graph is not None and trainer.launch.startswith("hip graph"), trainer.launch
+        else:
+            flipped, _handles = pin_g9_ties(trainer.model, g)
+        losses = check_g9(trainer, g, names)
+        print("G9 losses", losses, "reference", g["losses"], "pinned masks that differed:", flipped)
+        if flipped is not None:
+            assert flipped["n"] <= 12, flipped       # only elements with |z| of a few 1e-7 may land on the other side
+    finally:
+        F_.MIN_CLUSTERED_TILES = keep
+        if min_tiles is not None:
+            F_.invalidate_operator_caches()
 
 
 @pytest.mark.parametrize("V,B,Fin,Fout,K,dt", [
@@ -1027,3 +1053,50 @@ def test_unet_bf16_storage_tracks_fp32(pool_method):
     assert orc.max_rel_err(y16, y32.cpu().numpy()) <= tol_y
     worst = max(float((g16[n] - g32[n]).norm() / (g32[n].norm() + 1e-12)) for n in g32)
     assert worst <= tol_g, worst
+
+
+def test_bench_two_ranks_self_launched():
+    """`python bench.py --gpus 2` (no torchrun around it) starts two ranks itself, and the line says
+    so.  One GPU here, so both ranks share it and talk through gloo (DSW_DIST_BACKEND); the launch path, the world-size
+    check, the bucket + exchange after every step, the timed region and the max-over-ranks are the RCCL run's."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["DSW_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 12 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 32 and out["config"]["batch_per_gpu"] == 16
+    assert "self-launch" in out["config"]["launcher"]
+    assert out["grad_sync"]["identical"] and out["grad_sync"]["grad_l2"] > 0, out["grad_sync"]
+    assert out["allreduce_us"] > 0 and out["allreduce"]["bytes"] == 4 * (32 * 3 * 64 + 64)
+    assert out["value"] == pytest.approx(2 * 16 * 49152 * 32 / (out["ms_per_step"] * 1e-3), rel=1e-6)
+    assert "roofline" not in out and "cpu_baseline" not in out          # N = 1 legs only
+
+
+def test_bench_one_rank_world_captures_the_exchange():
+    """The RCCL exchange recorded INTO the step graph (what N > 1 runs replay): a one-rank RCCL world on this box
+    (DSW_FORCE_GRAD_SYNC=1).  The captured graph must reproduce the eager step + all-reduce, and the bench must say which
+    of the two launch modes it timed."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DSW_DIST_BACKEND")}
+    env.update(DSW_FORCE_GRAD_SYNC="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "2", "--no-cpu-baseline",
+                        "--no-roofline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    print(out["config"]["launch"], out.get("allreduce"))
+    assert out["n_gpus"] == 1 and "all-reduce" in out["config"]["launch"]
+    assert "captured in the graph" in out["config"]["launch"], (out["config"]["launch"], out["allreduce"], r.stderr[-1500:])
+    assert "%d steps per graph" % 10 in out["config"]["launch"]

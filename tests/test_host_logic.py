@@ -486,6 +486,35 @@ def build_g9_trainer(device="cpu", use_graph=False):
     return trainer, g, names
 
 
+def pin_g9_ties(model, g):
+    """Fixture G9 records, for every pre-activation the reference found within `tie_threshold` (1e-4) of zero, on which
+    side of zero its fp32 sum fell (block, forward number, flat index, sign).  A kernel that sums a row in another order
+    may land on the other side for the handful of elements with |z| ~ 1e-7 - a legitimate fp32 result, but on the 48-node
+    level ONE flipped mask moves a weight-gradient fingerprint by ~1e-2.  The hooks below give exactly these elements
+    the reference's mask (forward values change by < |z| <= 1e-4 only where the sign disagrees, i.e. by ~1e-7) and touch
+    nothing else; returns a counter of how many decisions actually differed."""
+    ties, blocks = g["ties"], [str(b) for b in g["tie_blocks"]]
+    flipped = {"n": 0}
+    handles = []
+    for bi, name in enumerate(blocks):
+        block = model.get_submodule(name)
+        mine = ties[ties[:, 0] == bi]
+        state = {"call": 0}
+
+        def hook(_m, _a, out, mine=mine, state=state):
+            rows = mine[mine[:, 1] == state["call"]]
+            state["call"] += 1
+            if len(rows):
+                flat = out.data.view(-1)                     # .data: not an autograd-visible edit of the saved ReLU output
+                idx = torch.from_numpy(rows[:, 2].copy()).to(out.device)
+                pos = torch.from_numpy(rows[:, 3].astype(bool)).to(out.device)
+                cur = flat[idx]
+                flipped["n"] += int(((cur > 0) != pos).sum())
+                flat[idx] = torch.where(pos, cur.clamp_min(1e-30), torch.zeros_like(cur))
+        handles.append(block.register_forward_hook(hook))
+    return flipped, handles
+
+
 def check_g9(trainer, g, names, tol=1e-5):
     """Losses of three optimisation steps, gradient fingerprints of step 0 and the first Adam update against the
     reference run.  Adam's first update is lr * g / (|g| + 1e-7): elements whose gradient is ~1e-7 amplify rounding
@@ -520,7 +549,9 @@ def check_g9(trainer, g, names, tol=1e-5):
 def test_ar_training_steps_match_reference_fixture_on_cpu_wiring(oracle_backend):
     trainer, g, names = build_g9_trainer()
     assert trainer.launch == "eager"
+    flipped, _handles = pin_g9_ties(trainer.model, g)
     check_g9(trainer, g, names)
+    assert flipped["n"] == 0, flipped     # the oracle backend IS the reference's op sequence: every recorded mask agrees
 
 
 def check_concat_in_place(device, dtype=torch.float32, tol=2e-6):
@@ -707,3 +738,104 @@ def test_in_tree_library_is_the_product_build():
     blob = open(_native.LIB_PATH, "rb").read()
     for name in (b"DSW_GEMM_X3", b"DSW_FWD_FUSED", b"DSW_H2_CHUNKS", b"DSW_SPMM_XCD", b"DSW_MIX_FIRST"):
         assert name not in blob, "diagnostics build in the tree: rebuild with `python -m dsw_amd.build --force`"
+
+
+# ----------------------------------------------------------------------------------------------
+# ADVICE round 2
+# ----------------------------------------------------------------------------------------------
+def test_node_linear_swag_flow(oracle_backend):
+    """The reference's SWAG (modules/swag.py:33-48, utils_config.py:399) pops every entry of `_parameters`, calls
+    `.to(device)`, then assigns plain tensors by attribute: `_NodeLinear` must survive `.to()` without a registered
+    weight, must not re-register one afterwards, and must give the same values from a row-major plain tensor."""
+    from modules.my_models_graph import _NodeLinear
+
+    torch.manual_seed(3)
+    lin = _NodeLinear(6, 4)
+    assert lin.weight.stride() == (1, 4)
+    x = torch.randn(2, 5, 6)
+    want = torch.nn.functional.linear(x, lin.weight.detach(), lin.bias.detach())
+    assert torch.allclose(lin(x), want, atol=1e-6)
+    w_mean, b_mean = lin.weight.detach().clone().contiguous(), lin.bias.detach().clone()
+    opt = torch.optim.SGD(lin.parameters(), lr=0.1)
+    ident = id(lin.weight)
+    lin.float()                                        # an _apply with a registered parameter: same Parameter object
+    assert id(lin.weight) == ident and opt.param_groups[0]["params"][0] is lin.weight
+    for name in list(lin._parameters):                 # SWAG: parameters become plain attributes
+        lin._parameters.pop(name)
+    lin.to("cpu").float()                              # used to raise AttributeError: no attribute 'weight'
+    lin.weight, lin.bias = w_mean, b_mean              # SWAG.sample(): plain (row-major) tensors
+    lin.double().float()
+    assert "weight" not in lin._parameters and not isinstance(lin.weight, torch.nn.Parameter)
+    assert torch.allclose(lin(x), want, atol=1e-6)
+
+
+def test_skip_buffer_ignores_lookalike_tensors():
+    """A caller's tensor that merely HAS the strides of a skip slice (right-hand channel slice of its own dense wider
+    tensor) is not a concatenation buffer: only storages allocated by skip_slot are ever completed in place."""
+    from dsw_amd import functional as F_
+
+    wide = torch.arange(2 * 5 * 24, dtype=torch.float32).reshape(2, 5, 24)
+    lookalike = wide[..., 8:]
+    assert lookalike.stride() == (5 * 24, 24, 1) and lookalike.storage_offset() == 8
+    assert F_.skip_buffer(lookalike, 8) is None
+    slot = F_.skip_slot(torch.zeros(2, 5, 4), 5, 8, 16)
+    assert F_.skip_buffer(slot, 8) is not None
+    assert F_.skip_buffer(slot, 4) is None and F_.skip_buffer(slot[:, :, :8], 8) is None   # other geometry: no
+    view = slot.view_as(slot)                                                             # what autograd nodes return
+    assert F_.skip_buffer(view, 8) is not None
+
+
+def test_fused_activation_path_fires_module_hooks(oracle_backend):
+    """ConvBlock's conv + relu runs through `ConvCheb.__call__` (activation kwarg): forward hooks / pre-hooks registered
+    on the conv fire on the fused path exactly as on the plain one."""
+    from modules.my_models_graph import ConvBlock
+
+    lap = tiny_laplacian() if "tiny_laplacian" in globals() else None
+    if lap is None:
+        from dsw_amd import sphere
+        from modules.layers import prepare_torch_laplacian
+        lap = prepare_torch_laplacian(sphere.SphereHealpix(2, nest=True, k=8).L, lmax=1.9)
+    block = ConvBlock(3, 5, lap, kernel_size=3)
+    seen = []
+    block.conv.register_forward_pre_hook(lambda m, a: seen.append("pre"))
+    block.conv.register_forward_hook(lambda m, a, o: seen.append(("post", tuple(o.shape), bool((o >= 0).all()))))
+    x = torch.randn(2, lap.shape[0], 3)
+    y = block(x)
+    assert seen == ["pre", ("post", (2, lap.shape[0], 5), True)]
+    assert torch.equal(y, torch.relu(block.conv(x)))
+
+
+def test_weighted_mse_keeps_fp32_weights_under_bf16():
+    from modules.loss import WeightedMSELoss
+
+    torch.manual_seed(0)
+    w = torch.rand(7) + 0.5
+    w = w / w.sum()
+    crit = WeightedMSELoss(weights=w)
+    p, t = torch.randn(3, 7, 2), torch.randn(3, 7, 2)
+    loss = crit(p.bfloat16(), t.bfloat16())
+    assert loss.dtype == torch.float32 and crit.weights is w and crit.weights.dtype == torch.float32
+    err2 = (p.bfloat16() - t.bfloat16()) ** 2                 # the reference: bf16 element-wise error x fp32 weights
+    want = (err2 * w.view(1, -1, 1)).sum() / w.sum() / 3 / 2
+    assert torch.allclose(loss, want, rtol=1e-6)
+    assert torch.allclose(crit(p, t), ((p - t) ** 2 * w.view(1, -1, 1)).sum() / w.sum() / 3 / 2, rtol=1e-6)
+
+
+def test_bench_gpus_flag_is_not_ignored():
+    import os
+    """VERDICT r2: `--gpus N` used to be parsed and dropped.  Without devices the self-launcher must refuse loudly (no
+    silent 1-rank run), and a torchrun environment whose WORLD_SIZE differs from --gpus must be rejected before any
+    process group is created."""
+    import subprocess
+    import sys
+
+    bench = os.path.join(REPO, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DSW_DIST_BACKEND")}
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "2"], env=env, capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode != 0 and "--gpus 2" in r.stderr and "device" in r.stderr, (r.returncode, r.stderr[-400:])
+        assert '"metric"' not in r.stdout
+    r = subprocess.run([sys.executable, bench, "--gpus", "4", "--steps", "2"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 4" in r.stderr and "2 rank" in r.stderr, (r.returncode, r.stderr[-400:])

@@ -66,6 +66,8 @@ def test_remap_fixture(tag):
         m = orc.coo_from_csr_arrays(rp, ci, va, shape)
         y = orc.remap_torch(m, torch.from_numpy(x))
         assert orc.max_rel_err(y, y_ref) <= TOL32
+        # the reference returns a PERMUTED VIEW (layers.py:963); the restatement reproduces its recorded strides
+        assert tuple(y.stride()) == tuple(int(v) for v in g[f"{tag}_{yout}_strides"])
         assert orc.max_rel_err(y_ref, orc.remap_f64(rp, ci, va, shape, x)) <= TOL64
         assert orc.max_rel_err(dx_ref, orc.remap_backward_f64(rp, ci, va, shape, gy)) <= TOL64
         # invariants the reference asserts on its pooling matrices (layers.py:557-571): rows sum to 1
