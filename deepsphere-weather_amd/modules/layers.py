@@ -53,10 +53,15 @@ _LINEAR_LIKE = {"linear", "hardshrink ", "sigmoid", "hardsigmoid", "tanh", "hard
 # Operator preparation
 # ----------------------------------------------------------------------------------------------
 def estimate_lmax(laplacian, tol=5e-3):
-    """Largest eigenvalue (ARPACK, one Ritz value) with the reference's (1 + 2 tol) safety margin."""
-    ev = sparse_linalg.eigs(
-        laplacian, k=1, tol=tol, ncv=min(laplacian.shape[0], 10), return_eigenvectors=False
-    )
+    """Largest eigenvalue (ARPACK, one Ritz value) with the reference's (1 + 2 tol) safety margin.
+
+    The reference (layers.py:57-69) lets ARPACK draw its start vector: at ``tol = 5e-3`` the estimate then jitters by
+    ~3e-4 from call to call, i.e. two builds of one model - or the replicas of a data-parallel job - convolve with
+    slightly different operators.  Here the start vector is a fixed seeded draw: same algorithm and tolerance, a value
+    inside the reference's own scatter, but the SAME value every time."""
+    n = laplacian.shape[0]
+    v0 = np.random.default_rng(20210317).standard_normal(n).astype(laplacian.dtype if laplacian.dtype.kind == "f" else np.float64)
+    ev = sparse_linalg.eigs(laplacian, k=1, tol=tol, ncv=min(n, 10), return_eigenvectors=False, v0=v0)
     return float(np.real(ev[0])) * (1 + 2 * tol)
 
 

@@ -186,11 +186,16 @@ def test_unet_nside32_batch8_vs_cpu_restatement():
         loss.backward()
         return y.detach().cpu(), loss.item(), {n: p.grad.detach().cpu() for n, p in m.named_parameters()}
 
+    from test_host_logic import pin_relu_masks, record_relu_masks
+
     functional.set_test_backend(OracleBackend())
     try:
+        masks, handles = record_relu_masks(model)
         y_ref, loss_ref, g_ref = run(model, "cpu")
     finally:
         functional.set_test_backend(None)
+        for h in handles:
+            h.remove()
     # second checker: the torch-CPU restatement of the reference model (oracle/unet_oracle.py, fp32 ATen kernels,
     # autograd backward; pinned on fixture G5).  Its own fp32 reductions are ~1e-4 off fp64 on the scalar / bias
     # gradients, so it gets the looser bound.
@@ -198,7 +203,14 @@ def test_unet_nside32_batch8_vs_cpu_restatement():
 
     sd = unet_oracle.leaf_state(model.state_dict())
     y_t, loss_t, g_t = unet_oracle.unet_fwd_bwd(sd, x, target)
+    # ReLU ties: of ~4e8 pre-activations a handful (|z| ~ 1e-7) fall on the other side of zero in a second correct fp32
+    # evaluation; on the 768-node level one of them moves a weight-gradient element by 1e-5 .. 1e-4.  The device run
+    # takes the reference run's decision for exactly those elements (they must be < 1e-4, else the hook raises)
+    flipped, handles = pin_relu_masks(model, masks)
     y_dev, loss_dev, g_dev = run(model.to(DEV), DEV)
+    for h in handles:
+        h.remove()
+    print("ReLU decisions that differed between the fp64-backed and the device run:", flipped)
     # weight tensors [Fin, K, Fout] / [Fout, Fin] vs the 1-D ones (biases, ReZero scalars): the latter are plain sums of
     # ~1e6 signed products whose fp32 evaluation cancels heavily - the reference's own fp32 CPU path is 1.2e-4 off fp64
     # there (recorded as torch32_vs_f64_*), so they get the looser bound
@@ -225,8 +237,9 @@ def test_unet_nside32_batch8_vs_cpu_restatement():
     except OSError:
         pass
     assert errs["y"] <= 1e-5 and errs["loss"] <= 1e-5, errs
-    # gradients of a 22-layer network against the fp64-backed run of the same model.  Gates = ~5x the measured errors
-    # (round 2, profiles/r02_parity_fullsize.json: weight tensors 1.06e-6, ReZero scalars / biases 1.3e-5 - the latter
-    # are single fp32 sums of ~1e6 signed products); the reference's own fp32 CPU path is 1.2e-4 / 3.6e-5 off the same run
+    # gradients of a 22-layer network against the fp64-backed run of the same model (same ReLU decisions, see above):
+    # what is left is fp32 storage rounding of the inter-layer tensors and the fp32 sums of ~1e6 signed products behind
+    # the biases / ReZero scalars.  The reference's own fp32 CPU path (torch32_vs_f64_*) is 3e-5 .. 1e-4 off the same run
+    # measured with the decisions pinned: weight tensors 1.1e-6, ReZero scalars / biases 1.3e-5 -> gates at ~4-5x
     assert errs["grad_weights_max"] <= 5e-6 and errs["grad_bias_rezero_max"] <= 5e-5, (worst_name, errs)
     assert errs["y_vs_torch32"] <= 1e-5 and errs["grad_weights_max_vs_torch32"] <= 3e-4, errs   # the restatement's own fp32 error

@@ -882,13 +882,21 @@ def test_unet_variants_vs_oracle_backed_run(bn_before_act, pool_method):
         return y.detach().cpu(), {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None}
 
     import copy
+    from test_host_logic import pin_relu_masks, record_relu_masks
+
     ref_model = copy.deepcopy(model)          # BatchNorm running statistics are updated by a forward: separate copies
     functional.set_test_backend(OracleBackend())
     try:
+        masks, _h = record_relu_masks(ref_model)
         y_ref, g_ref = run(ref_model, "cpu")
     finally:
         functional.set_test_backend(None)
+    # the device run takes the reference's decision for the (rare) pre-activations that land on the other side of zero
+    # by ~1e-7: with batch statistics over 144 samples per channel one such element moves whole weight gradients by 1e-2
+    flipped, _h = pin_relu_masks(model, masks)
     y_dev, g_dev = run(model.to(DEV), DEV)
+    print("ReLU decisions that differed (|z| < 1e-4):", flipped)
+    assert flipped["n"] <= 8, flipped
     assert set(g_dev) == set(g_ref)
     if pool_method == "maxval":
         # an arg-max is discontinuous: where two candidates tie to within fp32 rounding, the fp32 device run and the

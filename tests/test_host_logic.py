@@ -486,6 +486,60 @@ def build_g9_trainer(device="cpu", use_graph=False):
     return trainer, g, names
 
 
+def _relu_output_modules(model):
+    """(name, module whose forward output IS a ReLU result) for every ConvBlock with an activation: the conv itself when
+    conv + bias + relu run fused (its output is what backward takes the mask from), the block when the activation is a
+    separate op after a batch norm."""
+    out = []
+    for name, block in model.named_modules():
+        if not (hasattr(block, "act_fun") and hasattr(block, "conv") and block.act):
+            continue
+        if block.norm and block.bn_before_act:
+            out.append((name, block))
+        else:
+            out.append((name + ".conv", block.conv))
+    return out
+
+
+def record_relu_masks(model):
+    """Forward hooks that keep the sign pattern of every ReLU output (per module and call).  Returns (masks, handles)."""
+    masks, handles = {}, []
+    for name, mod in _relu_output_modules(model):
+        def hook(_m, _a, out, name=name):
+            masks.setdefault(name, []).append((out.detach() > 0).cpu())
+        handles.append(mod.register_forward_hook(hook))
+    return masks, handles
+
+
+def pin_relu_masks(model, masks, tiny=1e-4):
+    """Give a second run of the same model the ReLU decisions of a first one (`record_relu_masks`).  Two correct fp32
+    evaluations of a network agree to ~1e-6 per element, which still leaves the odd pre-activation with |z| ~ 1e-7 on
+    different sides of zero; on a 48- or 192-node level ONE such element moves a weight gradient by 1e-2 (measured:
+    uconv2.convblock1, |z| = 7e-7 -> 6e-2), so an element-wise gradient comparison would test the dice, not the kernels.
+    Only elements whose two evaluations disagree in sign are touched, and they must be smaller than `tiny` (else the
+    runs really differ and the hook raises).  Returns a counter of the decisions that differed."""
+    flipped = {"n": 0, "max_abs": 0.0}
+    handles = []
+    for name, mod in _relu_output_modules(model):
+        state = {"call": 0}
+
+        def hook(_m, _a, out, name=name, state=state):
+            want = masks[name][state["call"]].to(out.device)
+            state["call"] += 1
+            y = out.data                          # .data: not an autograd-visible edit of the saved ReLU output
+            dis = (y > 0) != want
+            n = int(dis.sum())
+            if n:
+                mag = float(y[dis].abs().max())
+                assert mag < tiny, (name, n, mag)
+                flipped["n"] += n
+                flipped["max_abs"] = max(flipped["max_abs"], mag)
+                y[dis & want] = 1e-30
+                y[dis & ~want] = 0.0
+        handles.append(mod.register_forward_hook(hook))
+    return flipped, handles
+
+
 def pin_g9_ties(model, g):
     """Fixture G9 records, for every pre-activation the reference found within `tie_threshold` (1e-4) of zero, on which
     side of zero its fp32 sum fell (block, forward number, flat index, sign).  A kernel that sums a row in another order
