@@ -77,6 +77,15 @@ static __device__ __forceinline__ bf16x8_t read_frag_tr(const unsigned short* p)
     return __builtin_bit_cast(bf16x8_t, r);
 }
 
+// the same fragment from two explicit addresses (rows +0..3 and rows +4..7): swizzled images
+static __device__ __forceinline__ bf16x8_t read_frag_tr2(const unsigned short* p0, const unsigned short* p1) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
+    const s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8_t, r);
+}
+
 // FUSE (fp32, one o-tile covering all of Fout, one (k,f)-group): the workgroup holds the dY rows it needs for dW
 // anyway, so it also evaluates the dgrad of those rows, G_k[n, f] = sum_o dY[n, o] W[f, k, o]: wave w multiplies the
 // staged dY image (row-major blocks: plain 16-byte A fragments) with its 32 columns of the pre-split W^T panel (LDS,
@@ -94,7 +103,16 @@ __global__ __launch_bounds__(64 * NW, FUSE ? 2 : 1) void cheb_wgrad_x3_kernel(co
     static_assert(NT_ % CQ == 0, "column-sum layout");
     constexpr int PF = FUSE ? 2 : 3;                    // the fused variant needs the registers of the third slot
     constexpr int TPLANE = BLK;                         // one (wave, plane) T tile
-    constexpr int DPLANE = NO * BLK;                    // one dY plane: NO blocks [32 n][32 o]
+    // dY image: NO blocks [32 n][32 o] per plane, 64-byte rows.  Two things keep BOTH ways it is read off the bank
+    // conflicts the plain layout had (41 % of the LDS-active cycles at the north-star shape, PMC round 2):
+    //  * the 16-byte chunks of a row are XOR-swizzled with (n >> 2) & 3: the fused dgrad reads the image by ROWS (lane =
+    //    row, 16 bytes at a fixed column), and rows n, n + 4, n + 8, n + 12 of a 64-byte-row image share their banks -
+    //    a 4-way conflict on every read; with the swizzle the 16 rows of a read phase hit 16 distinct bank quads.  The
+    //    transpose reads of the wgrad address 4-row groups (one key per group): still every bank exactly once.
+    //  * blocks are DBLK = BLK + 64 elements apart: a 32-lane write group stores rows n, n + 1 of BOTH blocks, and with
+    //    2 KiB between the blocks the two copies of a row fell on the same banks.
+    constexpr int DBLK = BLK + 64;
+    constexpr int DPLANE = NO * DBLK;                   // one dY plane
     extern __shared__ __attribute__((aligned(16))) unsigned short xs[];
     unsigned short* TsT = xs;                                  // [NW][NSPLIT][32 n][32 f]
     unsigned short* DsT = xs + (size_t)NW * NSPLIT * TPLANE;   // [NSPLIT][NO][32 n][32 o]
@@ -178,6 +196,12 @@ __global__ __launch_bounds__(64 * NW, FUSE ? 2 : 1) void cheb_wgrad_x3_kernel(co
     // this lane's element offset inside a block for the transpose reads: row (i >> 2) of its [4 n] group, 8 rows
     // further for the upper lane half, 8-byte chunk (i & 3) of the 16-column half (g & 1); i = lane & 15, g = lane >> 4
     const int frag_off = (((lane & 15) >> 2) + 8 * half) * 32 + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    // the same two reads in the swizzled dY image: the lane's 16-byte chunk ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1) moves
+    // with the key of its row group - 2 * half for rows +0..3, 2 * half + 1 for rows +4..7 (+16 rows: same key)
+    const int dchunk = ((lane >> 4) & 1) * 2 + ((lane & 3) >> 1);
+    const int drow = (((lane & 15) >> 2) + 8 * half) * 32 + (lane & 1) * 4;
+    const int dfrag0 = drow + ((dchunk ^ (2 * half)) << 3);
+    const int dfrag1 = drow + 4 * 32 + ((dchunk ^ (2 * half + 1)) << 3);
     unsigned short* tw = TsT + (size_t)wave * NSPLIT * TPLANE;
 
     auto stage = [&](auto U, const long ci) __attribute__((always_inline)) {
@@ -197,7 +221,8 @@ __global__ __launch_bounds__(64 * NW, FUSE ? 2 : 1) void cheb_wgrad_x3_kernel(co
             const int e = tid + NT_ * i;
             if (DV % NT_ == 0 || e < DV) {
                 const int n = e / CQ, c4 = (e % CQ) * 4;
-                split_store<NSPLIT>(DsT + (c4 >> 5) * BLK + n * 32 + (c4 & 31), DPLANE, srd[i]);
+                split_store<NSPLIT>(DsT + (c4 >> 5) * DBLK + n * 32 + (((((c4 & 31) >> 3) ^ (n >> 2)) & 3) << 3) + (c4 & 7),
+                                    DPLANE, srd[i]);
                 if (live && do_db) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) cs[i][j] += srd[i][j];
@@ -211,7 +236,6 @@ __global__ __launch_bounds__(64 * NW, FUSE ? 2 : 1) void cheb_wgrad_x3_kernel(co
         }
         if (live && active) {
             const unsigned short* ta = tw + frag_off;
-            const unsigned short* db = DsT + frag_off;
 #pragma unroll
             for (int s2 = 0; s2 < WR / 16; ++s2) {
                 const bf16x8_t ah = read_frag_tr(ta + 16 * s2 * 32);
@@ -222,11 +246,12 @@ __global__ __launch_bounds__(64 * NW, FUSE ? 2 : 1) void cheb_wgrad_x3_kernel(co
                 }
 #pragma unroll
                 for (int t = 0; t < NO; ++t) {
-                    const unsigned short* bp = db + t * BLK + 16 * s2 * 32;
-                    const bf16x8_t bh = read_frag_tr(bp);
+                    const unsigned short* bp = DsT + t * DBLK + 16 * s2 * 32;
+                    const bf16x8_t bh = read_frag_tr2(bp + dfrag0, bp + dfrag1);
                     f32x16 a_ = acc[t];
                     if constexpr (NSPLIT == 3) {
-                        const bf16x8_t bm = read_frag_tr(bp + DPLANE), bl = read_frag_tr(bp + 2 * DPLANE);
+                        const bf16x8_t bm = read_frag_tr2(bp + DPLANE + dfrag0, bp + DPLANE + dfrag1);
+                        const bf16x8_t bl = read_frag_tr2(bp + 2 * DPLANE + dfrag0, bp + 2 * DPLANE + dfrag1);
                         a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, a_, 0, 0, 0);
                         a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, a_, 0, 0, 0);
                         a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, a_, 0, 0, 0);
@@ -242,11 +267,12 @@ __global__ __launch_bounds__(64 * NW, FUSE ? 2 : 1) void cheb_wgrad_x3_kernel(co
                 f32x16 g;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) g[i] = 0.f;
-                const unsigned short* da = DsT + (size_t)l31 * 32 + 8 * half;                     // A: dY[n = l31][o ..]
+                const unsigned short* da = DsT + (size_t)l31 * 32;                                // A: dY[n = l31][o ..]
+                const int akey = (l31 >> 2) & 3;
                 const unsigned short* wb = Wp + (size_t)(wave * 32 + l31) * WKS + 8 * half;        // B: W^T[col = l31][o ..]
 #pragma unroll
                 for (int s = 0; s < BNO / 16; ++s) {
-                    const unsigned short* ap = da + ((16 * s) >> 5) * BLK + ((16 * s) & 31);
+                    const unsigned short* ap = da + ((16 * s) >> 5) * DBLK + ((((((16 * s) & 31) >> 3) + half) ^ akey) << 3);
                     const bf16x8_t xh = *reinterpret_cast<const bf16x8_t*>(ap);
                     const bf16x8_t xm = *reinterpret_cast<const bf16x8_t*>(ap + DPLANE);
                     const bf16x8_t xl = *reinterpret_cast<const bf16x8_t*>(ap + 2 * DPLANE);
@@ -553,7 +579,7 @@ int launch_wx3(WgradParams& P, int groups, int otiles, int64_t max_slabs, int64_
     constexpr int NT_ = 64 * NW;
     constexpr int BNO = 32 * NO;
     constexpr int G = NT_ / (BNO / 4);
-    const size_t lds = ((size_t)NW * NSPLIT * BLK + (size_t)NSPLIT * NO * BLK) * 2 + (size_t)G * BNO * 4 +
+    const size_t lds = ((size_t)NW * NSPLIT * BLK + (size_t)NSPLIT * NO * (BLK + 64)) * 2 + (size_t)G * BNO * 4 +
                        (FUSE ? (size_t)3 * NW * 32 * (BNO + 8) * 2 : 0);
     const void* kfn = (const void*)cheb_wgrad_x3_kernel<BF16IO, NSPLIT, NW, NO, FUSE>;
     if (lds > 64 * 1024 &&
