@@ -487,7 +487,7 @@ def launch_ranks(n, argv):
     if have < n and os.environ.get("DSW_DIST_BACKEND") != "gloo":
         sys.exit("bench.py: --gpus %d, but %d ROCm device(s) are visible (RCCL needs one device per rank; "
                  "DSW_DIST_BACKEND=gloo runs the N > 1 path with several ranks per device for tests)" % (n, have))
-    limit = float(os.environ.get("DSW_BENCH_TIMEOUT", "600"))
+    limit = float(os.environ.get("DSW_BENCH_TIMEOUT", "420"))
     attempts = [("graph-captured collectives", {}),
                 ("collectives after the graph replay", {"DSW_BENCH_COLLECTIVES": "eager"}),
                 ("eager launches", {"DSW_BENCH_COLLECTIVES": "eager", "DSW_BENCH_NO_GRAPH": "1"})]
@@ -520,15 +520,18 @@ def launch_ranks(n, argv):
     return 1
 
 
-def _arm_watchdog(rank, world):
+def _arm_watchdog(rank, world, limit=None, what="the run"):
     """A rank of an N > 1 run that is still alive after DSW_BENCH_TIMEOUT seconds (a collective that never completes)
-    exits with an error instead of holding the node: the launcher (ours, or torchrun) then tears the job down."""
+    exits with an error instead of holding the node: the launcher (ours, or torchrun) then tears the job down.  Also
+    used with a short limit around the FIRST replay of a graph that holds collectives."""
     import threading
 
-    limit = float(os.environ.get("DSW_BENCH_TIMEOUT", "600")) * 0.9
+    if limit is None:
+        limit = float(os.environ.get("DSW_BENCH_TIMEOUT", "420")) * 0.9
 
     def bark():
-        print("bench.py: rank %d/%d still running after %.0f s - giving up" % (rank, world, limit), file=sys.stderr, flush=True)
+        print("bench.py: rank %d/%d: %s still not finished after %.0f s - giving up" % (rank, world, what, limit),
+              file=sys.stderr, flush=True)
         os._exit(124)
 
     t = threading.Timer(limit, bark)
@@ -666,9 +669,13 @@ def main():
                 ok = False
                 torch.cuda.synchronize()
             if all_ranks_agree(ok):
-                # every rank replays the same collectives in the same order: validate what the graph computes
+                # every rank replays the same collectives in the same order: validate what the graph computes.  A replay
+                # that never completes must not cost the whole time limit: 90 s, then this rank exits and the launcher
+                # moves on to collectives outside the graph
+                guard = _arm_watchdog(rank, world, 90.0, "the first replay of the graph-captured exchange")
                 g1.replay()
                 torch.cuda.synchronize()
+                guard.cancel()
                 same = torch.equal(bucket.bucket, want) or bool(
                     (bucket.bucket - want).abs().max() <= 1e-5 * want.abs().max().clamp_min(1e-30))
                 if all_ranks_agree(same):
