@@ -64,6 +64,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--plain-resblock", action="store_true",
+                    help="unet: residual-block tails as separate passes instead of GEMM epilogues (A/B)")
+    ap.add_argument("--resblock-mode", default="", help="unet A/B: fused residual-block tails (off by default): subset of 'ef' "
+                    "(e = forward epilogue, f = fork), '-' = backward only")
     ap.add_argument("--torch-cat", action="store_true",
                     help="unet: decoder concatenations through torch.cat instead of in-place buffers (A/B)")
     return ap.parse_args()
@@ -573,6 +577,16 @@ def main():
         if args.torch_cat:
             import modules.my_models_graph as _arch
             _arch.UNetSpherical.concat_in_place = False
+        if args.resblock_mode:
+            import modules.my_models_graph as _arch
+            _arch.ResBlock.fuse_tail = True
+        if args.plain_resblock:
+            import modules.my_models_graph as _arch
+            _arch.ResBlock.fuse_tail = False
+        if args.resblock_mode:      # A/B: e = forward epilogue, f = fork (input gradient inside the residual map's dgrad)
+            import modules.my_models_graph as _arch
+            _arch.ResBlock.fuse_tail_epilogue = "e" in args.resblock_mode
+            _arch.ResBlock.fuse_fork = "f" in args.resblock_mode
         model = make_unet(wl, args.knn if args.knn != 8 else 20, device)
         x = torch.randn(B, 3, V, 6, device=device)
         target = torch.randn(B, 1, V, 2, device=device)

@@ -14,11 +14,22 @@ int dsw_spmm_launch(const int* rowptr, const int* colind, const float* vals, int
 // hints: bit1 = the epilogue operands Z / Z2 are cold (not produced by the previous launch): stream them
 // with non-temporal loads so they do not evict the gathered rows from L2 / Infinity Cache
 #define DSW_SPMM_HINT_COLD_Z 2
+struct DswEpiExtra {   // optional epilogue operands of the channel-mix launchers (dsw_gemm.hip)
+    const void* scale;
+    const void* R;
+    int64_t ldr;
+    int64_t ldc;
+};
 int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* bias, void* Y, int64_t N,
-                       int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int relu = 0);
+                       int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int relu = 0,
+                       const DswEpiExtra* extra = nullptr);
 int dsw_relu_inplace_launch(void* y, int64_t n, int dtype, hipStream_t s);
 int dsw_mix_dgrad_launch(const void* dY, const void* W, void* G0, void* Grest, int64_t N, int64_t Fin,
-                         int64_t Fout, int64_t K, int dtype, hipStream_t stream);
+                         int64_t Fout, int64_t K, int dtype, hipStream_t stream, const DswEpiExtra* extra = nullptr);
+int dsw_rezero_param_grads_launch(const void* W, const void* bias, const void* dW_raw, const void* db_raw, const void* scale,
+                                  void* dW, void* db, void* dscale, int64_t n_w, int64_t n_b, void* workspace, int dtype,
+                                  hipStream_t stream);
+int64_t dsw_rezero_param_grads_ws_bytes_impl();
 int64_t dsw_wgrad_slabs(int64_t N, int64_t Fin, int64_t Fout, int64_t K);
 int dsw_spmm2_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const void* Z1, const void* Z1b,
                      const void* Z2, void* Y1, void* Y2, int64_t B, int64_t C, float a1, float b1, float d1,
@@ -34,12 +45,12 @@ int dsw_bwd_gemm_fused_try(const void* X, const void* T, const void* W, const vo
                            void* Grest, float* partial, int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype,
                            hipStream_t stream, int* rc);
 int dsw_zmix_launch(const void* X, const void* W, const void* bias, void* Z0, void* Zrest, int64_t N, int64_t Fin,
-                    int64_t Fout, int64_t K, int dtype, hipStream_t stream);
+                    int64_t Fout, int64_t K, int dtype, hipStream_t stream, const DswEpiExtra* extra = nullptr);
 int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X, const void* W, const void* bias, void* Y,
                             void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
                             int* rc, int relu);
 int dsw_zdgrad_launch(const void* dY, const void* D, const void* W, void* dX, int64_t N, int64_t Fin, int64_t Fout,
-                      int64_t K, int dtype, hipStream_t stream);
+                      int64_t K, int dtype, hipStream_t stream, const DswEpiExtra* extra = nullptr);
 
 static inline int64_t elem_size(int dtype) { return dtype == DSW_BF16 ? 2 : 4; }
 static inline int64_t round_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -195,20 +206,28 @@ int dsw_cheb_mix_fwd(const void* X, const void* T, const void* W, const void* bi
 
 int dsw_cheb_mix_first(int64_t Fin, int64_t Fout, int64_t K) { return mix_first(Fin, Fout, K) ? 1 : 0; }
 
-int dsw_cheb_fwd_act(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V, int64_t nnz,
-                     const void* X, const void* W, const void* bias, void* Y, void* T, int64_t B, int64_t Fin,
-                     int64_t Fout, int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan, int act) {
+static int cheb_fwd_impl(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V, int64_t nnz,
+                         const void* X, const void* W, const void* bias, void* Y, void* T, int64_t B, int64_t Fin,
+                         int64_t Fout, int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan, int act,
+                         const void* scale, const void* R, int64_t ldr, int64_t ldy) {
     if (K <= 0 || (act != DSW_ACT_NONE && act != DSW_ACT_RELU)) return DSW_ERR_BAD_ARG;
+    if (R != nullptr && ldr < Fout) return DSW_ERR_BAD_ARG;
+    if (ldy != 0 && ldy < Fout) return DSW_ERR_BAD_ARG;
     const int relu = act == DSW_ACT_RELU;
+    const bool extras = scale != nullptr || R != nullptr || (ldy != 0 && ldy != Fout);
+    const DswEpiExtra ex = {scale, R, ldr, (ldy != 0 && ldy != Fout) ? ldy : 0};
     int rc = DSW_OK;
     if (mix_first(Fin, Fout, K)) {
+        if (ldy != 0 && ldy != Fout) return DSW_ERR_BAD_ARG;   // the recurrence on the output planes runs on dense [N, Fout]
         // T is scratch here: (K-1) planes of [N, Fin] hold the K-1 (+2 spare for K >= 4) planes of [N, Fout]
         if (B < 0 || V < 0 || Fin <= 0 || Fout <= 0) return DSW_ERR_BAD_ARG;
         if (B == 0 || V == 0) return DSW_OK;
         if (!X || !W || !Y || !T || !rowptr) return DSW_ERR_BAD_ARG;
         if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
         const int64_t N = B * V;
-        rc = dsw_zmix_launch(X, W, bias, Y, T, N, Fin, Fout, K, dtype, (hipStream_t)stream);
+        // scale and residual ride in the epilogue of the plane GEMM: Y = sum_k T_k(L) (s X W_k) + (s b + R) is linear in
+        // the planes, so Z_k = s (X W_k) (+ s b + R on plane 0) and the recurrence is unchanged
+        rc = dsw_zmix_launch(X, W, bias, Y, T, N, Fin, Fout, K, dtype, (hipStream_t)stream, extras ? &ex : nullptr);
         if (rc != DSW_OK) return rc;
         char* spare = static_cast<char*>(T) + (K - 1) * N * Fout * elem_size(dtype);
         // the Clenshaw recurrence has exactly the form of the adjoint recurrence (with L instead of L^T)
@@ -218,7 +237,7 @@ int dsw_cheb_fwd_act(const int32_t* rowptr, const int32_t* colind, const float* 
         if (rc == DSW_OK && relu) rc = dsw_relu_inplace_launch(Y, N * Fout, dtype, (hipStream_t)stream);
         return rc;
     }
-    if (K == 3 && X && W && Y && rowptr && B >= 0 && V >= 0) {
+    if (K == 3 && !extras && X && W && Y && rowptr && B >= 0 && V >= 0) {
         // K = 3, 32 input channels, fp32: both hops AND the channel mix in one launch (dsw_fwd3.hip)
         int rcf = DSW_OK;
         if (dsw_cheb3_fwd_fused_try(plan, V, X, W, bias, Y, T, B, Fin, Fout, K, dtype, (hipStream_t)stream, &rcf, relu)) return rcf;
@@ -230,7 +249,22 @@ int dsw_cheb_fwd_act(const int32_t* rowptr, const int32_t* colind, const float* 
     if (B * V < 0 || Fin <= 0 || Fout <= 0) return DSW_ERR_BAD_ARG;
     if (B * V == 0) return DSW_OK;
     if (!X || !W || !Y || (K > 1 && !T)) return DSW_ERR_BAD_ARG;
-    return dsw_mix_fwd_launch(X, T, W, bias, Y, B * V, Fin, Fout, K, dtype, (hipStream_t)stream, relu);
+    return dsw_mix_fwd_launch(X, T, W, bias, Y, B * V, Fin, Fout, K, dtype, (hipStream_t)stream, relu, extras ? &ex : nullptr);
+}
+
+int dsw_cheb_fwd_act(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V, int64_t nnz,
+                     const void* X, const void* W, const void* bias, void* Y, void* T, int64_t B, int64_t Fin,
+                     int64_t Fout, int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan, int act) {
+    return cheb_fwd_impl(rowptr, colind, vals, V, nnz, X, W, bias, Y, T, B, Fin, Fout, K, dtype, stream, plan, act,
+                         nullptr, nullptr, 0, 0);
+}
+
+int dsw_cheb_fwd_res(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V, int64_t nnz,
+                     const void* X, const void* W, const void* bias, void* Y, int64_t ldy, void* T, int64_t B, int64_t Fin,
+                     int64_t Fout, int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan, int act,
+                     const void* scale, const void* R, int64_t ldr) {
+    return cheb_fwd_impl(rowptr, colind, vals, V, nnz, X, W, bias, Y, T, B, Fin, Fout, K, dtype, stream, plan, act,
+                         scale, R, ldr, ldy);
 }
 
 int dsw_cheb_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V, int64_t nnz,
@@ -263,10 +297,14 @@ int64_t dsw_cheb_bwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t 
     return g + p + 256;
 }
 
-int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t, int64_t V,
+static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t, int64_t V,
                  int64_t nnz, const void* X, const void* T, const void* W, const void* dY, void* dX, void* dW,
                  void* db, void* workspace, int64_t workspace_bytes, int64_t B, int64_t Fin, int64_t Fout,
-                 int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan_t) {
+                 int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan_t, const void* scale,
+                 const void* dX_add, int64_t ld_add) {
+    if (dX_add != nullptr && ld_add < Fin) return DSW_ERR_BAD_ARG;
+    const bool extras = scale != nullptr || dX_add != nullptr;
+    const DswEpiExtra ex = {scale, dX_add, ld_add, 0};
     if (B < 0 || V < 0 || Fin <= 0 || Fout <= 0 || K <= 0 || nnz < 0) return DSW_ERR_BAD_ARG;
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     const int64_t need = dsw_cheb_bwd_workspace_bytes(B, V, Fin, Fout, K, dtype);
@@ -289,7 +327,7 @@ int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* 
         char* D = ws;                                                     // D_1 .. D_{K-1}
         float* part = reinterpret_cast<float*>(ws + round_up((K - 1) * dplane, 256));
         int rcm = dsw_cheb_basis_fwd(rowptr_t, colind_t, vals_t, V, nnz, dY, D, B, Fout, K, dtype, stream, plan_t);
-        if (rcm == DSW_OK && dX != nullptr) rcm = dsw_zdgrad_launch(dY, D, W, dX, N, Fin, Fout, K, dtype, s);
+        if (rcm == DSW_OK && dX != nullptr) rcm = dsw_zdgrad_launch(dY, D, W, dX, N, Fin, Fout, K, dtype, s, extras ? &ex : nullptr);
         if (rcm == DSW_OK && dW != nullptr)
             rcm = dsw_wgrad_mixfirst_launch(X, dY, D, dW, db, part, N, Fin, Fout, K, dtype, s);
         return rcm;
@@ -299,7 +337,7 @@ int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* 
     char* spare = G + (K - 1) * plane;
     float* partial = reinterpret_cast<float*>(ws + round_up((K - 1 + (K >= 4 ? 2 : 0)) * plane, 256));
     int rc = DSW_OK;
-    if (dX != nullptr && dW != nullptr && N > 0) {
+    if (dX != nullptr && dW != nullptr && N > 0 && !extras) {
         // small aligned fp32 layers: dgrad planes and dW partials from ONE pass over dY (dsw_wgrad_x3.hip, FUSE)
         if (K > 1 && !rowptr_t) return DSW_ERR_BAD_ARG;
         int rcf = DSW_OK;
@@ -313,7 +351,9 @@ int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* 
     }
     if (dX != nullptr && N > 0) {
         if (K > 1 && !rowptr_t) return DSW_ERR_BAD_ARG;
-        rc = dsw_mix_dgrad_launch(dY, W, dX, G, N, Fin, Fout, K, dtype, s);
+        // scale multiplies every dgrad plane (the recurrence is linear); dX_add joins plane 0 = the dX buffer, onto which
+        // the adjoint recurrence then accumulates
+        rc = dsw_mix_dgrad_launch(dY, W, dX, G, N, Fin, Fout, K, dtype, s, extras ? &ex : nullptr);
         if (rc == DSW_OK && K > 1)
             rc = dsw_cheb_basis_adj(rowptr_t, colind_t, vals_t, V, nnz, dX, G, B, Fin, K, dtype, stream, plan_t,
                                     K >= 4 ? spare : nullptr);
@@ -323,6 +363,36 @@ int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* 
         rc = dsw_wgrad_launch(X, T, dY, dW, db, partial, N, Fin, Fout, K, dtype, s);
     }
     return rc;
+}
+
+int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t, int64_t V,
+                 int64_t nnz, const void* X, const void* T, const void* W, const void* dY, void* dX, void* dW,
+                 void* db, void* workspace, int64_t workspace_bytes, int64_t B, int64_t Fin, int64_t Fout,
+                 int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan_t) {
+    return cheb_bwd_impl(rowptr_t, colind_t, vals_t, V, nnz, X, T, W, dY, dX, dW, db, workspace, workspace_bytes, B, Fin,
+                         Fout, K, dtype, stream, plan_t, nullptr, nullptr, 0);
+}
+
+int dsw_cheb_bwd_res(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t, int64_t V,
+                     int64_t nnz, const void* X, const void* T, const void* W, const void* dY, void* dX, void* dW,
+                     void* db, void* workspace, int64_t workspace_bytes, int64_t B, int64_t Fin, int64_t Fout,
+                     int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan_t, const void* scale,
+                     const void* dX_add, int64_t ld_add) {
+    return cheb_bwd_impl(rowptr_t, colind_t, vals_t, V, nnz, X, T, W, dY, dX, dW, db, workspace, workspace_bytes, B, Fin,
+                         Fout, K, dtype, stream, plan_t, scale, dX_add, ld_add);
+}
+
+int64_t dsw_rezero_param_grads_workspace_bytes(void) { return dsw_rezero_param_grads_ws_bytes_impl(); }
+
+int dsw_rezero_param_grads(const void* W, const void* bias, const void* dW_raw, const void* db_raw, const void* scale,
+                           void* dW, void* db, void* dscale, int64_t n_w, int64_t n_b, void* workspace,
+                           int64_t workspace_bytes, int dtype, dsw_stream_t stream) {
+    if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
+    if (n_w < 0 || n_b < 0 || !W || !dW_raw || !scale || !dW || !dscale || (n_b > 0 && (!bias || !db_raw || !db)))
+        return DSW_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < dsw_rezero_param_grads_ws_bytes_impl()) return DSW_ERR_WORKSPACE;
+    return dsw_rezero_param_grads_launch(W, bias, dW_raw, db_raw, scale, dW, db, dscale, n_w, n_b, workspace, dtype,
+                                         (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -134,6 +134,54 @@ __global__ __launch_bounds__(256) void rezero_bwd_final_kernel(const float* part
     if (threadIdx.x == 0) Ew<BF16>::store1(gw, 0, red[0]);
 }
 
+// Parameter gradients behind a fused  out = s * conv(x) + r  (ReZero tail of a residual block): the backward kernels
+// ran on g = d out with the UNSCALED weight gradients dW_raw = T^T g, db_raw = sum g; then
+//     dW = s * dW_raw,   db = s * db_raw,   ds = <W, dW_raw> + <bias, db_raw>      (= sum g * conv(x), without conv(x))
+// ONE launch of up to 64 workgroups: each scales its slice and leaves a partial sum in the workspace; the workgroup that
+// draws the last ticket adds the partials in index order (bit-identical reruns) and re-arms the ticket.
+constexpr int RPG_BLOCKS = 64;
+template <bool BF16>
+__global__ __launch_bounds__(256) void rezero_param_grads_kernel(const void* W, const void* bias, const void* dW_raw,
+                                                                 const void* db_raw, const void* sp, void* dW, void* db,
+                                                                 void* ds, long n_w, long n_b, float* ws) {
+    using E = Ew<BF16>;
+    __shared__ float red[4];
+    __shared__ int last;
+    const float s = E::load1(sp, 0);
+    float acc = 0.f;
+    const long n = n_w + n_b;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        if (i < n_w) {
+            const float g = E::load1(dW_raw, i);
+            acc = fmaf(E::load1(W, i), g, acc);
+            E::store1(dW, i, s * g);
+        } else {
+            const long j = i - n_w;
+            const float g = E::load1(db_raw, j);
+            acc = fmaf(E::load1(bias, j), g, acc);
+            E::store1(db, j, s * g);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ws[1 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        __threadfence();
+        const unsigned t = atomicAdd(reinterpret_cast<unsigned*>(ws), 1u);
+        last = (t == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        float t = 0.f;
+        for (unsigned k = 0; k < gridDim.x; ++k) t += reinterpret_cast<volatile float*>(ws)[1 + k];
+        E::store1(ds, 0, t);
+        *reinterpret_cast<unsigned*>(ws) = 0u;        // re-armed for the next launch on this workspace
+    }
+}
+
 // y = relu(y) in place (the mix-first layers end in an SpMM, not in a GEMM epilogue);  g_out = y > 0 ? g : 0
 template <bool BF16, bool BWD>
 __global__ __launch_bounds__(EW_THREADS) void relu_kernel(const void* g, const void* y, void* out, long n, int vec) {
@@ -230,6 +278,27 @@ int dsw_rezero_residual_fwd_ld(const void* c, const void* r, const void* w, void
                            (long)rows, cpr, (long)ldy);
     return dsw_check_launch();
 }
+
+}  // extern "C"
+
+int dsw_rezero_param_grads_launch(const void* W, const void* bias, const void* dW_raw, const void* db_raw, const void* scale,
+                                  void* dW, void* db, void* dscale, int64_t n_w, int64_t n_b, void* workspace, int dtype,
+                                  hipStream_t stream) {
+    const long n = n_w + n_b;
+    int nb = (int)((n + 2047) / 2048);
+    nb = nb < 1 ? 1 : (nb > RPG_BLOCKS ? RPG_BLOCKS : nb);
+    float* ws = static_cast<float*>(workspace);
+    if (dtype == DSW_F32)
+        hipLaunchKernelGGL(rezero_param_grads_kernel<false>, dim3(nb), dim3(256), 0, stream, W, bias, dW_raw, db_raw, scale, dW,
+                           db, dscale, (long)n_w, (long)n_b, ws);
+    else
+        hipLaunchKernelGGL(rezero_param_grads_kernel<true>, dim3(nb), dim3(256), 0, stream, W, bias, dW_raw, db_raw, scale, dW,
+                           db, dscale, (long)n_w, (long)n_b, ws);
+    return dsw_check_launch();
+}
+int64_t dsw_rezero_param_grads_ws_bytes_impl() { return (int64_t)(1 + RPG_BLOCKS) * 4; }
+
+extern "C" {
 
 int dsw_rezero_residual_bwd(const void* g, const void* c, const void* w, void* grad_c, void* grad_w, void* workspace,
                             int64_t workspace_bytes, int64_t n, int dtype, dsw_stream_t stream) {

@@ -46,7 +46,7 @@ namespace {
 // PF: depth of the register prefetch ring for A (chunks in flight per workgroup).  One chunk is
 // 16 KB; HBM latency under load is ~2-3 us while a chunk's MFMAs take < 1 us, so a single
 // chunk in flight leaves the matrix pipe idle most of the time (measured: 3 TB/s effective).
-template <bool BF16, int NT, bool RESIDENT, bool ALIGNED>
+template <bool BF16, int NT, bool RESIDENT, bool ALIGNED, bool RES = false>
 __global__ __launch_bounds__(256) void ts_gemm_kernel(const TsGemmParams P) {
     constexpr int BNT = 32 * NT;
     constexpr int PF = RESIDENT ? DSW_GEMM_PF : 2;   // streaming B doubles the ring's registers: keep it shallow
@@ -93,6 +93,8 @@ __global__ __launch_bounds__(256) void ts_gemm_kernel(const TsGemmParams P) {
     bool col_ok[NT];
     char* col_ptr[NT];
     float col_bias[NT];
+    const char* col_res[NT];
+    const float escale = RES ? epi_scale<BF16>(P) : 1.f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int j = col0 + 32 * nt + l31;
@@ -103,6 +105,7 @@ __global__ __launch_bounds__(256) void ts_gemm_kernel(const TsGemmParams P) {
         const size_t cbase = (q == 0) ? 0 : (size_t)(q - 1) * P.c_plane_stride;
         col_ptr[nt] = base + (cbase + (size_t)n) * (BF16 ? 2 : 4);
         col_bias[nt] = (P.bias != nullptr && !(P.bias_plane0 && q != 0)) ? ld1<BF16>(P.bias, n) : 0.f;
+        col_res[nt] = RES ? epi_res_ptr<BF16>(P, col_ok[nt], q, n) : nullptr;
     }
 
     // A staging.  RESIDENT: every wave stages exactly the 32 rows it consumes (rows wave*32 + (lane>>3)
@@ -232,17 +235,25 @@ __global__ __launch_bounds__(256) void ts_gemm_kernel(const TsGemmParams P) {
                 char* C = col_ptr[nt];          // points at (row 0, this lane's column) of the right plane
                 const float bias = col_bias[nt];
                 const long rbase = row0 + wave * 32 + 4 * half;
+                float rv[16];
+                if constexpr (RES) {
+                    asm volatile("" ::: "memory");   // the residual loads of tile nt + 1 stay behind the stores of tile nt
+                    epi_res_load<BF16>(rv, col_res[nt], rbase, P.ldr, P.M);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) rv[i] = 0.f;
+                }
                 if (full_rows) {
                     if (jok) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i)
-                            st1<BF16>(C, (size_t)(rbase + (i & 3) + 8 * (i >> 2)) * P.ldc, epi_act(acc[nt][i] + bias, P.relu));
+                            st1<BF16>(C, (size_t)(rbase + (i & 3) + 8 * (i >> 2)) * P.ldc, epi_fin(acc[nt][i], bias, escale, rv[i], P.relu));
                     }
                 } else {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const long r = rbase + (i & 3) + 8 * (i >> 2);
-                        if (jok && r < P.M) st1<BF16>(C, (size_t)r * P.ldc, epi_act(acc[nt][i] + bias, P.relu));
+                        if (jok && r < P.M) st1<BF16>(C, (size_t)r * P.ldc, epi_fin(acc[nt][i], bias, escale, rv[i], P.relu));
                     }
                 }
 #pragma unroll
@@ -493,11 +504,18 @@ static int launch_ts_gemm_nt(const TsGemmParams& P, int col_tiles, hipStream_t s
         int rc = DSW_OK;
         if (aligned && dsw_ts_gemm_x3_try_launch(P, NT, col_tiles, BF16 ? 1 : 0, stream, &rc)) return rc;
     }
+    const bool res = P.R != nullptr || P.scale != nullptr;
+#define DSW_TSG(RESIDENT_, ALIGNED_)                                                                                  \
+    (res ? (const void*)ts_gemm_kernel<BF16, NT, RESIDENT_, ALIGNED_, true> : (const void*)ts_gemm_kernel<BF16, NT, RESIDENT_, ALIGNED_, false>)
+#define DSW_TSG_LAUNCH(RESIDENT_, ALIGNED_, GRID_, LDS_)                                                              \
+    do {                                                                                                              \
+        if (res) hipLaunchKernelGGL((ts_gemm_kernel<BF16, NT, RESIDENT_, ALIGNED_, true>), GRID_, dim3(256), LDS_, stream, P);   \
+        else hipLaunchKernelGGL((ts_gemm_kernel<BF16, NT, RESIDENT_, ALIGNED_, false>), GRID_, dim3(256), LDS_, stream, P);      \
+    } while (0)
     if (resident) {
         const size_t lds = a_bytes + b_res;
         int per_cu = 0;
-        const void* kfn = aligned ? (const void*)ts_gemm_kernel<BF16, NT, true, true>
-                                  : (const void*)ts_gemm_kernel<BF16, NT, true, false>;
+        const void* kfn = aligned ? DSW_TSG(true, true) : DSW_TSG(true, false);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, lds) != hipSuccess || per_cu < 1)
             per_cu = 1;   // grid = resident workgroups only: the persistent loop has no tail wave
         long gx = 256L * per_cu / col_tiles;
@@ -505,14 +523,16 @@ static int launch_ts_gemm_nt(const TsGemmParams& P, int col_tiles, hipStream_t s
         if (gx > row_tiles) gx = row_tiles;
         if (col_tiles > 1 && gx >= 8) gx &= ~7L;   // column tiles of one row tile on one XCD: A re-reads hit its L2
         dim3 grid((unsigned)gx, (unsigned)col_tiles);
-        if (aligned) hipLaunchKernelGGL((ts_gemm_kernel<BF16, NT, true, true>), grid, dim3(256), lds, stream, P);
-        else hipLaunchKernelGGL((ts_gemm_kernel<BF16, NT, true, false>), grid, dim3(256), lds, stream, P);
+        if (aligned) DSW_TSG_LAUNCH(true, true, grid, lds);
+        else DSW_TSG_LAUNCH(true, false, grid, lds);
     } else {
         const size_t lds = a_bytes + (size_t)BK * BNT * 4;
         dim3 grid((unsigned)row_tiles, (unsigned)col_tiles);
-        if (aligned) hipLaunchKernelGGL((ts_gemm_kernel<BF16, NT, false, true>), grid, dim3(256), lds, stream, P);
-        else hipLaunchKernelGGL((ts_gemm_kernel<BF16, NT, false, false>), grid, dim3(256), lds, stream, P);
+        if (aligned) DSW_TSG_LAUNCH(false, true, grid, lds);
+        else DSW_TSG_LAUNCH(false, false, grid, lds);
     }
+#undef DSW_TSG
+#undef DSW_TSG_LAUNCH
     return dsw_check_launch();
 }
 
@@ -551,11 +571,27 @@ static int launch_ts_gemm(const TsGemmParams& P, hipStream_t stream) {
     return launch_ts_gemm_nt<BF16, 4>(P, t128, stream);
 }
 
+// optional epilogue operands of the channel-mix launchers (see TsGemmParams): C = act(scale * (acc + bias) + R) on output
+// plane 0 (R) / every plane (scale); ldc > 0 overrides the row stride of the output (a channel slice of a wider tensor)
+struct DswEpiExtra {
+    const void* scale;
+    const void* R;
+    int64_t ldr;
+    int64_t ldc;
+};
+static inline bool epi_extra_set(const DswEpiExtra* e) { return e && (e->scale || e->R || e->ldc > 0); }
+static inline void epi_extra_apply(TsGemmParams& P, const DswEpiExtra* e) {
+    if (!e) return;
+    P.scale = e->scale; P.R = e->R; P.ldr = (int)e->ldr;
+    if (e->ldc > 0) P.ldc = (int)e->ldc;
+}
+
 int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* bias, void* Y, int64_t N,
-                       int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int relu) {
+                       int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int relu,
+                       const DswEpiExtra* extra) {
     if (N == 0) return DSW_OK;
     if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
-    if (K == 1) {
+    if (K == 1 && !epi_extra_set(extra)) {
         int rcn = DSW_OK;
         if (dsw_narrow_fwd_try(X, W, bias, Y, nullptr, N, Fin, Fout, 1, dtype, stream, relu, &rcn)) return rcn;
     }
@@ -566,6 +602,7 @@ int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* 
     P.Bsrc = W; P.b_sp = Fout; P.b_sq = 0; P.b_skd = K * Fout; P.b_sn = 1;
     P.C0 = Y; P.C1 = Y; P.c_plane_stride = 0; P.ldc = (int)Fout; P.n_planes_c = 1; P.n_per_plane = (int)Fout;
     P.bias = bias; P.M = N; P.relu = relu;
+    epi_extra_apply(P, extra);
 #ifdef DSW_ABLATION   // build with -DDSW_ABLATION to enable the DSW_DBG ablation knobs (they produce wrong results by design)
     { static const char* d = dsw_diag_env("DSW_DBG"); P.dbg = d ? atoi(d) : 0; }
 #endif
@@ -578,10 +615,10 @@ int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* 
 
 // G_0 -> dX buffer, G_1.. -> Gws planes
 int dsw_mix_dgrad_launch(const void* dY, const void* W, void* G0, void* Grest, int64_t N, int64_t Fin,
-                         int64_t Fout, int64_t K, int dtype, hipStream_t stream) {
+                         int64_t Fout, int64_t K, int dtype, hipStream_t stream, const DswEpiExtra* extra) {
     if (N == 0) return DSW_OK;
     if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
-    if (K == 1) {
+    if (K == 1 && !epi_extra_set(extra)) {
         int rcn = DSW_OK;
         if (dsw_narrow_dgrad_try(dY, nullptr, W, G0, N, Fin, Fout, 1, dtype, stream, &rcn)) return rcn;
     }
@@ -592,6 +629,7 @@ int dsw_mix_dgrad_launch(const void* dY, const void* W, void* G0, void* Grest, i
     P.C0 = G0; P.C1 = Grest; P.c_plane_stride = (size_t)N * Fin; P.ldc = (int)Fin; P.n_planes_c = (int)K;
     P.n_per_plane = (int)Fin;
     P.bias = nullptr; P.M = N;
+    epi_extra_apply(P, extra);
 #ifdef DSW_ABLATION   // build with -DDSW_ABLATION to enable the DSW_DBG ablation knobs (they produce wrong results by design)
     { static const char* d = dsw_diag_env("DSW_DBG"); P.dbg = d ? atoi(d) : 0; }
 #endif
@@ -606,10 +644,10 @@ int dsw_mix_dgrad_launch(const void* dY, const void* W, void* G0, void* Grest, i
 // ---- mix-first evaluation order (Fout <= Fin / 2):  Y = sum_k T_k(L) (X W_k)  - the recurrence runs on Fout channels
 // Z_k = X W_k (+ bias on k = 0):  Z_0 -> Z0 buffer (the caller's Y), Z_1.. -> Zrest planes of [N, Fout]
 int dsw_zmix_launch(const void* X, const void* W, const void* bias, void* Z0, void* Zrest, int64_t N, int64_t Fin,
-                    int64_t Fout, int64_t K, int dtype, hipStream_t stream) {
+                    int64_t Fout, int64_t K, int dtype, hipStream_t stream, const DswEpiExtra* extra) {
     if (N == 0) return DSW_OK;
     if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
-    {
+    if (!epi_extra_set(extra)) {
         int rcn = DSW_OK;
         if (dsw_narrow_fwd_try(X, W, bias, Z0, Zrest, N, Fin, Fout, K, dtype, stream, 0, &rcn)) return rcn;
     }
@@ -620,6 +658,7 @@ int dsw_zmix_launch(const void* X, const void* W, const void* bias, void* Z0, vo
     P.C0 = Z0; P.C1 = Zrest; P.c_plane_stride = (size_t)N * Fout; P.ldc = (int)Fout; P.n_planes_c = (int)K;
     P.n_per_plane = (int)Fout;
     P.bias = bias; P.bias_plane0 = 1; P.M = N;
+    epi_extra_apply(P, extra);
     const uintptr_t am = (uintptr_t)(4 * es) - 1;
     P.a_vec = (Fin % 4 == 0) && (((uintptr_t)X & am) == 0);
     if (dtype == DSW_F32) return launch_ts_gemm<false>(P, stream);
@@ -629,10 +668,10 @@ int dsw_zmix_launch(const void* X, const void* W, const void* bias, void* Z0, vo
 
 // dX = sum_k D_k W_k^T with D_0 = dY and D_1.. = planes of [N, Fout] (the Chebyshev basis of dY under L^T)
 int dsw_zdgrad_launch(const void* dY, const void* D, const void* W, void* dX, int64_t N, int64_t Fin, int64_t Fout,
-                      int64_t K, int dtype, hipStream_t stream) {
+                      int64_t K, int dtype, hipStream_t stream, const DswEpiExtra* extra) {
     if (N == 0) return DSW_OK;
     if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
-    {
+    if (!epi_extra_set(extra)) {
         int rcn = DSW_OK;
         if (dsw_narrow_dgrad_try(dY, D, W, dX, N, Fin, Fout, K, dtype, stream, &rcn)) return rcn;
     }
@@ -643,6 +682,7 @@ int dsw_zdgrad_launch(const void* dY, const void* D, const void* W, void* dX, in
     P.Bsrc = W; P.b_sp = Fout; P.b_sq = 0; P.b_skd = 1; P.b_sn = K * Fout;      // element (p = k, kd = o, n = f) = W[f, k, o]
     P.C0 = dX; P.C1 = dX; P.c_plane_stride = 0; P.ldc = (int)Fin; P.n_planes_c = 1; P.n_per_plane = (int)Fin;
     P.bias = nullptr; P.M = N;
+    epi_extra_apply(P, extra);
     const uintptr_t am = (uintptr_t)(4 * es) - 1;
     P.a_vec = (Fout % 4 == 0) && (((uintptr_t)dY & am) == 0) && (K == 1 || ((uintptr_t)D & am) == 0);
     if (dtype == DSW_F32) return launch_ts_gemm<false>(P, stream);

@@ -65,10 +65,52 @@ struct TsGemmParams {
     int a_vec;              // 1 if float4/bf16x4 loads of A are legal
     int dbg;                // ablation builds only (-DDSW_ABLATION + DSW_DBG env): 1 = skip the epilogue stores, 2 = skip the MFMAs; else 0
     int relu;               // 1: ReLU in the epilogue (ConvBlock: conv -> relu, my_models_graph.py:108-114), after the bias
+    // Residual-block epilogue (my_models_graph.py:205-216: `x_out *= rezero_weight; x_out += res_connection(x)`) and
+    // gradient accumulation:  C = act(scale * (acc + bias) + R)
+    const void* scale;      // ONE device scalar of the data dtype (the ReZero parameter) applied to every output plane, or null
+    const void* R;          // [M, ldr] operand of the data dtype added to output PLANE 0 (later planes: nothing), or null
+    int ldr;
 };
 
 // epilogue activation; NaN stays NaN like torch.relu (fmaxf would turn it into 0)
 static __device__ __forceinline__ float epi_act(const float v, const int relu) { return (relu && v < 0.f) ? 0.f : v; }
+
+// act(scale * (acc + bias) + R[row]): `res` points at (row 0, this lane's column) of R or is null, `roff` = row * ldr.
+// scale == 1 and res == null reproduce acc + bias bit for bit (x * 1.0f is exact).
+template <bool BF16>
+static __device__ __forceinline__ float epi_out(const float acc, const float bias, const float scale, const char* res,
+                                                const size_t roff, const int relu) {
+    float v = (acc + bias) * scale;
+    if (res != nullptr) v += BF16 ? bf16_to_f32(reinterpret_cast<const uint16_t*>(res)[roff])
+                                  : reinterpret_cast<const float*>(res)[roff];
+    return epi_act(v, relu);
+}
+// The 16 residual values of one 32 x 32 accumulator tile, requested BACK TO BACK before any store of the tile: a load
+// issued after a store to memory the compiler cannot prove distinct stays behind it, i.e. one exposed memory latency
+// per element (measured: 56 -> 133 us on a 98 304 x 128 tile pass).
+template <bool BF16>
+static __device__ __forceinline__ void epi_res_load(float (&rv)[16], const char* res, const long rbase, const int ldr,
+                                                    const long M) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        long r = rbase + (i & 3) + 8 * (i >> 2);
+        r = r < M ? r : M - 1;                       // clamped: unconditional loads
+        rv[i] = res != nullptr ? (BF16 ? bf16_to_f32(reinterpret_cast<const uint16_t*>(res)[(size_t)r * ldr])
+                                       : reinterpret_cast<const float*>(res)[(size_t)r * ldr]) : 0.f;
+    }
+}
+static __device__ __forceinline__ float epi_fin(const float acc, const float bias, const float scale, const float rv, const int relu) {
+    return epi_act((acc + bias) * scale + rv, relu);
+}
+// per-column setup of the residual operand: plane-0 columns only
+template <bool BF16>
+static __device__ __forceinline__ const char* epi_res_ptr(const TsGemmParams& P, const bool col_ok, const int q, const int n) {
+    return (P.R != nullptr && col_ok && q == 0) ? static_cast<const char*>(P.R) + (size_t)n * (BF16 ? 2 : 4) : nullptr;
+}
+template <bool BF16>
+static __device__ __forceinline__ float epi_scale(const TsGemmParams& P) {
+    return P.scale != nullptr ? ld1<BF16>(P.scale, 0) : 1.f;
+}
 
 
 // Position of a persistent workgroup in its (row tile, A plane, chunk) sequence, advanced incrementally: the

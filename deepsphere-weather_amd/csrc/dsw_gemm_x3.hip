@@ -59,6 +59,8 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3_kernel(const TsGemmParams
     constexpr bool BF16IO = (IO & 1) != 0;
     constexpr bool WIDE = (IO & 2) != 0;
     constexpr bool EPI = (IO & 4) != 0;
+    constexpr bool RES = (IO & 16) != 0;     // epilogue operands (scale, residual): their own instantiation - the extra
+                                             // live registers must not cost the plain kernels their second wave per SIMD
     constexpr bool STREAM = (IO & 8) != 0;
     static_assert(!EPI || (BF16IO && NT % 2 == 0), "packed epilogue: bf16 rows, tile pairs");
     constexpr int BK = WIDE ? 64 : dsw_gemm::BK;     // reduction elements per chunk (shadows the namespace constant)
@@ -110,6 +112,8 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3_kernel(const TsGemmParams
     bool col_ok[NT];
     char* col_ptr[NT];
     float col_bias[NT];
+    const char* col_res[NT];
+    const float escale = RES ? epi_scale<BF16IO>(P) : 1.f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int j = col0 + tile_col(32 * nt + l31);
@@ -120,6 +124,7 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3_kernel(const TsGemmParams
         const size_t cbase = (q == 0) ? 0 : (size_t)(q - 1) * P.c_plane_stride;
         col_ptr[nt] = base + (cbase + (size_t)n) * (BF16IO ? 2 : 4);
         col_bias[nt] = (P.bias != nullptr && !(P.bias_plane0 && q != 0)) ? ld1<BF16IO>(P.bias, n) : 0.f;
+        col_res[nt] = RES ? epi_res_ptr<BF16IO>(P, col_ok[nt], q, n) : nullptr;
     }
 
     const int ar = wave * 32 + (lane >> 3);           // wave-local staging rows ar + 8*i
@@ -271,17 +276,25 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3_kernel(const TsGemmParams
                 char* C = col_ptr[nt];
                 const float bias = col_bias[nt];
                 const long rbase = row0 + wave * 32 + 4 * half;
+                float rv[16];
+                if constexpr (RES) {
+                    asm volatile("" ::: "memory");   // the residual loads of tile nt + 1 stay behind the stores of tile nt
+                    epi_res_load<BF16IO>(rv, col_res[nt], rbase, P.ldr, P.M);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) rv[i] = 0.f;
+                }
                 if (full_rows) {
                     if (col_ok[nt]) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i)
-                            st1<BF16IO>(C, (size_t)(rbase + (i & 3) + 8 * (i >> 2)) * P.ldc, epi_act(acc[nt][i] + bias, P.relu));
+                            st1<BF16IO>(C, (size_t)(rbase + (i & 3) + 8 * (i >> 2)) * P.ldc, epi_fin(acc[nt][i], bias, escale, rv[i], P.relu));
                     }
                 } else {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const long r = rbase + (i & 3) + 8 * (i >> 2);
-                        if (col_ok[nt] && r < P.M) st1<BF16IO>(C, (size_t)r * P.ldc, epi_act(acc[nt][i] + bias, P.relu));
+                        if (col_ok[nt] && r < P.M) st1<BF16IO>(C, (size_t)r * P.ldc, epi_fin(acc[nt][i], bias, escale, rv[i], P.relu));
                     }
                 }
 #pragma unroll
@@ -329,6 +342,8 @@ int dsw_ts_gemm_x3_try_launch(const TsGemmParams& P, int nt, int col_tiles, int 
     const size_t ks = (size_t)P.n_planes_a * P.kd_per_plane + 8;
     const bool wide = bf16 && P.kd_per_plane % 64 == 0;
     // packed epilogue: 64-column groups are whole, contiguous, 16-byte aligned row segments of one output plane
+    const bool res = P.R != nullptr || P.scale != nullptr;
+    if (res && bf16) return 0;     // epilogue operands: fp32 instantiations only (bf16 takes the generic MFMA kernel)
     const bool epi = bf16 && nt % 2 == 0 && P.n_per_plane % 64 == 0 && P.ldc % 8 == 0 && P.c_plane_stride % 8 == 0 &&
                      dsw_aligned16(P.C0) && (P.n_planes_c == 1 || dsw_aligned16(P.C1));
     const int nsplit = bf16 ? 1 : 3;
@@ -344,7 +359,8 @@ int dsw_ts_gemm_x3_try_launch(const TsGemmParams& P, int nt, int col_tiles, int 
     (strm ? launch_x3<NT_, NS_, (IO_) | 8, NWV_>(P, col_tiles, lds, stream)               \
           : launch_x3<NT_, NS_, IO_, NWV_>(P, col_tiles, lds, stream))
 #define DSW_X3_IO(NT_, NWV_)                                                               \
-    (wide ? DSW_X3_L(NT_, 1, 3, NWV_) : bf16 ? DSW_X3_L(NT_, 1, 1, NWV_) : DSW_X3_L(NT_, 3, 0, NWV_))
+    (wide ? DSW_X3_L(NT_, 1, 3, NWV_) : bf16 ? DSW_X3_L(NT_, 1, 1, NWV_)                   \
+          : res ? DSW_X3_L(NT_, 3, 16, NWV_) : DSW_X3_L(NT_, 3, 0, NWV_))
 #define DSW_X3_EPI(NT_, NWV_)                                                              \
     (wide ? DSW_X3_L(NT_, 1, 7, NWV_) : DSW_X3_L(NT_, 1, 5, NWV_))
 #define DSW_X3_CASE(NT_)                                                                   \

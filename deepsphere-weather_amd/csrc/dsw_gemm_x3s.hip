@@ -38,7 +38,7 @@ static __device__ __forceinline__ float trunc_bf16(float f) {
 }
 
 // KFAST: the B operand is contiguous along the reduction index (dgrad: W^T), else along the columns (forward).
-template <int NT, int NWV, bool KFAST>
+template <int NT, int NWV, bool KFAST, bool RES = false>
 __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParams P) {
     constexpr int BMT = 32 * NWV;
     constexpr int NTH = 64 * NWV;
@@ -69,6 +69,8 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
     bool col_ok[NT];
     char* col_ptr[NT];
     float col_bias[NT];
+    const char* col_res[NT];
+    const float escale = RES ? epi_scale<false>(P) : 1.f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int j = col0 + 32 * nt + l31;
@@ -79,6 +81,7 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
         const size_t cbase = (q == 0) ? 0 : (size_t)(q - 1) * P.c_plane_stride;
         col_ptr[nt] = base + (cbase + (size_t)n) * 4;
         col_bias[nt] = (P.bias != nullptr && !(P.bias_plane0 && q != 0)) ? static_cast<const float*>(P.bias)[n] : 0.f;
+        col_res[nt] = RES ? epi_res_ptr<false>(P, col_ok[nt], q, n) : nullptr;
     }
 
     // ---- W chunk: this thread's NPAIR (column, k-pair) slots; the global offset of a slot inside chunk 0
@@ -226,10 +229,18 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
             for (int nt = 0; nt < NT; ++nt) {
                 float* C = reinterpret_cast<float*>(col_ptr[nt]);
                 const float bias = col_bias[nt];
+                float rv[16];
+                if constexpr (RES) {
+                    asm volatile("" ::: "memory");   // see dsw_gemm_x3.hip
+                    epi_res_load<false>(rv, col_res[nt], rbase, P.ldr, P.M);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) rv[i] = 0.f;
+                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const long r = rbase + (i & 3) + 8 * (i >> 2);
-                    if (col_ok[nt] && r < P.M) C[(size_t)r * P.ldc] = epi_act(acc[nt][i] + bias, P.relu);
+                    if (col_ok[nt] && r < P.M) C[(size_t)r * P.ldc] = epi_fin(acc[nt][i], bias, escale, rv[i], P.relu);
                     acc[nt][i] = 0.f;
                 }
             }
@@ -243,12 +254,12 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
     }
 }
 
-template <int NT, int NWV, bool KFAST>
+template <int NT, int NWV, bool KFAST, bool RES = false>
 int launch_x3s(const TsGemmParams& P, int col_tiles, hipStream_t stream) {
     constexpr int BMT = 32 * NWV;
     const size_t lds = (size_t)2 * BMT * LDA * 4 + (size_t)2 * 3 * (32 * NT) * KSB * 2;
     const long row_tiles = (P.M + BMT - 1) / BMT;
-    const void* kfn = (const void*)ts_gemm_x3s_kernel<NT, NWV, KFAST>;
+    const void* kfn = (const void*)ts_gemm_x3s_kernel<NT, NWV, KFAST, RES>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DSW_ERR_LAUNCH;
@@ -259,7 +270,7 @@ int launch_x3s(const TsGemmParams& P, int col_tiles, hipStream_t stream) {
     if (gx > row_tiles) gx = row_tiles;
     if (col_tiles > 1 && gx >= 8) gx &= ~7L;   // column tiles of one row tile on one XCD (A re-reads hit its L2)
     dim3 grid((unsigned)gx, (unsigned)col_tiles);
-    hipLaunchKernelGGL((ts_gemm_x3s_kernel<NT, NWV, KFAST>), grid, dim3(64 * NWV), lds, stream, P);
+    hipLaunchKernelGGL((ts_gemm_x3s_kernel<NT, NWV, KFAST, RES>), grid, dim3(64 * NWV), lds, stream, P);
     return dsw_check_launch();
 }
 
@@ -275,6 +286,7 @@ int dsw_ts_gemm_x3s_try_launch(const TsGemmParams& P, hipStream_t stream, int* r
     if (!P.a_vec || P.kd_per_plane % BK != 0 || P.M <= 0) return 0;
     const int n_total = P.n_planes_c * P.n_per_plane;
     const bool kfast = P.b_skd == 1;
+    const bool res = P.R != nullptr || P.scale != nullptr;     // epilogue operands: separate instantiations
     const int nt = n_total > 64 ? 4 : 2;
     const int col_tiles = (n_total + 32 * nt - 1) / (32 * nt);
     // waves per workgroup (tile rows = 32 * waves).  Measured over the UNet shapes: a chunk step costs about the same
@@ -283,8 +295,10 @@ int dsw_ts_gemm_x3s_try_launch(const TsGemmParams& P, hipStream_t stream, int* r
     static const char* nwvenv = dsw_diag_env("DSW_X3S_NWV");
     const long tiles8 = ((P.M + 255) / 256) * col_tiles;
     const int nwv = nwvenv ? atoi(nwvenv) : (tiles8 < 128 ? 4 : 8);
-#define DSW_X3S(NT_, NWV_) (*rc = kfast ? launch_x3s<NT_, NWV_, true>(P, col_tiles, stream)   \
-                                        : launch_x3s<NT_, NWV_, false>(P, col_tiles, stream))
+#define DSW_X3S(NT_, NWV_)                                                                                          \
+    (*rc = res ? (kfast ? launch_x3s<NT_, NWV_, true, true>(P, col_tiles, stream)                                   \
+                        : launch_x3s<NT_, NWV_, false, true>(P, col_tiles, stream))                                 \
+               : (kfast ? launch_x3s<NT_, NWV_, true>(P, col_tiles, stream) : launch_x3s<NT_, NWV_, false>(P, col_tiles, stream)))
 #define DSW_X3S_NWV(NT_)                                                                     \
     if (nwv == 4) DSW_X3S(NT_, 4); else DSW_X3S(NT_, 8);
     if (nt == 4) { DSW_X3S_NWV(4) } else { DSW_X3S_NWV(2) }

@@ -63,6 +63,18 @@ SIGNATURES = {
         [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int],
     ),
     "dsw_relu_bwd": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
+    "dsw_cheb_fwd_res": (
+        _int,
+        [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int,
+         _vp, _vp, _i64],
+    ),
+    "dsw_cheb_bwd_res": (
+        _int,
+        [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
+         _i64, _int, _vp, _vp, _vp, _vp, _i64],
+    ),
+    "dsw_rezero_param_grads_workspace_bytes": (_i64, []),
+    "dsw_rezero_param_grads": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _int, _vp]),
     "dsw_cheb_bwd_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64, _i64, _int]),
     "dsw_cheb_bwd": (
         _int,

@@ -343,6 +343,73 @@ class _HipBackend:
         return dx, (dw if need_dw else None), (db if need_db else None)
 
 
+    def cheb_fwd_res(self, op, x, w, bias, scale, res, out=None):
+        """``y = scale * conv(x) + res`` in the epilogue of the channel-mix GEMM (dsw_cheb_fwd_res); ``out``: optional
+        row-strided destination (basis-first layers).  Returns (y, T or None)."""
+        lib = _native.load()
+        B, V, Fin = x.shape
+        _, K, Fout = w.shape
+        y = out if out is not None else torch.empty((B, V, Fout), dtype=x.dtype, device=x.device)
+        T = torch.empty((K - 1, B, V, Fin), dtype=x.dtype, device=x.device) if K > 1 else None
+        mix_first = bool(lib.dsw_cheb_mix_first(Fin, Fout, K))
+        pp, _keep = (_plan_ptr(op, x, Fout if mix_first else Fin)
+                     if (K > 2 and (_FWD_FUSED or mix_first)) else (None, None))
+        csr = (None, None, None, V, 0) if op is None else (
+            op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz)
+        with torch.cuda.device(x.device):
+            rc = lib.dsw_cheb_fwd_res(
+                *csr, x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), row_stride(y), _ptr(T), B, Fin, Fout, K,
+                _DTYPES[x.dtype], _stream(x), pp, 0, _ptr(scale), _ptr(res), 0 if res is None else row_stride(res),
+            )
+        _native.check(rc, "dsw_cheb_fwd_res")
+        return y, (None if mix_first else T)
+
+    def cheb_bwd_res(self, op, x, T, w, dy, need_dx, need_dw, scale=None, dx_add=None):
+        """Backward of ``scale * conv(x)`` taking ``dy`` as it arrives: ``dx = scale * (...) + dx_add``; ``dw_raw`` /
+        ``db_raw`` are NOT scaled (see ``rezero_param_grads``)."""
+        lib = _native.load()
+        B, V, Fin = x.shape
+        _, K, Fout = w.shape
+        dt = _DTYPES[x.dtype]
+        dx = torch.empty_like(x) if need_dx else None
+        dw = torch.empty_like(w) if need_dw else None
+        db = torch.empty((Fout,), dtype=w.dtype, device=w.device) if need_dw else None
+        nbytes = int(lib.dsw_cheb_bwd_workspace_bytes(B, V, Fin, Fout, K, dt))
+        if nbytes < 0:
+            _native.check(nbytes, "dsw_cheb_bwd_workspace_bytes")
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+        mix_first = bool(lib.dsw_cheb_mix_first(Fin, Fout, K))
+        need_hops = K > 1 and (need_dx or (mix_first and need_dw))
+        opt = op.transpose() if need_hops else op
+        pp, _keep = _plan_ptr(opt, x, Fout if mix_first else Fin) if (need_hops and K > 2) else (None, None)
+        csr = (None, None, None, V, 0) if opt is None else (
+            opt.rowptr.data_ptr(), opt.colind.data_ptr(), opt.values.data_ptr(), V, opt.nnz)
+        with torch.cuda.device(x.device):
+            rc = lib.dsw_cheb_bwd_res(
+                *csr, x.data_ptr(), _ptr(T), w.data_ptr(), dy.data_ptr(), _ptr(dx), _ptr(dw), _ptr(db),
+                ws.data_ptr(), nbytes, B, Fin, Fout, K, dt, _stream(x), pp, _ptr(scale),
+                _ptr(dx_add) if need_dx else None, 0 if dx_add is None else row_stride(dx_add),
+            )
+        _native.check(rc, "dsw_cheb_bwd_res")
+        return dx, dw, db
+
+    _rpg_ws = {}   # device -> the (zero-initialised, self-re-arming) ticket + partials workspace of dsw_rezero_param_grads
+
+    def rezero_param_grads(self, w, bias, dw_raw, db_raw, scale):
+        lib = _native.load()
+        ds = torch.empty_like(scale)
+        nb = 0 if bias is None else bias.numel()
+        ws = self._rpg_ws.get(w.device)
+        if ws is None:
+            ws = self._rpg_ws[w.device] = torch.zeros(int(lib.dsw_rezero_param_grads_workspace_bytes()), dtype=torch.uint8,
+                                                      device=w.device)
+        with torch.cuda.device(w.device):
+            rc = lib.dsw_rezero_param_grads(w.data_ptr(), _ptr(bias), dw_raw.data_ptr(), _ptr(db_raw) if nb else None,
+                                            scale.data_ptr(), dw_raw.data_ptr(), _ptr(db_raw) if nb else None, ds.data_ptr(),
+                                            w.numel(), nb, ws.data_ptr(), ws.numel(), _DTYPES[w.dtype], _stream(w))
+        _native.check(rc, "dsw_rezero_param_grads")
+        return dw_raw, (db_raw if nb else None), ds
+
     def relu_bwd(self, dy, y):
         lib = _native.load()
         out = torch.empty_like(dy)
@@ -494,6 +561,80 @@ class _ChebConvFn(torch.autograd.Function):
             dy = ctx.be.relu_bwd(dy, y)
         dx, dw, db = ctx.be.cheb_bwd(ctx.op, xc, T, wc, dy, need_dx, need_dw, need_db)
         return dx, dw, db, None, None
+
+
+class _ChebConvResFn(torch.autograd.Function):
+    """``scale * conv(x) + res`` - the last convolution of a residual block with the block's ReZero scale and residual add
+    in its epilogue (reference my_models_graph.py:205-216).  Backward never forms ``scale * dY``: the dgrad kernels scale
+    their output, the weight gradients are rescaled by one tiny launch that also yields d scale = <W, dW_raw> + <b, db_raw>
+    (= sum dY * conv(x), without conv(x) ever having been stored)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, scale, res, op, out, epilogue=True):
+        be = _backend_for(x)
+        xc, wc = x.contiguous(), weight.contiguous()
+        bc = None if bias is None else bias.contiguous()
+        if epilogue:
+            rc = res if _rows_ok(res) else res.contiguous()
+            y, T = be.cheb_fwd_res(op, xc, wc, bc, scale, rc, out=out.t if out is not None else None)
+        else:
+            # forward as two launches (convolution, then scale + residual in one pass over its output - the unscaled
+            # convolution is NOT kept); the backward below is the same
+            c, T = be.cheb_fwd(op, xc, wc, bc)
+            y = be.rezero_fwd(c, res.contiguous(), scale, out=out.t if out is not None else None)
+        ctx.save_for_backward(xc, wc, bc, T, scale)
+        ctx.op, ctx.be = op, be
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        xc, wc, bc, T, scale = ctx.saved_tensors
+        need_dx = ctx.needs_input_grad[0]
+        need_par = ctx.needs_input_grad[1] or (bc is not None and ctx.needs_input_grad[2]) or ctx.needs_input_grad[3]
+        g = g.contiguous()
+        dx, dw, db = ctx.be.cheb_bwd_res(ctx.op, xc, T, wc, g, need_dx, need_par, scale=scale)
+        ds = None
+        if need_par:
+            dw, db, ds = ctx.be.rezero_param_grads(wc, bc, dw, db, scale)
+        return (dx, dw if ctx.needs_input_grad[1] else None, db if (bc is not None and ctx.needs_input_grad[2]) else None,
+                ds if ctx.needs_input_grad[3] else None, g if ctx.needs_input_grad[4] else None, None, None, None)
+
+
+class _DenseForkFn(torch.autograd.Function):
+    """``(x_again, x @ weight + bias)`` for an input with a second consumer (the residual branch of a ResBlock reads the
+    block's input next to the convolution stack): the gradient the other consumer sends back through ``x_again`` is added
+    in the epilogue of this map's dgrad GEMM instead of by an autograd ``add`` pass over the tensor."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        be = _backend_for(x)
+        lead = x.shape[:-1]
+        x2 = x.contiguous().reshape(1, -1, x.shape[-1])
+        wc = weight.unsqueeze(1).contiguous()
+        bc = None if bias is None else bias.contiguous()
+        y, _T = be.cheb_fwd(None, x2, wc, bc)
+        ctx.save_for_backward(x2, wc)
+        ctx.be, ctx.has_bias, ctx.wshape = be, bias is not None, weight.shape
+        return x.view_as(x), y.reshape(*lead, weight.shape[1])
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_x, g_r):
+        x2, wc = ctx.saved_tensors
+        if g_r is None:
+            return g_x, None, None
+        need_dx = ctx.needs_input_grad[0]
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        g2 = g_r.contiguous().reshape(1, -1, g_r.shape[-1])
+        add = None
+        if g_x is not None and need_dx:
+            add = g_x.reshape(1, -1, g_x.shape[-1]) if g_x.is_contiguous() else g_x.contiguous().reshape(1, -1, g_x.shape[-1])
+        dx, dw, db = ctx.be.cheb_bwd_res(None, x2, None, wc, g2, need_dx, need_w, dx_add=add)
+        if dx is not None:
+            dx = dx.reshape(g_r.shape[:-1] + (x2.shape[-1],))
+        return (dx, dw.reshape(ctx.wshape) if (dw is not None and ctx.needs_input_grad[1]) else None,
+                db if (ctx.has_bias and ctx.needs_input_grad[2]) else None)
 
 
 class _Out:
@@ -690,6 +831,36 @@ def dense_mix(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
     lead = x.shape[:-1]
     y = _ChebConvFn.apply(x.reshape(1, -1, x.shape[-1]), weight.unsqueeze(1), bias, None)
     return y.reshape(*lead, weight.shape[1])
+
+
+def cheb_conv_res(op: CsrOperator, x: torch.Tensor, weight: torch.Tensor, bias, scale: torch.Tensor, res: torch.Tensor,
+                  out: torch.Tensor = None, epilogue: bool = True) -> torch.Tensor:
+    """``scale * (sum_k T_k(L) x W_k + bias) + res`` with ``scale`` a one-element tensor (the ReZero parameter) and
+    ``res`` of the output's shape: the tail of a residual block in the epilogue of its last convolution.  ``out``: optional
+    preallocated channel slice to write into (see ``skip_slot``; basis-first layers)."""
+    if x.dim() != 3 or weight.dim() != 3 or scale.numel() != 1:
+        raise ValueError("expected inputs [B, V, Fin], weight [Fin, K, Fout] and a one-element scale")
+    if x.shape[1] != op.shape[1] or op.shape[0] != op.shape[1]:
+        raise ValueError(f"operator shape {op.shape} does not match the {x.shape[1]} nodes of the input")
+    if tuple(res.shape) != (x.shape[0], x.shape[1], weight.shape[2]):
+        raise ValueError("`res` must have the shape of the layer's output")
+    _check_dtype(x, weight, bias, scale, res)
+    return _ChebConvResFn.apply(x, weight, bias, scale, res, op, _check_out(out, res.shape, x), epilogue)
+
+
+def cheb_conv_res_takes_out(fin: int, fout: int, K: int) -> bool:
+    """Whether ``cheb_conv_res(..., out=slice)`` can write into a row-strided destination for this layer shape (the
+    mix-first evaluation order ends in an SpMM on dense planes)."""
+    return not bool(_native.load().dsw_cheb_mix_first(fin, fout, K))
+
+
+def dense_mix_fork(x: torch.Tensor, weight: torch.Tensor, bias=None):
+    """``(x_again, dense_mix(x, weight, bias))``: give ``x_again`` to the OTHER consumer of ``x`` and its gradient is added
+    inside this map's backward GEMM (residual branch of a ResBlock, my_models_graph.py:213)."""
+    if weight.dim() != 2 or x.shape[-1] != weight.shape[0] or x.dim() != 3:
+        raise ValueError("expected x [B, V, Fin] and weight [Fin, Fout]")
+    _check_dtype(x, weight, bias)
+    return _DenseForkFn.apply(x, weight, bias)
 
 
 def _check_out(out, shape, like):

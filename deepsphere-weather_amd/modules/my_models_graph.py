@@ -146,9 +146,63 @@ class ResBlock(torch.nn.Module):
             torch.nn.init.constant_(last.bn.weight, 0)
             torch.nn.init.constant_(last.bn.bias, 0)
 
+    # Block-level fusion is IMPLEMENTED and OFF: measured same-box on the U-Net workload
+    # (nside 32, B 8: 3.93 ms plain) every variant was slower - backward only (ReZero scale inside the dgrad kernels,
+    # dscale = <W, dW_raw> + <b, db_raw>) +0.4 %, + forward epilogue +0.9 %, + fork +0.8 %, everything +1.8 %: the
+    # passes they remove run out of the Infinity Cache at these sizes (50 MB tensors), while a residual operand in the
+    # MFMA epilogue costs the GEMM 40-60 registers (its second wave per SIMD).  Worth switching on where the tensors
+    # exceed the cache (nside 64 models); fp32 only.
+    fuse_tail = False           # True: last convolution takes ReZero scale + residual add (see _fusable_tail)
+    fuse_tail_epilogue = True   # forward: scale + residual in the GEMM epilogue (False: one pass behind the convolution)
+    fuse_fork = True            # the residual map collects the convolution stack's input gradient in its dgrad GEMM
+
+    def _fusable_tail(self, x):
+        """The last convolution can take the block's tail - ReZero scale and residual add - into its GEMM epilogue: a plain
+        ConvCheb (no norm, no activation behind it), and nobody listening on the modules this shortcut does not call."""
+        from modules.layers import ConvCheb, conv_cheb
+
+        if not (self.fuse_tail and self.rezero and x.dim() == 3):
+            return False
+        last = getattr(self, self.conv_names_list[-1])
+        conv = last.conv
+        if last.norm or last.act or not isinstance(conv, ConvCheb) or conv._conv is not conv_cheb:
+            return False
+        if conv.kernel_size * conv.out_channels <= 16:
+            return False     # a few output columns (the model's 64 -> 2 layer): the vector-ALU kernels of dsw_narrow.hip
+                             # beat a matrix-core tile with 3-9 % live columns, and they have no epilogue operands
+        watched = [last, conv, self.res_connection]
+        if any(m._forward_hooks or m._forward_pre_hooks for m in watched):
+            return False
+        if not isinstance(self.res_connection, (_NodeLinear, Identity)):
+            return False
+        return x.dtype == torch.float32
+
     def forward(self, x, out=None):
         """``out`` (extension): a preallocated channel slice to write the block's output into (the encoder blocks of the
         U-Net write straight into the decoder's concatenation buffer, ``dsw_functional.skip_slot``)."""
+        if self._fusable_tail(x):
+            # out = rezero_weight * convs(x) + res_connection(x), the last two steps in the epilogue of the last
+            # convolution's channel mix (no separate pass over the output, nothing of the unscaled convolution is kept);
+            # the residual map hands the block input on to the convolutions and collects their gradient in its own
+            # backward GEMM (no autograd `add` over the input's gradient)
+            lin = self.res_connection
+            if isinstance(lin, _NodeLinear):
+                if self.fuse_fork and x.requires_grad:
+                    y, r = dsw_functional.dense_mix_fork(x, lin.weight.t(), lin.bias)
+                else:
+                    y, r = x, dsw_functional.dense_mix(x, lin.weight.t(), lin.bias)
+            else:
+                y, r = x, x
+            for name in self.conv_names_list[:-1]:
+                y = getattr(self, name)(y)
+            conv = getattr(self, self.conv_names_list[-1]).conv
+            if y.shape[2] == conv.weight.shape[0] and r.shape[2] == conv.weight.shape[2]:
+                epi = self.fuse_tail_epilogue
+                if epi and out is not None and not dsw_functional.cheb_conv_res_takes_out(*conv.weight.shape[::2], conv.weight.shape[1]):
+                    epi = False
+                return dsw_functional.cheb_conv_res(dsw_functional.get_operator(conv.laplacian), y, conv.weight, conv.bias,
+                                                    self.rezero_weight, r, out=out, epilogue=epi)
+            return dsw_functional.rezero_residual(getattr(self, self.conv_names_list[-1])(y), r, self.rezero_weight, out=out)
         y = x
         for name in self.conv_names_list:
             y = getattr(self, name)(y)

@@ -157,6 +157,20 @@ int dsw_cheb_fwd_act(const int32_t* rowptr, const int32_t* colind, const float* 
                      void* Y, void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K,
                      int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan, int act);
 
+/* ConvCheb.forward followed by the tail of the enclosing ResBlock (my_models_graph.py:205-216:
+ * `x_out *= self.rezero_weight; x_out += self.res_connection(x)`), in the epilogue of the channel-mix GEMM:
+ *     Y = act( scale * (sum_k T_k W_k + bias) + R )
+ * scale: ONE device scalar of the data dtype (the ReZero parameter) or NULL (= 1); R: [B*V, ldr >= Fout] or NULL; ldy:
+ * elements between consecutive rows of Y (0 or Fout = dense; > Fout = a channel slice of a wider tensor, e.g. the
+ * decoder's concatenation buffer - basis-first layers only, mix-first layers return DSW_ERR_BAD_ARG for it).  With
+ * scale = R = NULL and ldy = 0 this is dsw_cheb_fwd_act.  Saves the separate read-read-write pass over the block's
+ * output (and the write + read of the unscaled convolution in between). */
+int dsw_cheb_fwd_res(const int32_t* rowptr, const int32_t* colind, const float* vals,
+                     int64_t V, int64_t nnz, const void* X, const void* W, const void* bias,
+                     void* Y, int64_t ldy, void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K,
+                     int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan, int act,
+                     const void* scale, const void* R, int64_t ldr);
+
 /* Backward of that activation (autograd of F.relu, what the reference's ConvBlock records):
  *     dYm[i] = Y[i] > 0 ? dY[i] : 0          (Y = the layer's activated output; n elements; dYm may alias dY) */
 int dsw_relu_bwd(const void* dY, const void* Y, void* dYm, int64_t n, int dtype, dsw_stream_t stream);
@@ -177,6 +191,30 @@ int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* 
                  const void* dY, void* dX, void* dW, void* db, void* workspace,
                  int64_t workspace_bytes, int64_t B, int64_t Fin, int64_t Fout, int64_t K,
                  int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan_t);
+
+/* dsw_cheb_bwd with the two things a fused residual block needs from it:
+ *   scale   (device scalar or NULL): dX = scale * (closed form) - the backward of Y = scale * conv(X) takes dY as it
+ *           arrives, no scaled copy of it is made; dW / db stay UNSCALED (dW_raw = sum_n T_k dY): see
+ *           dsw_rezero_param_grads;
+ *   dX_add  ([B*V, ld_add >= Fin] or NULL): added to dX in the epilogue of the dgrad GEMM - the gradient a second
+ *           consumer of X sent (residual branch: my_models_graph.py:213), instead of an autograd `add` pass. */
+int dsw_cheb_bwd_res(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t,
+                     int64_t V, int64_t nnz, const void* X, const void* T, const void* W,
+                     const void* dY, void* dX, void* dW, void* db, void* workspace,
+                     int64_t workspace_bytes, int64_t B, int64_t Fin, int64_t Fout, int64_t K,
+                     int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan_t,
+                     const void* scale, const void* dX_add, int64_t ld_add);
+
+/* Parameter gradients behind Y = scale * conv(X) + R when the backward ran on dY (dsw_cheb_bwd_res):
+ *     dW = scale * dW_raw,  db = scale * db_raw,  dscale = <W, dW_raw> + <bias, db_raw>   (= sum dY * conv(X))
+ * n_w / n_b elements (n_b = 0: no bias); dW / db may alias dW_raw / db_raw; one launch, deterministic.
+ * workspace: dsw_rezero_param_grads_workspace_bytes() bytes that are ZERO before the first use and belong to this entry
+ * point from then on (it leaves them zeroed-where-it-matters for the next call; calls sharing a workspace must be
+ * stream-ordered). */
+int64_t dsw_rezero_param_grads_workspace_bytes(void);
+int dsw_rezero_param_grads(const void* W, const void* bias, const void* dW_raw, const void* db_raw, const void* scale,
+                           void* dW, void* db, void* dscale, int64_t n_w, int64_t n_b, void* workspace,
+                           int64_t workspace_bytes, int dtype, dsw_stream_t stream);
 
 /* Residual block epilogue (my_models_graph.py:205-216: `x_out *= rezero_weight; x_out += res_connection(x)`):
  *   forward   y[i] = w * c[i] + r[i]        (w: ONE device scalar of the data dtype - the ReZero parameter)

@@ -47,6 +47,30 @@ class OracleBackend:
         T = self.cheb_basis(op, x, K) if K > 1 else None
         return torch.from_numpy(y).to(x.dtype), T
 
+    def cheb_fwd_res(self, op, x, w, bias, scale, res, out=None):
+        y, T = self.cheb_fwd(op, x, w, bias)
+        y = (y.double() * scale.detach().double() + res.detach().double()).to(x.dtype)
+        return (y if out is None else out.copy_(y)), T
+
+    def cheb_bwd_res(self, op, x, T, w, dy, need_dx, need_dw, scale=None, dx_add=None):
+        dx, dw, db = self.cheb_bwd(op, x, T, w, dy, need_dx, need_dw, need_dw)
+        if dx is not None:
+            d = dx.double()
+            if scale is not None:
+                d = d * scale.detach().double()
+            if dx_add is not None:
+                d = d + dx_add.detach().double().reshape(d.shape)
+            dx = d.to(x.dtype)
+        return dx, dw, db
+
+    def rezero_param_grads(self, w, bias, dw_raw, db_raw, scale):
+        s = scale.detach().double()
+        ds = (w.detach().double() * dw_raw.double()).sum()
+        if bias is not None:
+            ds = ds + (bias.detach().double() * db_raw.double()).sum()
+        return ((s * dw_raw.double()).to(w.dtype), None if bias is None else (s * db_raw.double()).to(w.dtype),
+                ds.reshape(scale.shape).to(scale.dtype))
+
     def cheb_bwd(self, op, x, T, w, dy, need_dx, need_dw, need_db):
         rp, ci, va = _csr_np(op, x.shape[1])
         dx, dw, db = orc.cheb_backward_f64(

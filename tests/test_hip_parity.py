@@ -1108,3 +1108,23 @@ def test_bench_one_rank_world_captures_the_exchange():
     assert out["n_gpus"] == 1 and "all-reduce" in out["config"]["launch"]
     assert "captured in the graph" in out["config"]["launch"], (out["config"]["launch"], out["allreduce"], r.stderr[-1500:])
     assert "%d steps per graph" % 10 in out["config"]["launch"]
+
+
+@pytest.mark.parametrize("dt", [torch.float32])
+def test_resblock_fused_tail_vs_fp64(dt):
+    """ReZero scale + residual add in the epilogue of the block's last convolution
+    (dsw_cheb_fwd_res: resident-panel x3 GEMM 64 -> 128, mix-first plane GEMM 128 -> 64 and the 64 -> 2 output layer,
+    32 -> 32 with an identity residual, an unaligned 7 -> 12 -> 5 block on the exact-fp32 kernels), the backward on the
+    unscaled dY (dsw_cheb_bwd_res + dsw_rezero_param_grads) and the block input's gradient added inside the residual
+    map's dgrad GEMM - fused and plain evaluation against the reference's op order in fp64."""
+    from test_host_logic import check_resblock_tail
+
+    worst = check_resblock_tail(DEV, dt, TOL_F64 if dt == torch.float32 else TOL_BF16)
+    print("ResBlock tail, worst max-rel error", worst)
+
+
+def test_resblock_fused_tail_wide_layers():
+    """The same on the streaming-W GEMM (Kd = 3 * 192 = 576 -> 256 columns: ts_gemm_x3s) and a 512 -> 256 mix-first layer."""
+    from test_host_logic import check_resblock_tail
+
+    check_resblock_tail(DEV, torch.float32, TOL_F64, shapes=[(2, 128, (192, 256)), (2, 256, (512, 256)), (2, 512, (256, 128))])

@@ -893,3 +893,100 @@ def test_bench_gpus_flag_is_not_ignored():
     r = subprocess.run([sys.executable, bench, "--gpus", "4", "--steps", "2"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "--gpus 4" in r.stderr and "2 rank" in r.stderr, (r.returncode, r.stderr[-400:])
+
+
+def check_resblock_tail(device, dtype=torch.float32, tol=2e-6, shapes=None):
+    """ResBlock with its tail (ReZero scale + residual add) in the last convolution's epilogue and the block input's
+    gradient collected inside the residual map's backward GEMM, against the plain sequence of the reference
+    (my_models_graph.py:205-216) evaluated in fp64: output, input gradient, every parameter gradient."""
+    from dsw_amd import sphere
+    from modules.layers import prepare_torch_laplacian
+    from modules.my_models_graph import ResBlock
+
+    lap = prepare_torch_laplacian(sphere.SphereHealpix(4, nest=True, k=8).L, lmax=1.9)
+    V = lap.shape[0]
+    opts = dict(kernel_size=3, conv_type="graph", bias=True, batch_norm=False, batch_norm_before_activation=False,
+                activation=True, activation_fun="relu", periodic_padding=True, lonlat_ratio=None)
+    worst = 0.0
+    for B, cin, widths in shapes or [(2, 18, (64, 128)), (2, 256, (128, 64)), (3, 64, (2,)), (2, 32, (32,)), (2, 7, (12, 5))]:
+        torch.manual_seed(5)
+        block = ResBlock(cin, widths if len(widths) > 1 else widths[0], laplacian=lap, convblock_kwargs=opts)
+        with torch.no_grad():
+            block.rezero_weight.fill_(0.37)
+            for p in block.parameters():
+                if p.dim() == 1 and p.numel() > 1:
+                    p.normal_(0, 0.1)
+        x64 = torch.from_numpy(recipes.rand(900 + cin, (B, V, cin))).double()
+        g64 = torch.from_numpy(recipes.rand(901 + cin, (B, V, widths[-1]))).double()
+
+        def reference():     # fp64, dense operator, the reference's op order
+            L = lap.to_dense().double()
+            P = {n: p.detach().double().requires_grad_(True) for n, p in block.named_parameters()}
+            x = x64.clone().requires_grad_(True)
+
+            def conv(h, w, b):
+                t = [h, torch.einsum("vu,buf->bvf", L, h)]
+                t.append(2 * torch.einsum("vu,buf->bvf", L, t[1]) - t[0])
+                return sum(torch.einsum("bvf,fo->bvo", t[k], w[:, k, :]) for k in range(3)) + b
+            h = x
+            for i, name in enumerate(block.conv_names_list):
+                h = conv(h, P[f"{name}.conv.weight"], P[f"{name}.conv.bias"])
+                if i + 1 < len(block.conv_names_list):
+                    h = torch.relu(h)
+            res = x if cin == widths[-1] else x @ P["res_connection.weight"].t() + P["res_connection.bias"]
+            out = h * P["rezero_weight"] + res
+            out.backward(g64)
+            return out.detach(), x.grad, {n: p.grad for n, p in P.items()}
+
+        out_r, dx_r, gp_r = reference()
+        for fused in (True, False):
+            blk = block.to(device).to(dtype)
+            blk.fuse_tail = fused
+            blk.zero_grad(set_to_none=True)
+            x = x64.to(dtype).to(device).requires_grad_(True)
+            out = blk(x)
+            out.backward(g64.to(dtype).to(device))
+            errs = {"out": orc.max_rel_err(out.float(), out_r.numpy()), "dx": orc.max_rel_err(x.grad.float(), dx_r.numpy())}
+            for n, p in blk.named_parameters():
+                ref = gp_r[n].numpy()
+                errs[n] = orc.max_rel_err(p.grad.float().reshape(ref.shape), ref)
+            bad = {k: v for k, v in errs.items() if v > (tol if "rezero" not in k else 20 * tol)}
+            assert not bad, (cin, widths, fused, bad)
+            worst = max(worst, max(errs.values()))
+    return worst
+
+
+def test_resblock_fused_tail_cpu_wiring(oracle_backend):
+    check_resblock_tail("cpu")
+
+
+def test_resblock_tail_respects_hooks_and_switch(oracle_backend):
+    """A forward hook on the last ConvBlock / its conv / the residual map sends the block down the plain path (the
+    fused tail does not call those modules), and so does `fuse_tail = False`."""
+    from dsw_amd import sphere
+    from modules.layers import prepare_torch_laplacian
+    from modules.my_models_graph import ResBlock
+
+    lap = prepare_torch_laplacian(sphere.SphereHealpix(2, nest=True, k=8).L, lmax=1.9)
+    opts = dict(kernel_size=3, conv_type="graph", bias=True, batch_norm=False, batch_norm_before_activation=False,
+                activation=True, activation_fun="relu", periodic_padding=True, lonlat_ratio=None)
+    block = ResBlock(6, (8, 12), laplacian=lap, convblock_kwargs=opts)
+    x = torch.randn(2, lap.shape[0], 6)
+    assert not block._fusable_tail(x)            # off by default (measured slower at the U-Net's sizes, see ResBlock)
+    block.fuse_tail = True
+    assert block._fusable_tail(x)
+    narrow = ResBlock(6, (8, 4), laplacian=lap, convblock_kwargs=opts)
+    narrow.fuse_tail = True
+    assert not narrow._fusable_tail(x)           # narrow output layer: plain path
+    seen = []
+    h = block.convblock2.conv.register_forward_hook(lambda m, a, o: seen.append(tuple(o.shape)))
+    assert not block._fusable_tail(x)
+    y = block(x)
+    assert seen == [(2, lap.shape[0], 12)]
+    h.remove()
+    assert block._fusable_tail(x) and torch.allclose(block(x), y, atol=1e-6)
+    block.fuse_tail = False
+    assert not block._fusable_tail(x)
+    bn = ResBlock(6, (8, 12), laplacian=lap, convblock_kwargs=dict(opts, batch_norm=True))
+    bn.fuse_tail = True
+    assert not bn._fusable_tail(x)
