@@ -41,7 +41,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s measured copy ceiling
 
-GRAPH_STEPS = 10   # steps per captured graph on a single GPU (see main)
+GRAPH_STEPS = 10   # steps per captured graph (see main): the largest divisor of --steps in 5..25, else this
 
 WORKLOADS = {
     "ns": dict(nside=64, K=3, fin=32, fout=64, batch=16, dtype="f32"),
@@ -545,7 +545,13 @@ def _arm_watchdog(rank, world, limit=None, what="the run"):
 
 
 def main():
+    global GRAPH_STEPS
     args = parse()
+    # consecutive graph launches leave the GPU idle for ~40 us: the timed K steps should be whole replays of one graph
+    for g in range(25, 4, -1):
+        if args.steps % g == 0:
+            GRAPH_STEPS = g
+            break
     env_world = os.environ.get("WORLD_SIZE")
     if args.gpus is None:
         args.gpus = int(env_world) if env_world else 1

@@ -1107,7 +1107,7 @@ def test_bench_one_rank_world_captures_the_exchange():
     print(out["config"]["launch"], out.get("allreduce"))
     assert out["n_gpus"] == 1 and "all-reduce" in out["config"]["launch"]
     assert "captured in the graph" in out["config"]["launch"], (out["config"]["launch"], out["allreduce"], r.stderr[-1500:])
-    assert "%d steps per graph" % 10 in out["config"]["launch"]
+    assert "20 steps per graph" in out["config"]["launch"]        # --steps 20: one replay of a 20-step graph
 
 
 @pytest.mark.parametrize("dt", [torch.float32])
