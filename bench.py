@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
     ap.add_argument("--knn", type=int, default=8, help="neighbours of the HEALPix k-NN stencil (8 or 20)")
+    ap.add_argument("--min-timed-ms", type=float, default=150.0,
+                    help="repeat the timed region (exactly --steps steps each) until this much has been timed; median reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
@@ -762,7 +764,7 @@ def main():
     # enough for a single clock-ramp or scheduling hiccup to move the number by 10-20 %.  So the region is repeated
     # back to back - every repetition is exactly K steps inside its own barrier + synchronize bracket - until >= 150 ms
     # have been timed, and the MEDIAN region is reported (all regions are listed in "region_ms").
-    n_regions = int(min(64, max(3, -(-0.15 // max(probe, 1e-6)))))
+    n_regions = int(min(64, max(3, -(-(args.min_timed_ms * 1e-3) // max(probe, 1e-6)))))
     regions = sorted(timed_region(args.steps) for _ in range(n_regions))
     elapsed = regions[len(regions) // 2]
 

@@ -18,9 +18,15 @@ bash tools/prof_stats.sh ${tag}_unet --workload unet --no-cpu-baseline --no-roof
 bash tools/prof_stats.sh ${tag}_c3 --workload c3 --no-cpu-baseline --steps 20 > $out/stats_c3.txt 2>&1
 bash tools/prof_stats.sh ${tag}_k20 --knn 20 --no-cpu-baseline --steps 20 > $out/stats_k20.txt 2>&1
 for t in default unet c3 k20; do cp $root/gpurun_out/prof_${tag}_$t/${tag}_${t}_kernel_stats.csv $out/${tag}_${t}_kernel_stats.csv 2>/dev/null; done
+bash tools/prof_stats.sh ${tag}_c5 --workload c5 --no-cpu-baseline --steps 20 > $out/stats_c5.txt 2>&1
+cp $root/gpurun_out/prof_${tag}_c5/${tag}_c5_kernel_stats.csv $out/${tag}_c5_kernel_stats.csv 2>/dev/null
 bash tools/prof_pmc.sh ${tag}_ns > $out/${tag}_ns_pmc_summary.txt 2>&1
 BENCH_ARGS="--workload c3 --steps 10 --warmup 3 --no-cpu-baseline" bash tools/prof_pmc.sh ${tag}_c3 > $out/${tag}_c3_pmc_summary.txt 2>&1
 BENCH_ARGS="--knn 20 --steps 10 --warmup 3 --no-cpu-baseline" bash tools/prof_pmc.sh ${tag}_k20 > $out/${tag}_k20_pmc_summary.txt 2>&1
-python tools/make_traffic_json.py ns ${tag}_ns c3 ${tag}_c3 ns_k20 ${tag}_k20 > $out/traffic.log 2>&1
+# whole-model workloads: HBM bytes of the SpMM launches of the roofline leg's layer (one step, then the leg: the leg's
+# dispatches are the majority of their kernel - make_traffic_json.py takes the MEDIAN dispatch); passes A / B only
+PMC_PASSES="A B" BENCH_ARGS="--workload unet --steps 1 --warmup 0 --min-timed-ms 0 --no-graph --no-cpu-baseline" bash tools/prof_pmc.sh ${tag}_unet > $out/${tag}_unet_pmc_summary.txt 2>&1
+PMC_PASSES="A B" BENCH_ARGS="--workload c5 --steps 1 --warmup 0 --min-timed-ms 0 --no-graph --no-cpu-baseline" bash tools/prof_pmc.sh ${tag}_c5 > $out/${tag}_c5_pmc_summary.txt 2>&1
+python tools/make_traffic_json.py ns ${tag}_ns c3 ${tag}_c3 ns_k20 ${tag}_k20 unet ${tag}_unet c5 ${tag}_c5 > $out/traffic.log 2>&1
 cp profiles/spmm_traffic.json $out/spmm_traffic.json
 ls -la $out

@@ -5,7 +5,7 @@ usage: tools/make_traffic_json.py <workload key> <tag> [<workload key> <tag> ...
 Reads gpurun_out/pmc_<tag>_{A,B}/**/*counter_collection.csv.  HBM bytes per dispatch of the SpMM recurrence
 kernels = (2 * FETCH_SIZE + WRITE_SIZE) KiB: FETCH_SIZE reports half of wide (16 B/lane) coalesced reads on gfx950
 (MI355X_MICROARCH.md, HBM section), WRITE_SIZE is exact.  The per-launch figure bench.py reports next to the
-algorithmic bytes is the mean over the SpMM launches of one step (forward recurrence + adjoint recurrence)."""
+algorithmic bytes is the median dispatch per kernel, mean over the SpMM launches of one step (forward recurrence + adjoint recurrence)."""
 import collections
 import csv
 import glob
@@ -31,8 +31,11 @@ for key, tag in zip(args[0::2], args[1::2]):
     for name, d in sorted(vals.items()):
         if not d["FETCH_SIZE"] or not d["WRITE_SIZE"]:
             continue
-        rd = 2.0 * 1024 * sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"])
-        wr = 1024.0 * sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
+        # MEDIAN dispatch: in whole-model runs one kernel variant serves layers of different sizes; the profiled command is
+        # arranged so that the launches of interest (the roofline leg's layer) are the majority of its dispatches
+        med = lambda v: sorted(v)[len(v) // 2]
+        rd = 2.0 * 1024 * med(d["FETCH_SIZE"])
+        wr = 1024.0 * med(d["WRITE_SIZE"])
         kernels[name] = {"read": round(rd), "write": round(wr), "dispatches_sampled": len(d["WRITE_SIZE"])}
         if name.startswith("spmm"):          # other kernels of the step are listed, not part of the SpMM mean
             per_kernel[name] = rd + wr
@@ -50,6 +53,6 @@ for key, tag in zip(args[0::2], args[1::2]):
         total += per_kernel[n] * w; launches += w
     if launches:
         result[key] = {"hbm_bytes_per_launch": round(total / launches), "kernels": kernels,
-                       "source": f"tools/prof_pmc.sh {tag} (passes A: FETCH_SIZE x2, B: WRITE_SIZE), mean over the SpMM launches of one step"}
+                       "source": f"tools/prof_pmc.sh {tag} (passes A: FETCH_SIZE x2, B: WRITE_SIZE), median dispatch per kernel, mean over the SpMM launches of one step"}
 json.dump(result, open(out_path, "w"), indent=1)
 print(json.dumps(result, indent=1))

@@ -7,6 +7,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for pass in "A FETCH_SIZE" "B WRITE_SIZE" "C SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE" "D TCC_HIT_sum TCC_MISS_sum" "E SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_WAIT_INST_LDS"; do
   set -- $pass; p=$1; shift
+  if [ -n "$PMC_PASSES" ] && ! echo " $PMC_PASSES " | grep -q " $p "; then continue; fi
   out=$root/gpurun_out/pmc_${tag}_$p
   mkdir -p $out
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $@ --output-format csv -d $out -o pmc -- python $root/bench.py ${BENCH_ARGS:---steps 10 --warmup 3 --no-cpu-baseline} > $out/run.log 2>&1
