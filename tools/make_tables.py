@@ -59,7 +59,7 @@ w("In-step kernels of the default command (`roofline.in_step` of the bench line:
   "algorithmic bytes = SURVEY 8d pass counts) next to rocprofv3 of the same command (`profiles/%s_default_kernel_stats.csv`) "
   "and the PMC traffic (`profiles/spmm_traffic.json`, `%s_ns_pmc_summary.txt`):" % (tag, tag))
 w("")
-w("| role | bench leg us | algorithmic MB -> fraction of 8 TB/s | rocprofv3 kernel (avg us, %% of GPU time) | measured HBM MB (read + write) -> TB/s |")
+w("| role | bench leg us | algorithmic MB -> fraction of 8 TB/s | rocprofv3 kernel (avg us, % of GPU time) | measured HBM MB (read + write) -> TB/s |")
 w("|---|---|---|---|---|")
 ns = lines.get("ns_default")
 st = stats("%s_default_kernel_stats.csv" % tag)
