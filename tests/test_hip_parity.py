@@ -1074,7 +1074,7 @@ def test_bench_two_ranks_self_launched():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["DSW_DIST_BACKEND"] = "gloo"
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2"],
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "2", "--min-timed-ms", "100"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -1128,3 +1128,27 @@ def test_resblock_fused_tail_wide_layers():
     from test_host_logic import check_resblock_tail
 
     check_resblock_tail(DEV, torch.float32, TOL_F64, shapes=[(2, 128, (192, 256)), (2, 256, (512, 256)), (2, 512, (256, 128))])
+
+
+def test_bench_two_ranks_under_torchrun():
+    """The driver's other way of starting N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...` (here both ranks on the one GPU, gloo).  bench.py must
+    notice the torchrun environment (no second launcher level) and report the same things as the self-launched run."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["DSW_DIST_BACKEND"] = "gloo"
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10",
+                        "--warmup", "2", "--min-timed-ms", "100"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and "launcher" not in out["config"]
+    assert out["grad_sync"]["identical"] and out["allreduce_us"] > 0
