@@ -243,3 +243,61 @@ def test_unet_nside32_batch8_vs_cpu_restatement():
     # measured with the decisions pinned: weight tensors 1.1e-6, ReZero scalars / biases 1.3e-5 -> gates at ~4-5x
     assert errs["grad_weights_max"] <= 5e-6 and errs["grad_bias_rezero_max"] <= 5e-5, (worst_name, errs)
     assert errs["y_vs_torch32"] <= 1e-5 and errs["grad_weights_max_vs_torch32"] <= 3e-4, errs   # the restatement's own fp32 error
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Size-independent properties at the full benchmark sizes (no oracle in the loop): what a linear operator and its
+# hand-written adjoint must satisfy whatever their size
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("knn,Fin,Fout,K,dt", [(8, 32, 64, 3, torch.float32), (20, 32, 64, 3, torch.float32),
+                                              (8, 64, 128, 5, torch.float32), (20, 128, 64, 3, torch.float32)])
+def test_full_size_adjoint_identity_and_linearity(knn, Fin, Fout, K, dt):
+    """ConvCheb without bias is linear in x and in W, and its closed-form backward is the adjoint of its forward:
+        <conv(x; W), g> = <x, dX(g)> = <W, dW(x, g)>        (fp64 inner products of the fp32 device results)
+        conv(a x1 + x2; W) = a conv(x1; W) + conv(x2; W)
+    at nside 64, B 16 (786 432 rows): the whole-forward kernel, the fused backward GEMM pass, both two-hop pairs, the
+    K = 5 pairs with spare planes, a mix-first layer - each against ITSELF, so a slab / tile / halo bug that an
+    element-wise comparison at small size cannot see shows up here as a broken identity."""
+    from modules.layers import ConvCheb
+
+    lap = _healpix_operator(64, knn)
+    V, B = lap.shape[0], 16
+    torch.manual_seed(11)
+    layer = ConvCheb(Fin, Fout, K, laplacian=lap, bias=False).to(DEV).to(dt)
+    x1 = torch.randn(B, V, Fin, device=DEV, dtype=dt)
+    x2 = torch.randn(B, V, Fin, device=DEV, dtype=dt)
+    g = torch.randn(B, V, Fout, device=DEV, dtype=dt)
+    xa = x1.clone().requires_grad_(True)
+    y = layer(xa)
+    y.backward(g)
+    dot = lambda a, b: float((a.double() * b.double()).sum())
+    lhs = dot(y.detach(), g)
+    rhs_x, rhs_w = dot(x1, xa.grad), dot(layer.weight.detach(), layer.weight.grad)
+    scale = float(y.detach().double().norm() * g.double().norm())
+    assert abs(lhs - rhs_x) <= 2e-6 * scale and abs(lhs - rhs_w) <= 2e-6 * scale, (lhs, rhs_x, rhs_w, scale)
+    with torch.no_grad():
+        y2, y12 = layer(x2), layer(0.5 * x1 + x2)
+        err = float((y12.double() - (0.5 * y.detach().double() + y2.double())).abs().max() / y12.double().abs().max())
+    assert err <= 2e-6, err
+    _record("adjoint_identity_k%d_%dto%d_K%d" % (knn, Fin, Fout, K),
+            {"adjoint_x": abs(lhs - rhs_x) / scale, "adjoint_w": abs(lhs - rhs_w) / scale, "linearity": err})
+
+
+def test_full_size_pool_unpool_adjoint_and_row_sums():
+    """Interpolation pooling at nside 64 -> 32 (B 16, 64 channels): M 1 = 1 (rows sum to one: a constant field stays
+    constant), and backward is the transposed product: <M x, g> = <x, M^T g>."""
+    from dsw_amd import sphere
+    from modules.layers import GeneralAvgPool
+
+    pool_m, _ = sphere.healpix_pool_matrices(64, nest=True)
+    pool = GeneralAvgPool(pool_m).to(DEV)
+    B, C = 16, 64
+    x = torch.randn(B, 49152, C, device=DEV).requires_grad_(True)
+    g = torch.randn(B, 12288, C, device=DEV)
+    y, _ = pool(x)
+    y.backward(g)
+    dot = lambda a, b: float((a.double() * b.double()).sum())
+    lhs, rhs = dot(y.detach(), g), dot(x.detach(), x.grad)
+    assert abs(lhs - rhs) <= 2e-6 * float(y.detach().double().norm() * g.double().norm())
+    ones, _ = pool(torch.full((1, 49152, 4), 3.25, device=DEV))
+    assert float((ones - 3.25).abs().max()) <= 1e-5
