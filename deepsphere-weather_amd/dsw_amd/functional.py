@@ -531,12 +531,35 @@ def _check_dtype(*tensors):
 # ----------------------------------------------------------------------------------------------
 # autograd Functions
 # ----------------------------------------------------------------------------------------------
+PAD_INPUT_CHANNELS = True   # see _padded_width
+
+
+def _padded_width(fin: int, dtype) -> int:
+    """Input width the kernels should see.  The fast paths (whole-forward kernel, two-hop pairs, bf16-pipe GEMMs, fused
+    backward pass) want rows of whole 32-channel chunks; a layer with, say, 18 input channels (the U-Net's first:
+    3 time steps x 6 fields) otherwise takes the exact-fp32 kernels with predicated scalar loads - 4 launches, 150 us =
+    4 % of the U-Net step (round 2).  Zero channels contribute exact zeros, so such a layer is evaluated as the next
+    multiple of 32 (x and the weight rows padded with zeros, the gradients sliced back) whenever that is at most twice
+    the real width: 16..31 -> 32, 33..63 -> 64, ...  fp32 only (the bf16 paths have other alignment rules)."""
+    if not PAD_INPUT_CHANNELS or dtype != torch.float32 or fin % 32 == 0:
+        return fin
+    padded = (fin + 31) // 32 * 32
+    return padded if padded <= 2 * fin else fin
+
+
 class _ChebConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, op, relu=False):
         be = _backend_for(x)
-        xc = x.contiguous()
-        wc = weight.contiguous()
+        fin = x.shape[-1]
+        fpad = _padded_width(fin, x.dtype) if x.is_cuda else fin
+        ctx.fin = fin
+        if fpad != fin:
+            xc = torch.nn.functional.pad(x, (0, fpad - fin))                       # [B, V, fpad], zeros behind the real channels
+            wc = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, fpad - fin))      # [fpad, K, Fout]
+        else:
+            xc = x.contiguous()
+            wc = weight.contiguous()
         bc = None if bias is None else bias.contiguous()
         y, T = be.cheb_fwd(op, xc, wc, bc, relu) if relu else be.cheb_fwd(op, xc, wc, bc)
         # the plain output is NOT saved: callers modify it in place (layers.py:375, my_models_graph.py:213).  With the
@@ -560,6 +583,9 @@ class _ChebConvFn(torch.autograd.Function):
         if ctx.relu:
             dy = ctx.be.relu_bwd(dy, y)
         dx, dw, db = ctx.be.cheb_bwd(ctx.op, xc, T, wc, dy, need_dx, need_dw, need_db)
+        if ctx.fin != xc.shape[-1]:       # zero-padded input channels: the real ones are the leading slice
+            dx = None if dx is None else dx[..., :ctx.fin].contiguous()
+            dw = None if dw is None else dw[:ctx.fin].contiguous()
         return dx, dw, db, None, None
 
 

@@ -1152,3 +1152,35 @@ def test_bench_two_ranks_under_torchrun():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and "launcher" not in out["config"]
     assert out["grad_sync"]["identical"] and out["allreduce_us"] > 0
+
+
+@pytest.mark.parametrize("Fin,Fout,K", [(18, 64, 3), (24, 40, 2), (48, 32, 3), (18, 128, 1)])
+def test_unaligned_input_width_runs_zero_padded(Fin, Fout, K):
+    """Input widths that are not whole 32-channel chunks (the U-Net's first layer: 18) are evaluated zero-padded on the
+    aligned kernels (`functional._padded_width`): forward and every gradient against the fp64 oracle, and against the
+    unpadded evaluation of the same layer (exact-fp32 kernels) - the padding must be invisible."""
+    from dsw_amd import functional as F_
+    from modules.layers import ConvCheb
+
+    assert F_._padded_width(Fin, torch.float32) == (Fin + 31) // 32 * 32 and F_._padded_width(7, torch.float32) == 7
+    assert F_._padded_width(Fin, torch.bfloat16) == Fin and F_._padded_width(64, torch.float32) == 64
+    (rp, ci, va), x, w, b, gy = _rand_case(768, 3, Fin, Fout, K, seed=300 + Fin, bias=True)
+    lap = orc.coo_from_csr_arrays(rp, ci, va, (768, 768))
+    layer = ConvCheb(Fin, Fout, K, laplacian=lap, bias=True)
+    layer.set_parameters(torch.from_numpy(w), torch.from_numpy(b))
+    layer = layer.to(DEV)
+    res = {}
+    for pad in (True, False):
+        F_.PAD_INPUT_CHANNELS = pad
+        layer.zero_grad(set_to_none=True)
+        try:
+            res[pad] = _run_layer(layer, torch.from_numpy(x).to(DEV), torch.from_numpy(gy).to(DEV))
+        finally:
+            F_.PAD_INPUT_CHANNELS = True
+    y64 = orc.cheb_forward_f64(rp, ci, va, x, w, b)
+    dx64, dw64, db64 = orc.cheb_backward_f64(rp, ci, va, x, w, gy, True)
+    for pad in (True, False):
+        y, dx, dw, db = res[pad]
+        assert dx.shape == x.shape and dw.shape == w.shape
+        for got, ref in ((y, y64), (dx, dx64), (dw, dw64), (db, db64)):
+            assert orc.max_rel_err(got, ref) <= TOL_F64, pad
