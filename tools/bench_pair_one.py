@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""One configuration of the K = 3 recurrences for profiling: tools/bench_pair_one.py <quads 0|1> <knn> [fwd|adj] [nside C B]"""
+"""One configuration of the K = 3 recurrences for profiling (tools/pmc_pair.sh):
+    tools/bench_pair_one.py <unused 0|1> <knn> [fwd|adj] [nside C B]
+(the first argument selected the row-group kernel of the round-3 experiment, branch exp/quad-gather; ignored on main)"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(REPO, "deepsphere-weather_amd"), REPO]
@@ -10,7 +12,6 @@ from modules.layers import prepare_torch_laplacian
 quads, knn = int(sys.argv[1]), int(sys.argv[2])
 which = sys.argv[3] if len(sys.argv) > 3 else "fwd"
 nside, C, B = (int(v) for v in sys.argv[4:7]) if len(sys.argv) > 6 else (64, 32, 16)
-F_.QUAD_GATHER = bool(quads)
 lib = _native.load()
 g = sphere.SphereHealpix(nside, nest=True, k=knn)
 op = F_.get_operator(prepare_torch_laplacian(g.L, lmax=1.95).to("cuda"))
