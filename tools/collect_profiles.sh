@@ -30,3 +30,7 @@ PMC_PASSES="A B" BENCH_ARGS="--workload c5 --steps 1 --warmup 0 --min-timed-ms 0
 python tools/make_traffic_json.py ns ${tag}_ns c3 ${tag}_c3 ns_k20 ${tag}_k20 unet ${tag}_unet c5 ${tag}_c5 > $out/traffic.log 2>&1
 cp profiles/spmm_traffic.json $out/spmm_traffic.json
 ls -la $out
+# what travels back is limited (64 MiB): the raw traces have been summarised above
+find $root/gpurun_out -name "*kernel_trace.csv" -delete 2>/dev/null
+find $root/gpurun_out -name "*counter_collection.csv" -delete 2>/dev/null
+du -sh $root/gpurun_out
