@@ -115,8 +115,9 @@ class Trainer:
         dim_names = dim_names or ["sample", "time", "node", "feature"]
         self.dim_info = {n: i for i, n in enumerate(dim_names)}
         self.criterion = WeightedMSELoss(weights=None if weights is None else weights.to(x.device))   # fp32 area weights, as the reference
+        # (DSW_FORCE_GRAD_SYNC=1: a one-rank world runs the N > 1 code path - RCCL exchange, in-graph capture - on one GPU)
         self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized() \
-            and torch.distributed.get_world_size() > 1
+            and (torch.distributed.get_world_size() > 1 or os.environ.get("DSW_FORCE_GRAD_SYNC") == "1")
         # capturable: the step counter lives on the device, so optimizer.step() can sit inside a HIP graph
         self.optimizer = torch.optim.Adam(model.parameters(), lr=lr, eps=1e-7, weight_decay=0, amsgrad=False,
                                           capturable=bool(use_graph and x.is_cuda))

@@ -1184,3 +1184,33 @@ def test_unaligned_input_width_runs_zero_padded(Fin, Fout, K):
         assert dx.shape == x.shape and dw.shape == w.shape
         for got, ref in ((y, y64), (dx, dx64), (dw, dw64), (db, db64)):
             assert orc.max_rel_err(got, ref) <= TOL_F64, pad
+
+
+def test_training_driver_one_rank_world_whole_step_graph(tmp_path):
+    """The training driver's N > 1 graph mode in a one-rank RCCL world (DSW_FORCE_GRAD_SYNC=1, --graph): the exchange and
+    the Adam update are recorded into the step graph ("whole step incl. the RCCL gradient all-reduce"), and the losses
+    are those of the plain single-process run (averaging over one rank changes nothing)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = json.load(open(os.path.join(root, "configs/UNetSpherical/Healpix_400km/InterpPool-Graph_knn.synthetic.json")))
+    cfg["model_settings"]["sampling_kwargs"]["subdivisions"] = 8
+    cfg["model_settings"]["knn"] = 8
+    path = tmp_path / "cfg.json"
+    path.write_text(json.dumps(cfg))
+    base = [sys.executable, os.path.join(root, "scripts_training", "train_synthetic_state.py"), "--config_file", str(path),
+            "--steps", "6", "--warmup", "0", "--batch_size", "2", "--ar_iterations", "1"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DSW_DIST_BACKEND")}
+    outs = []
+    for extra_env, extra_args in (({}, []), ({"DSW_FORCE_GRAD_SYNC": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29641"},
+                                             ["--graph"])):
+        r = subprocess.run(base + extra_args, env=dict(env, **extra_env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
+    plain, ranked = outs
+    assert plain["launch"] == "hip graph: whole step"
+    assert ranked["launch"] == "hip graph: whole step incl. the RCCL gradient all-reduce", ranked["launch"]
+    assert abs(ranked["loss_first"] - plain["loss_first"]) <= 1e-6 * abs(plain["loss_first"])
+    assert abs(ranked["loss_last"] - plain["loss_last"]) <= 1e-4 * abs(plain["loss_last"])
