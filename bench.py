@@ -623,6 +623,7 @@ def main():
     bucket = GradBucket(model.parameters(), overlap=False, attach=False)
     if bucket.active():
         bucket.attach()
+        bucket.direct_accumulation()     # the weight-gradient kernels add into the bucket: no autograd `add` per parameter
         zero_grads = bucket.zero
     else:
         def zero_grads():

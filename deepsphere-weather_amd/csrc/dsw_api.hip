@@ -26,6 +26,7 @@ int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* 
 int dsw_relu_inplace_launch(void* y, int64_t n, int dtype, hipStream_t s);
 int dsw_mix_dgrad_launch(const void* dY, const void* W, void* G0, void* Grest, int64_t N, int64_t Fin,
                          int64_t Fout, int64_t K, int dtype, hipStream_t stream, const DswEpiExtra* extra = nullptr);
+void dsw_wgrad_set_accumulate(int on);
 int dsw_rezero_param_grads_launch(const void* W, const void* bias, const void* dW_raw, const void* db_raw, const void* scale,
                                   void* dW, void* db, void* dscale, int64_t n_w, int64_t n_b, void* workspace, int dtype,
                                   hipStream_t stream);
@@ -377,9 +378,13 @@ int dsw_cheb_bwd_res(const int32_t* rowptr_t, const int32_t* colind_t, const flo
                      int64_t nnz, const void* X, const void* T, const void* W, const void* dY, void* dX, void* dW,
                      void* db, void* workspace, int64_t workspace_bytes, int64_t B, int64_t Fin, int64_t Fout,
                      int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan_t, const void* scale,
-                     const void* dX_add, int64_t ld_add) {
-    return cheb_bwd_impl(rowptr_t, colind_t, vals_t, V, nnz, X, T, W, dY, dX, dW, db, workspace, workspace_bytes, B, Fin,
-                         Fout, K, dtype, stream, plan_t, scale, dX_add, ld_add);
+                     const void* dX_add, int64_t ld_add, int accumulate_dw) {
+    if (accumulate_dw && B * V == 0) return DSW_OK;        // an empty shard adds nothing
+    dsw_wgrad_set_accumulate(accumulate_dw ? 1 : 0);
+    const int rc = cheb_bwd_impl(rowptr_t, colind_t, vals_t, V, nnz, X, T, W, dY, dX, dW, db, workspace, workspace_bytes, B,
+                                 Fin, Fout, K, dtype, stream, plan_t, scale, dX_add, ld_add);
+    dsw_wgrad_set_accumulate(0);
+    return rc;
 }
 
 int64_t dsw_rezero_param_grads_workspace_bytes(void) { return dsw_rezero_param_grads_ws_bytes_impl(); }

@@ -452,7 +452,8 @@ __global__ __launch_bounds__(64 * NW) void cheb_wgrad_kernel(const WgradParams P
 template <bool BF16, int NG = 8>
 __global__ __launch_bounds__(32 * NG) void cheb_wgrad_reduce_kernel(const float* __restrict__ partial, int S,
                                                                     int Fin, int Fout, int K, void* dW,
-                                                                    void* db, int K_out, int k_off, int db_cols = 1 << 30) {
+                                                                    void* db, int K_out, int k_off, int db_cols = 1 << 30,
+                                                                    int accumulate = 0) {
     __shared__ float red[NG][32];
     const int Kd = K * Fin;
     const long total = (long)(Kd + 1) * Fout;
@@ -477,11 +478,14 @@ __global__ __launch_bounds__(32 * NG) void cheb_wgrad_reduce_kernel(const float*
 #pragma unroll
         for (int g = 0; g < NG; ++g) v += red[g][lane_o];
         const int kd = (int)(idx / Fout), o = (int)(idx - (long)kd * Fout);
+        // accumulate: dW / db are gradient buffers that already hold the contributions of other uses of the parameter (an
+        // autoregressive step applies every layer 7 times): add instead of leaving 38 x 7 tiny `add` launches to autograd
         if (kd == Kd) {
-            if (db != nullptr && o < db_cols) st1<BF16>(db, o, v);   // (planes side by side: only plane 0 is dY)
+            if (db != nullptr && o < db_cols) st1<BF16>(db, o, accumulate ? v + ld1<BF16>(db, o) : v);   // (planes side by side: only plane 0 is dY)
         } else {
             const int k = kd / Fin, f = kd - k * Fin;
-            st1<BF16>(dW, ((size_t)f * K_out + k_off + k) * Fout + o, v);   // dW is [Fin, K_out, Fout]
+            const size_t at = ((size_t)f * K_out + k_off + k) * Fout + o;        // dW is [Fin, K_out, Fout]
+            st1<BF16>(dW, at, accumulate ? v + ld1<BF16>(dW, at) : v);
         }
     }
 }
@@ -820,25 +824,31 @@ reduce:
 }
 
 // partial [S][K * Fin + 1][Fout] -> dW / db (used by dsw_narrow.hip as well)
+// Set by the C-ABI entry point for the duration of one call on the calling thread (dsw_cheb_bwd_res, accumulate_dw): the
+// reduce stage of EVERY weight-gradient path of that call adds to dW / db instead of overwriting them.
+static thread_local int g_wgrad_accumulate = 0;
+void dsw_wgrad_set_accumulate(int on) { g_wgrad_accumulate = on; }
+
 int dsw_wgrad_reduce_launch(const float* partial, int64_t S, int64_t Fin, int64_t Fout, int64_t K, void* dW, void* db,
                             int64_t K_out, int64_t k_off, int db_cols, int dtype, hipStream_t stream) {
     const long total = (long)(K * Fin + 1) * Fout;
+    const int acc = g_wgrad_accumulate;
     dim3 rgrid((unsigned)((total + 31) / 32));
     if (total <= 16384 && S > 64) {   // few outputs (<= 512 blocks), many slabs: 32 slab groups per block
         if (dtype == DSW_F32)
             hipLaunchKernelGGL((cheb_wgrad_reduce_kernel<false, 32>), rgrid, dim3(1024), 0, stream, partial, (int)S,
-                               (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols);
+                               (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols, acc);
         else
             hipLaunchKernelGGL((cheb_wgrad_reduce_kernel<true, 32>), rgrid, dim3(1024), 0, stream, partial, (int)S,
-                               (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols);
+                               (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols, acc);
         return dsw_check_launch();
     }
     if (dtype == DSW_F32)
         hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, stream, partial, (int)S,
-                           (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols);
+                           (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols, acc);
     else
         hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, stream, partial, (int)S,
-                           (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols);
+                           (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols, acc);
     return dsw_check_launch();
 }
 

@@ -364,16 +364,21 @@ class _HipBackend:
         _native.check(rc, "dsw_cheb_fwd_res")
         return y, (None if mix_first else T)
 
-    def cheb_bwd_res(self, op, x, T, w, dy, need_dx, need_dw, scale=None, dx_add=None):
+    def cheb_bwd_res(self, op, x, T, w, dy, need_dx, need_dw, scale=None, dx_add=None, acc_w=None, acc_b=None):
         """Backward of ``scale * conv(x)`` taking ``dy`` as it arrives: ``dx = scale * (...) + dx_add``; ``dw_raw`` /
-        ``db_raw`` are NOT scaled (see ``rezero_param_grads``)."""
+        ``db_raw`` are NOT scaled (see ``rezero_param_grads``).  ``acc_w`` (and ``acc_b``): gradient buffers of the
+        parameters to ADD the weight gradients to (``dsw_cheb_bwd_res`` with ``accumulate_dw``); they are returned."""
         lib = _native.load()
         B, V, Fin = x.shape
         _, K, Fout = w.shape
         dt = _DTYPES[x.dtype]
         dx = torch.empty_like(x) if need_dx else None
-        dw = torch.empty_like(w) if need_dw else None
-        db = torch.empty((Fout,), dtype=w.dtype, device=w.device) if need_dw else None
+        accumulate = acc_w is not None
+        if accumulate:
+            dw, db = acc_w, acc_b
+        else:
+            dw = torch.empty_like(w) if need_dw else None
+            db = torch.empty((Fout,), dtype=w.dtype, device=w.device) if need_dw else None
         nbytes = int(lib.dsw_cheb_bwd_workspace_bytes(B, V, Fin, Fout, K, dt))
         if nbytes < 0:
             _native.check(nbytes, "dsw_cheb_bwd_workspace_bytes")
@@ -388,7 +393,7 @@ class _HipBackend:
             rc = lib.dsw_cheb_bwd_res(
                 *csr, x.data_ptr(), _ptr(T), w.data_ptr(), dy.data_ptr(), _ptr(dx), _ptr(dw), _ptr(db),
                 ws.data_ptr(), nbytes, B, Fin, Fout, K, dt, _stream(x), pp, _ptr(scale),
-                _ptr(dx_add) if need_dx else None, 0 if dx_add is None else row_stride(dx_add),
+                _ptr(dx_add) if need_dx else None, 0 if dx_add is None else row_stride(dx_add), 1 if accumulate else 0,
             )
         _native.check(rc, "dsw_cheb_bwd_res")
         return dx, dw, db
@@ -547,10 +552,23 @@ def _padded_width(fin: int, dtype) -> int:
     return padded if padded <= 2 * fin else fin
 
 
+def grad_accumulators(weight, bias):
+    """The gradient buffers a ``GradBucket`` in direct mode attached to these parameters (``None`` otherwise / when the
+    bias has none while the weight does: the kernels produce both or neither)."""
+    aw = getattr(weight, "_dsw_grad_acc", None)
+    if aw is None:
+        return None
+    ab = None if bias is None else getattr(bias, "_dsw_grad_acc", None)
+    if bias is not None and ab is None:
+        return None
+    return aw, ab
+
+
 class _ChebConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, op, relu=False):
+    def forward(ctx, x, weight, bias, op, relu=False, acc=None):
         be = _backend_for(x)
+        ctx.acc = acc if (acc is not None and x.is_cuda) else None
         fin = x.shape[-1]
         fpad = _padded_width(fin, x.dtype) if x.is_cuda else fin
         ctx.fin = fin
@@ -582,11 +600,16 @@ class _ChebConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         if ctx.relu:
             dy = ctx.be.relu_bwd(dy, y)
+        if ctx.acc is not None and need_dw and ctx.fin == xc.shape[-1]:
+            # the parameters' gradient buffers take the contribution directly (dW +=, db += in the reduce stage of the
+            # weight-gradient kernels): nothing is returned for them, autograd launches no `add`
+            dx, _w, _b = ctx.be.cheb_bwd_res(ctx.op, xc, T, wc, dy, need_dx, True, acc_w=ctx.acc[0], acc_b=ctx.acc[1])
+            return dx, None, None, None, None, None
         dx, dw, db = ctx.be.cheb_bwd(ctx.op, xc, T, wc, dy, need_dx, need_dw, need_db)
         if ctx.fin != xc.shape[-1]:       # zero-padded input channels: the real ones are the leading slice
             dx = None if dx is None else dx[..., :ctx.fin].contiguous()
             dw = None if dw is None else dw[:ctx.fin].contiguous()
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class _ChebConvResFn(torch.autograd.Function):
@@ -844,10 +867,10 @@ def cheb_conv(op: CsrOperator, x: torch.Tensor, weight: torch.Tensor, bias=None,
             f"operator shape {op.shape} does not match the {x.shape[1]} nodes of the input"
         )
     _check_dtype(x, weight, bias)
-    return _ChebConvFn.apply(x, weight, bias, op, activation == "relu")
+    return _ChebConvFn.apply(x, weight, bias, op, activation == "relu", grad_accumulators(weight, bias))
 
 
-def dense_mix(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
+def dense_mix(x: torch.Tensor, weight: torch.Tensor, bias=None, acc=None) -> torch.Tensor:
     """``y = x @ weight (+ bias)`` over the last axis, ``weight [Fin, Fout]``: the K = 1 channel mix (no operator),
     i.e. the per-node linear map of the residual branch (my_models_graph.py:177-180) on the same MFMA GEMM
     kernels as ConvCheb - forward, dgrad and wgrad."""
@@ -855,7 +878,7 @@ def dense_mix(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
         raise ValueError("expected x [..., Fin] and weight [Fin, Fout]")
     _check_dtype(x, weight, bias)
     lead = x.shape[:-1]
-    y = _ChebConvFn.apply(x.reshape(1, -1, x.shape[-1]), weight.unsqueeze(1), bias, None)
+    y = _ChebConvFn.apply(x.reshape(1, -1, x.shape[-1]), weight.unsqueeze(1), bias, None, False, acc)
     return y.reshape(*lead, weight.shape[1])
 
 

@@ -167,6 +167,21 @@ class GradBucket:
         self.attached = True
         return self
 
+    def direct_accumulation(self, enable=True):
+        """Let the weight-gradient kernels ADD into the bucket themselves (`p._dsw_grad_acc`, read by
+        ``dsw_amd.functional``): a parameter that is used several times per backward (an autoregressive step applies every
+        layer once per forward) otherwise costs one tiny autograd `add` launch per use - 266 of the 1 530 launches of the
+        nside-16 training step.  The layers then return no gradient for such parameters, so their post-accumulate hooks do
+        not fire: with ``overlap`` their chunks are simply exchanged by ``finish()`` instead of during backward."""
+        if enable and not self.attached:
+            raise RuntimeError("direct accumulation needs an attached bucket")
+        for p in self.params:
+            if enable:
+                p._dsw_grad_acc = self.views[p]
+            elif hasattr(p, "_dsw_grad_acc"):
+                del p._dsw_grad_acc
+        return self
+
     def zero(self):
         if not self.attached:
             raise RuntimeError("zero() is the zero_grad of an attached bucket")

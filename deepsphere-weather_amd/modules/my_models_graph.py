@@ -115,7 +115,10 @@ class _NodeLinear(Linear):
     def forward(self, x):
         # `weight.t()` is dense [in, out] for the column-major parameter; a row-major tensor (SWAG sample, user
         # assignment) is made contiguous inside dense_mix - same values either way
-        return dsw_functional.dense_mix(x, self.weight.t(), self.bias)   # raises on CPU tensors like every layer here
+        # (the parameter's gradient buffer, if a GradBucket in direct mode attached one: memory order [in][out], which is
+        # the layout of the gradient the kernels produce for `weight.t()`)
+        acc = dsw_functional.grad_accumulators(self.weight, self.bias) if self.weight.stride() == (1, self.weight.shape[0]) else None
+        return dsw_functional.dense_mix(x, self.weight.t(), self.bias, acc=acc)   # raises on CPU tensors like every layer here
 
 
 class ResBlock(torch.nn.Module):

@@ -197,13 +197,17 @@ int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* 
  *           arrives, no scaled copy of it is made; dW / db stay UNSCALED (dW_raw = sum_n T_k dY): see
  *           dsw_rezero_param_grads;
  *   dX_add  ([B*V, ld_add >= Fin] or NULL): added to dX in the epilogue of the dgrad GEMM - the gradient a second
- *           consumer of X sent (residual branch: my_models_graph.py:213), instead of an autograd `add` pass. */
+ *           consumer of X sent (residual branch: my_models_graph.py:213), instead of an autograd `add` pass;
+ *   accumulate_dw (0 / 1): dW += and db += instead of overwriting them - dW / db are then the parameter's gradient
+ *           buffers, which already hold the contributions of its other uses (an autoregressive training step applies
+ *           every layer once per forward: 7 uses -> 7 x 38 tiny `add` launches of autograd's AccumulateGrad otherwise).
+ *           The summation order is the call order (deterministic). */
 int dsw_cheb_bwd_res(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t,
                      int64_t V, int64_t nnz, const void* X, const void* T, const void* W,
                      const void* dY, void* dX, void* dW, void* db, void* workspace,
                      int64_t workspace_bytes, int64_t B, int64_t Fin, int64_t Fout, int64_t K,
                      int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan_t,
-                     const void* scale, const void* dX_add, int64_t ld_add);
+                     const void* scale, const void* dX_add, int64_t ld_add, int accumulate_dw);
 
 /* Parameter gradients behind Y = scale * conv(X) + R when the backward ran on dY (dsw_cheb_bwd_res):
  *     dW = scale * dW_raw,  db = scale * db_raw,  dscale = <W, dW_raw> + <bias, db_raw>   (= sum dY * conv(X))

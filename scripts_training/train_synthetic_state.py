@@ -122,6 +122,10 @@ class Trainer:
         self.optimizer = torch.optim.Adam(model.parameters(), lr=lr, eps=1e-7, weight_decay=0, amsgrad=False,
                                           capturable=bool(use_graph and x.is_cuda))
         self.bucket = GradBucket(model.parameters(), overlap=True)
+        # every layer is applied once per AR forward: its weight gradients are ADDED into the bucket by the kernels
+        # themselves (no autograd `add` per use).  An eager N > 1 run keeps the hook-driven overlapped exchange instead.
+        if x.is_cuda and (not self.distributed or use_graph):
+            self.bucket.direct_accumulation()
         self.loss = None
         self.graph = None
         self.sync_in_graph = False

@@ -1214,3 +1214,32 @@ def test_training_driver_one_rank_world_whole_step_graph(tmp_path):
     assert ranked["launch"] == "hip graph: whole step incl. the RCCL gradient all-reduce", ranked["launch"]
     assert abs(ranked["loss_first"] - plain["loss_first"]) <= 1e-6 * abs(plain["loss_first"])
     assert abs(ranked["loss_last"] - plain["loss_last"]) <= 1e-4 * abs(plain["loss_last"])
+
+
+def test_direct_gradient_accumulation_matches_autograd():
+    """GradBucket.direct_accumulation(): the weight-gradient kernels add into the parameters' gradient buffers
+    (dsw_cheb_bwd_res, accumulate_dw) instead of returning tensors for autograd to add - a model whose layers are applied
+    twice per backward (an autoregressive window) must end up with the same gradients either way, the first (padded,
+    18-channel) layer and the column-major residual maps included."""
+    from dsw_amd.parallel import GradBucket
+    from test_host_logic import build_g5_model
+
+    model, g, names = build_g5_model(DEV)
+    x = torch.from_numpy(recipes.rand(77, (2, 3, 768, 6))).to(DEV)
+    t = torch.from_numpy(recipes.rand(78, (2, 1, 768, 2))).to(DEV)
+    bucket = GradBucket(model.parameters(), overlap=False)
+    grads = {}
+    for direct in (False, True):
+        bucket.direct_accumulation(direct)
+        assert hasattr(model.conv1.convblock2.conv.weight, "_dsw_grad_acc") == direct
+        bucket.zero()
+        y1 = model(x)
+        x2 = torch.cat((x[:, 1:], torch.cat((x[:, -1:, :, :4], y1), dim=3)), dim=1)      # second forward sees the first's output
+        loss = ((y1 - t) ** 2).mean() + ((model(x2) - t) ** 2).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        assert all(p.grad is bucket.views[p] for p in bucket.params)
+        grads[direct] = bucket.bucket.clone()
+    ref = grads[False]
+    assert float(ref.abs().max()) > 0
+    assert float((grads[True] - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
