@@ -35,6 +35,9 @@ int64_t dsw_wgrad_slabs(int64_t N, int64_t Fin, int64_t Fout, int64_t K);
 int dsw_spmm2_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const void* Z1, const void* Z1b,
                      const void* Z2, void* Y1, void* Y2, int64_t B, int64_t C, float a1, float b1, float d1,
                      float a2, float b2, float c2, int dtype, hipStream_t stream);
+int dsw_spmm1s_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const void* Z, const void* Z2, void* Y,
+                      int64_t B, int64_t C, float a, float b, float c, int dtype, hipStream_t stream, int stream_out);
+int dsw_spmm1s_supported(const dsw_hop2_plan* plan, int64_t C, int dtype);
 int dsw_wgrad_launch(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
                      int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream);
 int dsw_wgrad_launch_ex(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
@@ -116,6 +119,15 @@ int dsw_spmm2_fused(const dsw_hop2_plan* plan, int64_t V, const void* U, const v
                             (hipStream_t)stream);
 }
 
+int dsw_spmm_staged(const dsw_hop2_plan* plan, int64_t V, const void* U, const void* Z, const void* Z2, void* Y,
+                    int64_t B, int64_t C, float a, float b, float c, int dtype, dsw_stream_t stream, int stream_out) {
+    if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
+    if (V < 0 || B < 0 || C < 0) return DSW_ERR_BAD_ARG;
+    return dsw_spmm1s_launch(plan, V, U, Z, Z2, Y, B, C, a, b, c, dtype, (hipStream_t)stream, stream_out);
+}
+
+int dsw_spmm_staged_supported(const dsw_hop2_plan* plan, int64_t C, int dtype) { return dsw_spmm1s_supported(plan, C, dtype); }
+
 int dsw_cheb_basis_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V,
                        int64_t nnz, const void* X, void* T, int64_t B, int64_t C, int64_t K, int dtype,
                        dsw_stream_t stream, const dsw_hop2_plan* plan) {
@@ -131,10 +143,16 @@ int dsw_cheb_basis_fwd(const int32_t* rowptr, const int32_t* colind, const float
     // hop pairs run fused whenever a supported plan is given (DSW_HOP2_FWD=0 forces one launch per hop)
     static const char* fwd_env = dsw_diag_env("DSW_HOP2_FWD");
     const bool fused = plan != nullptr && !(fwd_env != nullptr && fwd_env[0] == '0') && dsw_spmm2_supported(plan, C, dtype);
+    const bool staged = plan != nullptr && dsw_spmm1s_supported(plan, C, dtype);   // dense stencils: one staged launch per hop
     int rc = DSW_OK;
     int64_t k = 1;   // next basis index to produce
     while (k < K && rc == DSW_OK) {
-        if (fused && k + 1 < K) {
+        if (staged) {
+            // the plane is gathered by the next hop (cached stores) unless it is the last one
+            rc = dsw_spmm1s_launch(plan, V, Tk(k - 1), k > 1 ? Tk(k - 2) : nullptr, nullptr, t + (k - 1) * plane, B, C,
+                                   k == 1 ? 1.f : 2.f, -1.f, 0.f, dtype, s, k + 1 < K ? 0 : 1);
+            k += 1;
+        } else if (fused && k + 1 < K) {
             // T_k = c L T_{k-1} - [k>1] T_{k-2};  T_{k+1} = 2 L T_k - T_{k-1}   (c = 1 for k = 1, else 2)
             rc = dsw_spmm2_launch(plan, V, Tk(k - 1), k > 1 ? Tk(k - 2) : nullptr, nullptr, nullptr,
                                   t + (k - 1) * plane, t + k * plane, B, C, k == 1 ? 1.f : 2.f, -1.f, 0.f, 2.f,
@@ -169,8 +187,17 @@ int dsw_cheb_basis_adj(const int32_t* rowptr_t, const int32_t* colind_t, const f
     int spare_sel = 0;
     int rc = DSW_OK;
     int64_t j = K - 1;
+    const bool staged = plan_t != nullptr && dsw_spmm1s_supported(plan_t, C, dtype);
     while (j >= 1 && rc == DSW_OK) {
-        if (fused && j >= 2) {
+        if (staged) {
+            // single step on staged neighbourhoods: G'_{j-1} = c_j L^T G'_j + G_{j-1} - G'_{j+1}, in place on plane j-1
+            char* gm1 = own(j - 1);
+            rc = dsw_spmm1s_launch(plan_t, V, loc_j, gm1, loc_jp1, gm1, B, C, (j == 1) ? 1.f : 2.f, 1.f, -1.f, dtype, s,
+                                   j > 1 ? 0 : 1);
+            loc_jp1 = loc_j;
+            loc_j = gm1;
+            j -= 1;
+        } else if (fused && j >= 2) {
             // pair (j, j-1):  Y1 = G'_{j-1} = 2 L^T G'_j + G_{j-1} - G'_{j+1}
             //                 Y2 = G'_{j-2} = c L^T Y1 + G_{j-2} - G'_j        (c = 1 if j-1 == 1 else 2)
             const bool last = (j - 2 == 0);

@@ -39,6 +39,8 @@ SIGNATURES = {
         [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _int, _vp],
     ),
     "dsw_spmm2_supported": (_int, [_vp, _i64, _int]),
+    "dsw_spmm_staged": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _f32, _int, _vp, _int]),
+    "dsw_spmm_staged_supported": (_int, [_vp, _i64, _int]),
     "dsw_cheb_basis_fwd": (_int, [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _int, _vp, _vp]),
     "dsw_cheb_basis_adj": (
         _int, [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _int, _vp, _vp, _vp]

@@ -72,34 +72,65 @@ class CsrOperator:
         return self.values.device
 
     def hop2_plan(self, row_bytes: int):
-        """Tile plan of the fused two-hop SpMM for rows of ``row_bytes`` bytes, or ``None`` when the
-        operator is not square / the tile neighbourhoods do not fit LDS (built once, cached)."""
+        """Tile plan of the LDS-staged recurrence kernels for rows of ``row_bytes`` bytes, or ``None`` when the operator
+        is not square / the tile neighbourhoods do not fit LDS (built once, cached).  Sparse stencils (HEALPix k = 8: 9
+        entries per row) get the plan of the fused TWO-hop kernel; dense ones (the reference's default k = 20 graph,
+        equiangular k = 20: 21+ entries) the plan of the staged ONE-hop kernel - there the first-hop redundancy of a fused
+        pair costs more than the round trip of the intermediate plane (``HOP_MODE`` overrides the choice for A/B runs)."""
         if self.shape[0] != self.shape[1] or row_bytes % 16 != 0 or not self.values.is_cuda:
             return None
-        if row_bytes not in self._plans:
+        key = (row_bytes, HOP_MODE, STAGED_TILE_ROWS)
+        if key not in self._plans:
             from . import hop2
 
             plan = None
             host_csr = []
 
-            def host_plan(rows, clustered=False):
-                key = (rows, clustered)
+            def host(i):
+                if not host_csr:
+                    host_csr.extend(t.cpu().numpy() for t in (self.rowptr, self.colind, self.values))
+                return host_csr[i]
+
+            def host_plan(rows, clustered=False, hops=2):
+                key = (rows, clustered, hops)
                 if key not in self._plans_by_rows:
-                    if not host_csr:
-                        host_csr.extend(t.cpu().numpy() for t in (self.rowptr, self.colind, self.values))
                     try:
                         tiles = None
-                        if clustered:
+                        lens = host(0)[1:] - host(0)[:-1]
+                        w = (int(lens.max()) + 3) & ~3 if lens.size else 4
+                        if clustered and hops == 2:
                             # neighbourhood caps = what two workgroups per CU can stage of 128-byte rows (one input
                             # buffer, ELL of the longest row): n1 * (128 + 6 w) + n2 * 128 <= 80 KiB at n2 ~ 1.8 n1
-                            lens = host_csr[0][1:] - host_csr[0][:-1]
-                            w = (int(lens.max()) + 3) & ~3 if lens.size else 4
                             cap1 = int((80 * 1024 - 2048) / (128 + 6 * w + 1.8 * 128))
-                            tiles = hop2.cluster_tiles(host_csr[0], host_csr[1], rows, max_n1=cap1, max_n2=int(1.8 * cap1))
-                        self._plans_by_rows[key] = hop2.build_hop2_plan(*host_csr, rows, tiles=tiles)
+                            tiles = hop2.cluster_tiles(host(0), host(1), rows, max_n1=cap1, max_n2=int(1.8 * cap1))
+                        elif clustered:
+                            # one hop: tile + 1-ring staged, ELL of the tile rows only
+                            cap1 = int((80 * 1024 - 2560 - rows * (6 * w + 4)) / 132)
+                            tiles = hop2.cluster_tiles(host(0), host(1), rows, max_n1=cap1)
+                        self._plans_by_rows[key] = hop2.build_hop2_plan(host(0), host(1), host(2), rows, tiles=tiles, hops=hops)
                     except ValueError:
                         self._plans_by_rows[key] = None
                 return self._plans_by_rows[key]
+
+            dense = self.nnz >= STAGED_MIN_ROW_LEN * self.shape[0]
+            if HOP_MODE == "staged" or (HOP_MODE == "auto" and dense):
+                # staged one-hop plan: the largest tile that leaves two workgroups on a CU; consecutive rows first
+                # (HEALPix nested order), else tiles clustered from the graph
+                for rows in STAGED_TILE_ROWS:
+                    if rows > self.shape[0]:
+                        continue
+                    cand = host_plan(rows, False, 1)
+                    if cand is not None and cand.lds_bytes(row_bytes) <= 80 * 1024 and cand.max_n2 * row_bytes <= 65535:
+                        plan = cand
+                        break
+                if plan is None:
+                    for rows in STAGED_TILE_ROWS:
+                        if self.shape[0] < MIN_CLUSTERED_TILES * rows:
+                            continue
+                        cand = host_plan(rows, True, 1)
+                        if cand is not None and cand.lds_bytes(row_bytes) <= 80 * 1024 and cand.max_n2 * row_bytes <= 65535:
+                            plan = cand
+                            break
 
             # largest tile whose workgroup still leaves room for >= 2 workgroups per CU (<= 80 KiB of
             # the 160 KiB LDS); a single resident workgroup (<= 156 KiB) is the last resort
@@ -108,6 +139,8 @@ class CsrOperator:
             # neighbourhoods are too large - row order that is not 2-D local: equiangular row-major, HEALPix ring
             # order - tiles clustered from the operator's graph.
             for budget, single in ((80 * 1024, False), (80 * 1024, True), (156 * 1024, False), (156 * 1024, True)):
+                if plan is not None:
+                    break
                 for rows in (256, 128, 64):
                     if rows > self.shape[0]:
                         continue
@@ -130,10 +163,8 @@ class CsrOperator:
                         cost = cand.gather_passes_per_row()
                         if best is None or cost < best:
                             best, plan = cost, cand
-                if plan is not None:
-                    break
-            self._plans[row_bytes] = None if plan is None else plan.to(self.device)
-        return self._plans[row_bytes]
+            self._plans[key] = None if plan is None else plan.to(self.device)
+        return self._plans[key]
 
     def transpose(self) -> "CsrOperator":
         """CSR of the transposed operator (built once, on first backward)."""
@@ -160,6 +191,9 @@ class CsrOperator:
         return self._t
 
 
+HOP_MODE = "auto"            # "auto" | "fused" | "staged": which staged recurrence kernel dense stencils take (A/B runs, tests)
+STAGED_TILE_ROWS = (128, 64) # tile heights the staged one-hop plan tries, in this order
+STAGED_MIN_ROW_LEN = 14.0    # average entries per row from which "auto" picks the staged one-hop kernel
 MIN_CLUSTERED_TILES = 8   # performance choice only (tests lower it to run the fused path on tiny graphs as well)
 
 _op_cache: dict = {}
@@ -283,7 +317,7 @@ class _HipBackend:
         B, V, C = x.shape
         T = torch.empty((max(K - 1, 0), B, V, C), dtype=x.dtype, device=x.device)
         if K > 1:
-            pp, _keep = _plan_ptr(op, x) if (K > 2 and _FWD_FUSED) else (None, None)
+            pp, _keep = _plan_ptr(op, x) if (K > 1 and _FWD_FUSED) else (None, None)
             with torch.cuda.device(x.device):
                 rc = lib.dsw_cheb_basis_fwd(
                     op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz,
@@ -302,7 +336,7 @@ class _HipBackend:
         # scratch only and need nothing but x for backward
         mix_first = bool(lib.dsw_cheb_mix_first(Fin, Fout, K))
         pp, _keep = (_plan_ptr(op, x, Fout if mix_first else Fin)
-                     if (K > 2 and (_FWD_FUSED or mix_first)) else (None, None))
+                     if (K > 1 and (_FWD_FUSED or mix_first)) else (None, None))
         csr = (None, None, None, V, 0) if op is None else (
             op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz)
         with torch.cuda.device(x.device):
@@ -330,7 +364,7 @@ class _HipBackend:
         mix_first = bool(lib.dsw_cheb_mix_first(Fin, Fout, K))
         need_hops = K > 1 and (need_dx or (mix_first and want_w))
         opt = op.transpose() if need_hops else op
-        pp, _keep = _plan_ptr(opt, x, Fout if mix_first else Fin) if (need_hops and K > 2) else (None, None)
+        pp, _keep = _plan_ptr(opt, x, Fout if mix_first else Fin) if (need_hops and K > 1) else (None, None)
         csr = (None, None, None, V, 0) if opt is None else (
             opt.rowptr.data_ptr(), opt.colind.data_ptr(), opt.values.data_ptr(), V, opt.nnz)
         with torch.cuda.device(x.device):
@@ -353,7 +387,7 @@ class _HipBackend:
         T = torch.empty((K - 1, B, V, Fin), dtype=x.dtype, device=x.device) if K > 1 else None
         mix_first = bool(lib.dsw_cheb_mix_first(Fin, Fout, K))
         pp, _keep = (_plan_ptr(op, x, Fout if mix_first else Fin)
-                     if (K > 2 and (_FWD_FUSED or mix_first)) else (None, None))
+                     if (K > 1 and (_FWD_FUSED or mix_first)) else (None, None))
         csr = (None, None, None, V, 0) if op is None else (
             op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz)
         with torch.cuda.device(x.device):
@@ -386,7 +420,7 @@ class _HipBackend:
         mix_first = bool(lib.dsw_cheb_mix_first(Fin, Fout, K))
         need_hops = K > 1 and (need_dx or (mix_first and need_dw))
         opt = op.transpose() if need_hops else op
-        pp, _keep = _plan_ptr(opt, x, Fout if mix_first else Fin) if (need_hops and K > 2) else (None, None)
+        pp, _keep = _plan_ptr(opt, x, Fout if mix_first else Fin) if (need_hops and K > 1) else (None, None)
         csr = (None, None, None, V, 0) if opt is None else (
             opt.rowptr.data_ptr(), opt.colind.data_ptr(), opt.values.data_ptr(), V, opt.nnz)
         with torch.cuda.device(x.device):

@@ -42,12 +42,14 @@ class Hop2PlanStruct(ctypes.Structure):
         ("lcol", ctypes.c_void_p),        # uint16, concatenated
         ("lval", ctypes.c_void_p),        # float32, concatenated
         ("explicit_tiles", ctypes.c_int32),   # 1: tile rows = the first tile_meta[t][5] entries of the gather list
+        ("hops", ctypes.c_int32),             # 2: fused two-hop kernel; 1: staged one-hop kernel (csrc/dsw_spmm1s.hip)
     ]
 
 
 class Hop2Plan:
     def __init__(self, tile_rows, tile_meta, s2_rows, lrowptr, lcol, lval, max_n1, max_n2, max_nnz, n_rows,
-                 max_row_len=0, explicit_tiles=False):
+                 max_row_len=0, explicit_tiles=False, hops=2):
+        self.hops = int(hops)
         self.max_row_len = int(max_row_len)
         self.explicit_tiles = bool(explicit_tiles)
         self.tile_rows = int(tile_rows)
@@ -66,6 +68,9 @@ class Hop2Plan:
         """LDS the kernel carves (must match hop2_lds_bytes in csrc/dsw_spmm2.hip): the input rows on
         S2 (two buffers unless ``single_buf``), the first-hop rows on S1, {col, val} pairs, the gather list."""
         ell_w = (self.max_row_len + 3) & ~3
+        if self.hops == 1:      # hop1_lds_bytes in csrc/dsw_spmm1s.hip: staged rows, ELL of the tile rows, list, row pointers
+            s = self.max_n2 * row_bytes + self.max_n1 * ell_w * 6 + ((self.max_n2 + 3) & ~3) * 4 + 16 + (self.max_n1 + 1) * 4
+            return (s + 15) & ~15
         s = (self.max_n1 + (1 if single_buf else 2) * self.max_n2) * row_bytes   # bufT + input rows
         s += self.max_n1 * ell_w * 6                      # ELL: fp32 values + u16 list positions
         s += ((self.max_n2 + 3) & ~3) * 4 + 16            # gather list + the tile's loop length
@@ -77,6 +82,8 @@ class Hop2Plan:
         n1 = self.tile_meta[:, 1].astype(np.int64)
         rt = self.tile_meta[:, 5].astype(np.int64) if self.explicit_tiles else \
             np.minimum(self.tile_rows, self.n_rows - np.arange(self.n_tiles) * self.tile_rows)
+        if self.hops == 1:
+            return float((-(-rt // slots)).sum()) / float(rt.sum())
         return float((-(-n1 // slots) + -(-rt // slots)).sum()) / float(rt.sum())
 
     def to(self, device):
@@ -91,7 +98,7 @@ class Hop2Plan:
         st = Hop2PlanStruct(
             self.n_tiles, self.tile_rows, self.max_n1, self.max_n2, self.max_nnz, self.max_row_len,
             arrs["tile_meta"].data_ptr(), arrs["s2_rows"].data_ptr(), arrs["lrowptr"].data_ptr(),
-            arrs["lcol"].data_ptr(), arrs["lval"].data_ptr(), 1 if self.explicit_tiles else 0,
+            arrs["lcol"].data_ptr(), arrs["lval"].data_ptr(), 1 if self.explicit_tiles else 0, self.hops,
         )
         self._dev = (device, arrs)   # keeps the device tensors alive
         self._struct = st
@@ -188,9 +195,14 @@ def cluster_tiles(rowptr: np.ndarray, colind: np.ndarray, tile_rows: int, max_n1
     return tiles
 
 
-def build_hop2_plan(rowptr: np.ndarray, colind: np.ndarray, values: np.ndarray, tile_rows: int, tiles=None) -> Hop2Plan:
+def build_hop2_plan(rowptr: np.ndarray, colind: np.ndarray, values: np.ndarray, tile_rows: int, tiles=None,
+                    hops: int = 2) -> Hop2Plan:
     """Plan for a square CSR operator (int32 rowptr/colind, fp32 values) and a tile size.  ``tiles``: explicit row sets
-    (a partition of the rows, each of <= ``tile_rows`` rows, e.g. from ``cluster_tiles``); default: consecutive rows."""
+    (a partition of the rows, each of <= ``tile_rows`` rows, e.g. from ``cluster_tiles``); default: consecutive rows.
+    ``hops = 1``: plan of the staged ONE-hop kernel - the local CSR covers the tile rows only (``n1`` = tile rows) and
+    the gather list ends with their 1-ring."""
+    if hops not in (1, 2):
+        raise ValueError("hops must be 1 or 2")
     rowptr = np.asarray(rowptr, dtype=np.int64)
     colind = np.asarray(colind, dtype=np.int64)
     values = np.asarray(values, dtype=np.float32)
@@ -222,7 +234,7 @@ def build_hop2_plan(rowptr: np.ndarray, colind: np.ndarray, values: np.ndarray, 
             tile = np.arange(r0, r1)
             c1 = np.unique(colind[rowptr[r0]:rowptr[r1]])
             halo1 = c1[(c1 < r0) | (c1 >= r1)]
-        s1 = np.concatenate([tile, halo1])
+        s1 = tile if hops == 1 else np.concatenate([tile, halo1])
         # columns referenced by the S1 rows
         starts, ends = rowptr[s1], rowptr[s1 + 1]
         lens = ends - starts
@@ -251,7 +263,7 @@ def build_hop2_plan(rowptr: np.ndarray, colind: np.ndarray, values: np.ndarray, 
         max_len = max(max_len, int(lens.max()) if lens.size else 0)
     return Hop2Plan(
         tile_rows, meta, np.concatenate(s2_chunks), np.concatenate(rp_chunks), np.concatenate(col_chunks),
-        np.concatenate(val_chunks), max_n1, max_n2, max_nnz, n, max_len, explicit_tiles=explicit,
+        np.concatenate(val_chunks), max_n1, max_n2, max_nnz, n, max_len, explicit_tiles=explicit, hops=hops,
     )
 
 
@@ -274,6 +286,29 @@ def _bank_friendly_order(lcol: np.ndarray, lens: np.ndarray) -> np.ndarray:
     rank[o] = np.arange(ks.size) - np.searchsorted(ks, ks, side="left")
     slot = 2 * rank + (~first)
     return np.lexsort((slot, rid))
+
+
+def emulate_hop1(plan: Hop2Plan, U, Z, Z2, a, b, c):
+    """numpy restatement of one staged single-hop launch (``hops = 1`` plans): ``Y = a * L U + b * Z + c * Z2``."""
+    assert plan.hops == 1
+    V, C = U.shape
+    y = np.zeros((V, C))
+    for t in range(plan.n_tiles):
+        s2_off, rt, n2, nnz_off, rp_off, _ = (int(v) for v in plan.tile_meta[t])
+        rows = plan.s2_rows[s2_off:s2_off + n2].astype(np.int64)
+        lrp = plan.lrowptr[rp_off:rp_off + rt + 1].astype(np.int64)
+        lcol = plan.lcol[nnz_off:nnz_off + lrp[-1]].astype(np.int64)
+        lval = plan.lval[nnz_off:nnz_off + lrp[-1]].astype(np.float64)
+        bufx = U[rows]
+        for i in range(rt):
+            sl = slice(lrp[i], lrp[i + 1])
+            acc = a * (lval[sl, None] * bufx[lcol[sl]]).sum(0)
+            if Z is not None:
+                acc = acc + b * Z[rows[i]]
+            if Z2 is not None:
+                acc = acc + c * Z2[rows[i]]
+            y[rows[i]] = acc
+    return y
 
 
 def emulate_hop2(plan: Hop2Plan, U, Z1, Z1b, Z2, a1, b1, d1, a2, b2, c2):

@@ -58,6 +58,8 @@ typedef struct dsw_hop2_plan {
     const uint16_t* lcol;      /* concatenated local column positions */
     const float* lval;         /* concatenated values */
     int32_t explicit_tiles;
+    int32_t hops;              /* 2 (or 0): plan of the fused two-hop kernel; 1: plan of the staged ONE-hop kernel - the
+                                  gather list ends with the 1-ring, local CSR of the tile rows only (n1 = tile rows) */
 } dsw_hop2_plan;
 
 /* Library version (major*10000 + minor*100 + patch). */
@@ -102,9 +104,21 @@ int dsw_spmm2_fused(const dsw_hop2_plan* plan, int64_t V, const void* U, const v
 /* 1 if the fused two-hop kernel can take this plan and row size (LDS capacity, 16-byte lanes). */
 int dsw_spmm2_supported(const dsw_hop2_plan* plan, int64_t C, int dtype);
 
+/* One application of a square operator with the tile's neighbourhood staged in LDS (plan->hops == 1), per sample:
+ *     Y = a * (A U) + b * Z + c * Z2
+ * U, Z, Z2, Y: [B, V, C]; Z / Z2 may be NULL; Y may alias Z or Z2 (a tile reads them on its own rows only), not U.
+ * The form the recurrences take on DENSE stencils (the reference's default k = 20 graph, utils_config.py:50: 21-23
+ * entries per row), where the first-hop redundancy of the fused pair costs more than the round trip of the
+ * intermediate plane it saves.  stream_out = 1: nontemporal stores (nothing gathers Y next).
+ * Returns DSW_ERR_BAD_ARG if dsw_spmm_staged_supported() is 0. */
+int dsw_spmm_staged(const dsw_hop2_plan* plan, int64_t V, const void* U, const void* Z, const void* Z2, void* Y,
+                    int64_t B, int64_t C, float a, float b, float c, int dtype, dsw_stream_t stream, int stream_out);
+int dsw_spmm_staged_supported(const dsw_hop2_plan* plan, int64_t C, int dtype);
+
 /* Chebyshev basis T_1 .. T_{K-1} of X (T_0 = X is not copied):
  *     T_1 = L X,  T_k = 2 L T_{k-1} - T_{k-2}        (layers.py:163-169)
- * T: [K-1, B, V, C].  K <= 1 is a no-op.  With a (supported) plan of L, hops run pairwise fused. */
+ * T: [K-1, B, V, C].  K <= 1 is a no-op.  With a (supported) plan of L, hops run pairwise fused (plan->hops == 2) or one
+ * staged launch per hop (plan->hops == 1). */
 int dsw_cheb_basis_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals,
                        int64_t V, int64_t nnz, const void* X, void* T,
                        int64_t B, int64_t C, int64_t K, int dtype, dsw_stream_t stream,

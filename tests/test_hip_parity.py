@@ -461,6 +461,92 @@ def test_spmm2_fused_vs_formula(opname, C, B, dt):
     assert orc.max_rel_err(Z2c.float(), ref) <= tol
 
 
+@pytest.mark.parametrize("opname,C,B,dt", [("nest20", 32, 3, torch.float32), ("ring20", 8, 2, torch.float32),
+                                            ("irregular", 12, 2, torch.float32), ("nest20", 64, 2, torch.bfloat16),
+                                            ("nest20", 128, 2, torch.float32), ("nest8", 32, 1, torch.float32)])
+def test_spmm_staged_vs_formula(opname, C, B, dt, monkeypatch):
+    """The staged one-hop kernel (dsw_spmm_staged: dense stencils) against Y = a A U + b Z + c Z2 in fp64, incl. NULL
+    optionals, the in-place forms of the adjoint step (Y aliases Z) and wide rows (128-byte channel chunks)."""
+    import ctypes
+    from dsw_amd import functional as F_, _native, sphere
+
+    monkeypatch.setattr(F_, "HOP_MODE", "staged")
+    monkeypatch.setattr(F_, "MIN_CLUSTERED_TILES", 1)
+    if opname == "irregular":
+        rp, ci, va = recipes.irregular_operator(300, seed=8, min_deg=0, max_deg=30)
+    else:
+        m = sphere.SphereHealpix(8, nest=opname.startswith("nest"), k=int(opname[4:])).L
+        rp, ci, va = m.indptr, m.indices, m.data.astype(np.float32)
+    V = len(rp) - 1
+    op = F_.CsrOperator.from_sparse_coo(orc.coo_from_csr_arrays(rp, ci, va, (V, V)).to(DEV))
+    es = 2 if dt == torch.bfloat16 else 4
+    plan = op.hop2_plan(min(C * es, 128))
+    assert plan is not None and plan.hops == 1
+    lib = _native.load()
+    code = 1 if dt == torch.bfloat16 else 0
+    pa = ctypes.addressof(plan._struct)
+    assert lib.dsw_spmm_staged_supported(pa, C, code) == 1 and lib.dsw_spmm2_supported(pa, C, code) == 0
+    mk = lambda s: torch.from_numpy(recipes.rand(s, (B, V, C))).to(dt).to(DEV)
+    U, Z, Z2 = mk(1), mk(2), mk(3)
+    Y = torch.empty_like(U)
+    st = torch.cuda.current_stream().cuda_stream
+    f = lambda t: t.float().cpu().numpy().astype(np.float64)
+    tol = TOL_BF16 if dt == torch.bfloat16 else TOL_F64
+    AU = orc.remap_f64(rp, ci, va, (V, V), f(U))
+    for so in (0, 1):
+        assert lib.dsw_spmm_staged(pa, V, U.data_ptr(), Z.data_ptr(), Z2.data_ptr(), Y.data_ptr(), B, C, 2.0, -1.0, 0.5, code, st, so) == 0
+        assert orc.max_rel_err(Y.float(), 2.0 * AU - f(Z) + 0.5 * f(Z2)) <= tol
+    assert lib.dsw_spmm_staged(pa, V, U.data_ptr(), None, None, Y.data_ptr(), B, C, 1.0, 0.0, 0.0, code, st, 0) == 0
+    assert orc.max_rel_err(Y.float(), AU) <= tol
+    Zc = Z.clone()     # adjoint step, in place on the Z plane
+    assert lib.dsw_spmm_staged(pa, V, U.data_ptr(), Zc.data_ptr(), Z2.data_ptr(), Zc.data_ptr(), B, C, 2.0, 1.0, -1.0, code, st, 0) == 0
+    assert orc.max_rel_err(Zc.float(), 2.0 * AU + f(Z) - f(Z2)) <= tol
+    Zc = Z.clone()     # only the second epilogue operand
+    assert lib.dsw_spmm_staged(pa, V, U.data_ptr(), None, Zc.data_ptr(), Zc.data_ptr(), B, C, 1.0, 0.0, -1.0, code, st, 0) == 0
+    assert orc.max_rel_err(Zc.float(), AU - f(Z)) <= tol
+    assert lib.dsw_spmm_staged(pa, V, U.data_ptr(), None, None, Y.data_ptr(), 0, C, 1.0, 0.0, 0.0, code, st, 0) == 0   # empty batch
+    assert lib.dsw_spmm2_fused(pa, V, U.data_ptr(), None, None, None, None, Y.data_ptr(), B, C, 1.0, 0.0, 0.0, 2.0, -1.0, 0.0,
+                               code, st) != 0      # a one-hop plan is not a two-hop plan
+
+
+@pytest.mark.parametrize("K", [2, 3, 4, 5])
+def test_staged_recurrences_equal_unfused(K, monkeypatch):
+    """Forward basis and adjoint recurrence on a dense (k = 20) non-symmetric operator: one staged launch per hop vs the
+    plain one-hop kernel, and the forward basis against the fp64 oracle."""
+    from dsw_amd import functional as F_, _native, sphere
+
+    monkeypatch.setattr(F_, "HOP_MODE", "auto")
+    m = sphere.SphereHealpix(8, nest=True, k=20).L
+    rp, ci, va = m.indptr, m.indices, (m.data * 0.7).astype(np.float32)
+    va = (va * np.repeat(0.5 + np.random.default_rng(1).random(768), np.diff(rp))).astype(np.float32)
+    op = F_.CsrOperator.from_sparse_coo(orc.coo_from_csr_arrays(rp, ci, va, (768, 768)).to(DEV))
+    opt = op.transpose()
+    B, V, C = 3, 768, 32
+    lib = _native.load()
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.from_numpy(recipes.rand(5, (B, V, C))).to(DEV)
+    res = {}
+    for staged in (False, True):
+        pp, keep = F_._plan_ptr(op, x) if staged else (None, None)
+        ppt, keept = F_._plan_ptr(opt, x) if staged else (None, None)
+        assert (pp is not None) == staged and (not staged or (keep.hops == 1 and keept.hops == 1))
+        T = torch.empty(K - 1, B, V, C, device=DEV)
+        assert lib.dsw_cheb_basis_fwd(op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz,
+                                      x.data_ptr(), T.data_ptr(), B, C, K, 0, st, pp) == 0
+        G0 = torch.from_numpy(recipes.rand(6, (B, V, C))).to(DEV)
+        Gr = torch.from_numpy(recipes.rand(7, (K - 1, B, V, C))).to(DEV)
+        spare = torch.empty(2, B, V, C, device=DEV)
+        assert lib.dsw_cheb_basis_adj(opt.rowptr.data_ptr(), opt.colind.data_ptr(), opt.values.data_ptr(), V, opt.nnz,
+                                      G0.data_ptr(), Gr.data_ptr(), B, C, K, 0, st, ppt, spare.data_ptr()) == 0
+        torch.cuda.synchronize()
+        res[staged] = (T.clone(), G0.clone())
+    assert orc.max_rel_err(res[True][0], res[False][0].double()) <= TOL_F64
+    assert orc.max_rel_err(res[True][1], res[False][1].double()) <= TOL_F64
+    L = orc._csr64(rp, ci, va, (V, V))
+    Tref = np.stack(orc.cheb_basis_f64(L, x.cpu().numpy(), K)[1:])
+    assert orc.max_rel_err(res[True][0], Tref) <= TOL_F64
+
+
 @pytest.mark.parametrize("K", [3, 4, 5, 6])
 def test_fused_recurrences_equal_unfused(K):
     """Forward basis and adjoint recurrence: pairwise-fused launches vs one launch per hop."""

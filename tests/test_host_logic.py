@@ -311,6 +311,33 @@ def test_hop2_plan_matches_two_plain_hops():
         hop2.build_hop2_plan(rp, ci, va, 64, tiles=[np.arange(10)])     # not a partition of the rows
 
 
+def test_hop1_plan_matches_one_plain_hop():
+    """Plans of the staged ONE-hop kernel (dense stencils): local CSR of the tile rows only, gather list = tile + 1-ring;
+    emulated in numpy they equal one operator application with its axpby epilogue - consecutive and clustered tiles."""
+    from dsw_amd import hop2, sphere
+
+    ops = {"nest_k20": sphere.SphereHealpix(4, nest=True, k=20).L, "ring_k20": sphere.SphereHealpix(4, nest=False, k=20).L}
+    ops = {k: (m.indptr, m.indices, m.data.astype(np.float32)) for k, m in ops.items()}
+    ops["irregular"] = recipes.irregular_operator(300, seed=5, min_deg=0, max_deg=40)
+    rng = np.random.default_rng(1)
+    for name, (rp, ci, va) in ops.items():
+        n = len(rp) - 1
+        L = sparse.csr_matrix((np.asarray(va, dtype=np.float64), ci, rp), shape=(n, n))
+        for rows, clustered in ((128, False), (64, False), (64, True)):
+            tiles = hop2.cluster_tiles(rp, ci, rows, max_n1=150) if clustered else None
+            plan = hop2.build_hop2_plan(rp, ci, va, rows, tiles=tiles, hops=1)
+            assert plan.hops == 1 and plan.max_n1 <= rows and plan.lds_bytes(128) > 0
+            assert (plan.tile_meta[:, 1] <= rows).all() and (plan.tile_meta[:, 2] >= plan.tile_meta[:, 1]).all()
+            if clustered:
+                assert (plan.tile_meta[:, 2] <= 150).all()
+            U, Z, Z2 = (rng.standard_normal((n, 3)) for _ in range(3))
+            y = hop2.emulate_hop1(plan, U, Z, Z2, 2.0, -1.0, 0.5)
+            np.testing.assert_allclose(y, 2.0 * (L @ U) - Z + 0.5 * Z2, atol=1e-12)
+            np.testing.assert_allclose(hop2.emulate_hop1(plan, U, None, None, 1.0, 0.0, 0.0), L @ U, atol=1e-12)
+    with pytest.raises(ValueError):
+        hop2.build_hop2_plan(rp, ci, va, 64, hops=3)
+
+
 def test_clustered_tiles_make_non_local_row_orders_compact():
     """HEALPix RING order and equiangular row-major order: a strip of 64 consecutive rows has a 2-ring several times the
     tile; the graph clustering brings it down to what a square patch has, so the operator takes the fused two-hop path."""
