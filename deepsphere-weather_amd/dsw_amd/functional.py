@@ -192,7 +192,7 @@ class CsrOperator:
 
 
 HOP_MODE = "auto"            # "auto" | "fused" | "staged": which staged recurrence kernel dense stencils take (A/B runs, tests)
-STAGED_TILE_ROWS = (128, 64) # tile heights the staged one-hop plan tries, in this order
+STAGED_TILE_ROWS = (64, 128) # tile heights the staged one-hop plan tries, in this order (64: one row per lane group)
 STAGED_MIN_ROW_LEN = 14.0    # average entries per row from which "auto" picks the staged one-hop kernel
 MIN_CLUSTERED_TILES = 8   # performance choice only (tests lower it to run the fused path on tiny graphs as well)
 

@@ -43,6 +43,9 @@ class Hop2PlanStruct(ctypes.Structure):
         ("lval", ctypes.c_void_p),        # float32, concatenated
         ("explicit_tiles", ctypes.c_int32),   # 1: tile rows = the first tile_meta[t][5] entries of the gather list
         ("hops", ctypes.c_int32),             # 2: fused two-hop kernel; 1: staged one-hop kernel (csrc/dsw_spmm1s.hip)
+        ("ell_w", ctypes.c_int32),            # > 0: the tile rows' stencils also as padded ELL (64 rows x ell_w per tile)
+        ("ell_pos", ctypes.c_void_p),         # uint16 [n_tiles][64][ell_w]: list positions (padding: the row itself)
+        ("ell_val", ctypes.c_void_p),         # float32 [n_tiles][64][ell_w] (padding: 0)
     ]
 
 
@@ -50,6 +53,8 @@ class Hop2Plan:
     def __init__(self, tile_rows, tile_meta, s2_rows, lrowptr, lcol, lval, max_n1, max_n2, max_nnz, n_rows,
                  max_row_len=0, explicit_tiles=False, hops=2):
         self.hops = int(hops)
+        self.ell_w = 0
+        self.ell_pos = self.ell_val = None
         self.max_row_len = int(max_row_len)
         self.explicit_tiles = bool(explicit_tiles)
         self.tile_rows = int(tile_rows)
@@ -68,19 +73,50 @@ class Hop2Plan:
         """LDS the kernel carves (must match hop2_lds_bytes in csrc/dsw_spmm2.hip): the input rows on
         S2 (two buffers unless ``single_buf``), the first-hop rows on S1, {col, val} pairs, the gather list."""
         ell_w = (self.max_row_len + 3) & ~3
-        if self.hops == 1:      # hop1_lds_bytes in csrc/dsw_spmm1s.hip: staged rows, ELL of the tile rows, list, row pointers
-            s = self.max_n2 * row_bytes + self.max_n1 * ell_w * 6 + ((self.max_n2 + 3) & ~3) * 4 + 16 + (self.max_n1 + 1) * 4
-            return (s + 15) & ~15
+        if self.hops == 1:      # hop1_lds_bytes / hop1_dma_lds_bytes in csrc/dsw_spmm1s.hip
+            scratch = self.max_n1 * ell_w * 6 + ((self.max_n2 + 3) & ~3) * 4 + 16 + (self.max_n1 + 1) * 4
+            buf = self.max_n2 * row_bytes
+            dma = self.ell_w > 0 and self.tile_rows * row_bytes <= 512 * 16 and (row_bytes // 16) & (row_bytes // 16 - 1) == 0 \
+                and self.max_n2 * row_bytes <= 3 * 512 * 16
+            # LDS-DMA form: ring of three buffers of staged rows + two 8 KiB buffers of epilogue rows (stencils from the ELL image);
+            # generic form: one buffer + the scratch
+            return ((3 * buf + 2 * 512 * 16 if dma else buf + scratch) + 15) & ~15
         s = (self.max_n1 + (1 if single_buf else 2) * self.max_n2) * row_bytes   # bufT + input rows
         s += self.max_n1 * ell_w * 6                      # ELL: fp32 values + u16 list positions
         s += ((self.max_n2 + 3) & ~3) * 4 + 16            # gather list + the tile's loop length
         return (s + 15) & ~15
 
+    ELL_ROWS, ELL_W = 64, 24   # shape the LDS-DMA kernel keeps in registers: one row per lane group, 24 entries
+
+    def add_ell(self):
+        """Padded ELL image of the tile rows' stencils (hops = 1 plans with <= 64 rows per tile and <= 24 entries per
+        row): what the LDS-DMA kernel loads straight into registers - 9 independent 16-byte loads per lane instead of a
+        CSR -> ELL expansion through LDS with two workgroup barriers in every workgroup's prologue.  tile_meta[t][5]
+        becomes the tile's longest row (the kernel's gather length; explicit tiles keep their row count in [1])."""
+        if self.hops != 1 or self.tile_rows > self.ELL_ROWS or self.max_row_len > self.ELL_W or self.max_n1 > self.ELL_ROWS:
+            return self
+        R, W = self.ELL_ROWS, self.ELL_W
+        pos = np.zeros((self.n_tiles, R, W), dtype=np.uint16)
+        pos[:] = np.arange(R, dtype=np.uint16)[None, :, None]          # padding: the row itself, weight 0
+        val = np.zeros((self.n_tiles, R, W), dtype=np.float32)
+        meta = self.tile_meta.copy()
+        for t in range(self.n_tiles):
+            s2_off, rt, n2, nnz_off, rp_off, _ = (int(v) for v in self.tile_meta[t])
+            lrp = self.lrowptr[rp_off:rp_off + rt + 1].astype(np.int64)
+            lens = np.diff(lrp)
+            rid = np.repeat(np.arange(rt), lens)
+            col = np.arange(int(lrp[-1])) - np.repeat(lrp[:-1], lens)
+            pos[t, rid, col] = self.lcol[nnz_off:nnz_off + lrp[-1]]
+            val[t, rid, col] = self.lval[nnz_off:nnz_off + lrp[-1]]
+            meta[t, 5] = int(lens.max()) if lens.size else 0
+        self.tile_meta, self.ell_pos, self.ell_val, self.ell_w = meta, pos.reshape(-1), val.reshape(-1), W
+        return self
+
     def gather_passes_per_row(self, slots: int = 64) -> float:
         """Passes of ``slots`` row slots the kernel spends per output row (first hop on tile + 1-ring, second hop on the
         tile) - the cost figure tile heights are compared by."""
         n1 = self.tile_meta[:, 1].astype(np.int64)
-        rt = self.tile_meta[:, 5].astype(np.int64) if self.explicit_tiles else \
+        rt = self.tile_meta[:, 1].astype(np.int64) if self.hops == 1 else self.tile_meta[:, 5].astype(np.int64) if self.explicit_tiles else \
             np.minimum(self.tile_rows, self.n_rows - np.arange(self.n_tiles) * self.tile_rows)
         if self.hops == 1:
             return float((-(-rt // slots)).sum()) / float(rt.sum())
@@ -91,7 +127,7 @@ class Hop2Plan:
         if self._dev is not None and self._dev[0] == device:
             return self
         arrs = {}
-        for name in ("tile_meta", "s2_rows", "lrowptr", "lcol", "lval"):
+        for name in ("tile_meta", "s2_rows", "lrowptr", "lcol", "lval") + (("ell_pos", "ell_val") if self.ell_w else ()):
             a = getattr(self, name)
             t = torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a)
             arrs[name] = t.to(device)
@@ -99,6 +135,7 @@ class Hop2Plan:
             self.n_tiles, self.tile_rows, self.max_n1, self.max_n2, self.max_nnz, self.max_row_len,
             arrs["tile_meta"].data_ptr(), arrs["s2_rows"].data_ptr(), arrs["lrowptr"].data_ptr(),
             arrs["lcol"].data_ptr(), arrs["lval"].data_ptr(), 1 if self.explicit_tiles else 0, self.hops,
+            self.ell_w, arrs["ell_pos"].data_ptr() if self.ell_w else None, arrs["ell_val"].data_ptr() if self.ell_w else None,
         )
         self._dev = (device, arrs)   # keeps the device tensors alive
         self._struct = st
@@ -264,7 +301,7 @@ def build_hop2_plan(rowptr: np.ndarray, colind: np.ndarray, values: np.ndarray, 
     return Hop2Plan(
         tile_rows, meta, np.concatenate(s2_chunks), np.concatenate(rp_chunks), np.concatenate(col_chunks),
         np.concatenate(val_chunks), max_n1, max_n2, max_nnz, n, max_len, explicit_tiles=explicit, hops=hops,
-    )
+    ).add_ell()
 
 
 def _bank_friendly_order(lcol: np.ndarray, lens: np.ndarray) -> np.ndarray:

@@ -60,6 +60,11 @@ typedef struct dsw_hop2_plan {
     int32_t explicit_tiles;
     int32_t hops;              /* 2 (or 0): plan of the fused two-hop kernel; 1: plan of the staged ONE-hop kernel - the
                                   gather list ends with the 1-ring, local CSR of the tile rows only (n1 = tile rows) */
+    int32_t ell_w;             /* > 0 (hops == 1, <= 64 rows per tile, <= ell_w entries per row): the tile rows' stencils
+                                  ALSO as a padded ELL image, 64 rows x ell_w entries per tile, and tile_meta[t][5] = the
+                                  tile's longest row */
+    const uint16_t* ell_pos;   /* [n_tiles][64][ell_w] list positions (padding: the row's own position) */
+    const float* ell_val;      /* [n_tiles][64][ell_w] values (padding: 0) */
 } dsw_hop2_plan;
 
 /* Library version (major*10000 + minor*100 + patch). */

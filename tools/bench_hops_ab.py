@@ -36,7 +36,7 @@ for knn in knns:
     T = torch.empty(2, B, V, C, device="cuda")
     G0 = torch.randn_like(x); Gr = torch.randn(2, B, V, C, device="cuda"); spare = torch.empty(2, B, V, C, device="cuda")
     E = B * V * C * 4
-    for mode, tiles in (("fused", (128, 64)), ("staged", (128, 64)), ("staged", (64,)), ("staged", (256, 128))):
+    for mode, tiles in (("fused", (64,)), ("staged", (64,)), ("staged", (128,))):
         F_.HOP_MODE, F_.STAGED_TILE_ROWS = mode, tiles
         op = F_.get_operator(lap); opt = op.transpose()
         Lb = op.nnz * 8 + 4 * (V + 1)

@@ -12,6 +12,10 @@ from modules.layers import prepare_torch_laplacian
 quads, knn = int(sys.argv[1]), int(sys.argv[2])
 which = sys.argv[3] if len(sys.argv) > 3 else "fwd"
 nside, C, B = (int(v) for v in sys.argv[4:7]) if len(sys.argv) > 6 else (64, 32, 16)
+if os.environ.get("HOP_MODE"):          # tool-side A/B switch: "fused" | "staged" | "auto"
+    F_.HOP_MODE = os.environ["HOP_MODE"]
+if os.environ.get("TILES"):
+    F_.STAGED_TILE_ROWS = tuple(int(v) for v in os.environ["TILES"].split(","))
 lib = _native.load()
 g = sphere.SphereHealpix(nside, nest=True, k=knn)
 op = F_.get_operator(prepare_torch_laplacian(g.L, lmax=1.95).to("cuda"))
