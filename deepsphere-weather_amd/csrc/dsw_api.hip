@@ -24,6 +24,7 @@ int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* 
                        int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int relu = 0,
                        const DswEpiExtra* extra = nullptr);
 int dsw_relu_inplace_launch(void* y, int64_t n, int dtype, hipStream_t s);
+int dsw_fold_w_launch(const void* W, void* Wf, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t s);
 int dsw_mix_dgrad_launch(const void* dY, const void* W, void* G0, void* Grest, int64_t N, int64_t Fin,
                          int64_t Fout, int64_t K, int dtype, hipStream_t stream, const DswEpiExtra* extra = nullptr);
 void dsw_wgrad_set_accumulate(int on);
@@ -167,9 +168,11 @@ int dsw_cheb_basis_fwd(const int32_t* rowptr, const int32_t* colind, const float
     return rc;
 }
 
-int dsw_cheb_basis_adj(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t, int64_t V,
-                       int64_t nnz, void* G0, void* Grest, int64_t B, int64_t C, int64_t K, int dtype,
-                       dsw_stream_t stream, const dsw_hop2_plan* plan_t, void* spare) {
+// folded != 0: the caller produced plane K-3 as G_{K-3} - G_{K-1} (dsw_fold_w_launch), so the step that computes
+// G'_{K-3} does not subtract plane K-1 again
+static int cheb_basis_adj_impl(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t, int64_t V,
+                               int64_t nnz, void* G0, void* Grest, int64_t B, int64_t C, int64_t K, int dtype,
+                               dsw_stream_t stream, const dsw_hop2_plan* plan_t, void* spare, int folded) {
     if (K <= 1) return K == 1 ? DSW_OK : DSW_ERR_BAD_ARG;
     if (V < 0 || B < 0 || C < 0 || nnz < 0) return DSW_ERR_BAD_ARG;
     if (V == 0 || B == 0 || C == 0) return DSW_OK;
@@ -192,8 +195,8 @@ int dsw_cheb_basis_adj(const int32_t* rowptr_t, const int32_t* colind_t, const f
         if (staged) {
             // single step on staged neighbourhoods: G'_{j-1} = c_j L^T G'_j + G_{j-1} - G'_{j+1}, in place on plane j-1
             char* gm1 = own(j - 1);
-            rc = dsw_spmm1s_launch(plan_t, V, loc_j, gm1, loc_jp1, gm1, B, C, (j == 1) ? 1.f : 2.f, 1.f, -1.f, dtype, s,
-                                   j > 1 ? 0 : 1);
+            rc = dsw_spmm1s_launch(plan_t, V, loc_j, gm1, (folded && j == K - 2) ? nullptr : loc_jp1, gm1, B, C,
+                                   (j == 1) ? 1.f : 2.f, 1.f, -1.f, dtype, s, j > 1 ? 0 : 1);
             loc_jp1 = loc_j;
             loc_j = gm1;
             j -= 1;
@@ -206,7 +209,7 @@ int dsw_cheb_basis_adj(const int32_t* rowptr_t, const int32_t* colind_t, const f
             char* y1 = last ? nullptr : static_cast<char*>(spare) + (size_t)spare_sel * plane;
             char* y2 = own(j - 2);   // in place: Z2 = G_{j-2} is read on the writer's own rows only
             rc = dsw_spmm2_launch(plan_t, V, loc_j, own(j - 1), loc_jp1, own(j - 2), y1, y2, B, C, 2.f, 1.f, -1.f,
-                                  (j - 1 == 1) ? 1.f : 2.f, -1.f, 1.f, dtype, s);
+                                  (j - 1 == 1) ? 1.f : 2.f, (folded && j == K - 1) ? 0.f : -1.f, 1.f, dtype, s);
             loc_jp1 = y1;
             loc_j = y2;
             spare_sel ^= 1;
@@ -215,13 +218,19 @@ int dsw_cheb_basis_adj(const int32_t* rowptr_t, const int32_t* colind_t, const f
             // single step: G'_{j-1} = c_j L^T G'_j + G_{j-1} - G'_{j+1}, in place on plane j-1
             char* gm1 = own(j - 1);
             rc = dsw_spmm_launch(rowptr_t, colind_t, vals_t, V, V, loc_j, gm1, B, C, (j == 1) ? 1.f : 2.f, gm1, 1.f,
-                                 loc_jp1, -1.f, dtype, s, DSW_SPMM_HINT_COLD_Z);
+                                 (folded && j == K - 2) ? nullptr : loc_jp1, -1.f, dtype, s, DSW_SPMM_HINT_COLD_Z);
             loc_jp1 = loc_j;
             loc_j = gm1;
             j -= 1;
         }
     }
     return rc;
+}
+
+int dsw_cheb_basis_adj(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t, int64_t V,
+                       int64_t nnz, void* G0, void* Grest, int64_t B, int64_t C, int64_t K, int dtype,
+                       dsw_stream_t stream, const dsw_hop2_plan* plan_t, void* spare) {
+    return cheb_basis_adj_impl(rowptr_t, colind_t, vals_t, V, nnz, G0, Grest, B, C, K, dtype, stream, plan_t, spare, 0);
 }
 
 int dsw_cheb_mix_fwd(const void* X, const void* T, const void* W, const void* bias, void* Y, int64_t N,
@@ -255,12 +264,27 @@ static int cheb_fwd_impl(const int32_t* rowptr, const int32_t* colind, const flo
         const int64_t N = B * V;
         // scale and residual ride in the epilogue of the plane GEMM: Y = sum_k T_k(L) (s X W_k) + (s b + R) is linear in
         // the planes, so Z_k = s (X W_k) (+ s b + R on plane 0) and the recurrence is unchanged
-        rc = dsw_zmix_launch(X, W, bias, Y, T, N, Fin, Fout, K, dtype, (hipStream_t)stream, extras ? &ex : nullptr);
-        if (rc != DSW_OK) return rc;
         char* spare = static_cast<char*>(T) + (K - 1) * N * Fout * elem_size(dtype);
+        // plane K-3 is produced as Z_{K-3} - Z_{K-1} (folded weights, parked behind the planes in the T scratch when it has
+        // the room - it does unless the batch is a handful of nodes): one epilogue operand less at the top of the recurrence
+        const void* Wz = W;
+        int folded = 0;
+        if (K >= 3) {
+            const int64_t used = round_up((K - 1 + (K >= 4 ? 2 : 0)) * N * Fout * elem_size(dtype), 256);
+            const int64_t have = (K - 1) * N * Fin * elem_size(dtype);
+            if (have - used >= Fin * K * Fout * elem_size(dtype)) {
+                void* Wf = static_cast<char*>(T) + used;
+                rc = dsw_fold_w_launch(W, Wf, Fin, Fout, K, dtype, (hipStream_t)stream);
+                if (rc != DSW_OK) return rc;
+                Wz = Wf;
+                folded = 1;
+            }
+        }
+        rc = dsw_zmix_launch(X, Wz, bias, Y, T, N, Fin, Fout, K, dtype, (hipStream_t)stream, extras ? &ex : nullptr);
+        if (rc != DSW_OK) return rc;
         // the Clenshaw recurrence has exactly the form of the adjoint recurrence (with L instead of L^T)
-        rc = dsw_cheb_basis_adj(rowptr, colind, vals, V, nnz, Y, T, B, Fout, K, dtype, stream, plan,
-                                K >= 4 ? spare : nullptr);
+        rc = cheb_basis_adj_impl(rowptr, colind, vals, V, nnz, Y, T, B, Fout, K, dtype, stream, plan,
+                                 K >= 4 ? spare : nullptr, folded);
         // the mix-first order ends in an SpMM: the activation is one in-place pass over the (Fout-channel) output
         if (rc == DSW_OK && relu) rc = dsw_relu_inplace_launch(Y, N * Fout, dtype, (hipStream_t)stream);
         return rc;
@@ -322,7 +346,8 @@ int64_t dsw_cheb_bwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t 
     const int64_t g = round_up((K - 1 + (K >= 4 ? 2 : 0)) * N * Fin * elem_size(dtype), 256);
     const int64_t S = dsw_wgrad_slabs(N, Fin, Fout, K);
     const int64_t p = round_up((S > 0 ? S : 1) * (K * Fin + 1) * Fout * 4, 256);
-    return g + p + 256;
+    const int64_t wf = K >= 3 ? round_up(Fin * K * Fout * elem_size(dtype), 256) : 0;   // folded dgrad weights
+    return g + p + wf + 256;
 }
 
 static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t, int64_t V,
@@ -365,15 +390,26 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
     char* spare = G + (K - 1) * plane;
     float* partial = reinterpret_cast<float*>(ws + round_up((K - 1 + (K >= 4 ? 2 : 0)) * plane, 256));
     int rc = DSW_OK;
+    // dgrad weights with plane K-3 folded (G_{K-3} - G_{K-1} out of the GEMM): the adjoint recurrence then has one
+    // epilogue operand less at its top - for K = 3 every step is a one-operand step
+    const void* Wd = W;
+    const int folded = (K >= 3 && dX != nullptr && N > 0) ? 1 : 0;
+    if (folded) {
+        const int64_t S_ = dsw_wgrad_slabs(N, Fin, Fout, K);
+        void* Wf = reinterpret_cast<char*>(partial) + round_up((S_ > 0 ? S_ : 1) * (K * Fin + 1) * Fout * 4, 256);
+        rc = dsw_fold_w_launch(W, Wf, Fin, Fout, K, dtype, s);
+        if (rc != DSW_OK) return rc;
+        Wd = Wf;
+    }
     if (dX != nullptr && dW != nullptr && N > 0 && !extras) {
         // small aligned fp32 layers: dgrad planes and dW partials from ONE pass over dY (dsw_wgrad_x3.hip, FUSE)
         if (K > 1 && !rowptr_t) return DSW_ERR_BAD_ARG;
         int rcf = DSW_OK;
-        if (dsw_bwd_gemm_fused_try(X, T, W, dY, dW, db, dX, G, partial, N, Fin, Fout, K, dtype, s, &rcf)) {
+        if (dsw_bwd_gemm_fused_try(X, T, Wd, dY, dW, db, dX, G, partial, N, Fin, Fout, K, dtype, s, &rcf)) {
             if (rcf != DSW_OK) return rcf;
             if (K > 1)
-                rcf = dsw_cheb_basis_adj(rowptr_t, colind_t, vals_t, V, nnz, dX, G, B, Fin, K, dtype, stream, plan_t,
-                                         K >= 4 ? spare : nullptr);
+                rcf = cheb_basis_adj_impl(rowptr_t, colind_t, vals_t, V, nnz, dX, G, B, Fin, K, dtype, stream, plan_t,
+                                          K >= 4 ? spare : nullptr, folded);
             return rcf;
         }
     }
@@ -381,10 +417,10 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
         if (K > 1 && !rowptr_t) return DSW_ERR_BAD_ARG;
         // scale multiplies every dgrad plane (the recurrence is linear); dX_add joins plane 0 = the dX buffer, onto which
         // the adjoint recurrence then accumulates
-        rc = dsw_mix_dgrad_launch(dY, W, dX, G, N, Fin, Fout, K, dtype, s, extras ? &ex : nullptr);
+        rc = dsw_mix_dgrad_launch(dY, Wd, dX, G, N, Fin, Fout, K, dtype, s, extras ? &ex : nullptr);
         if (rc == DSW_OK && K > 1)
-            rc = dsw_cheb_basis_adj(rowptr_t, colind_t, vals_t, V, nnz, dX, G, B, Fin, K, dtype, stream, plan_t,
-                                    K >= 4 ? spare : nullptr);
+            rc = cheb_basis_adj_impl(rowptr_t, colind_t, vals_t, V, nnz, dX, G, B, Fin, K, dtype, stream, plan_t,
+                                     K >= 4 ? spare : nullptr, folded);
         if (rc != DSW_OK) return rc;
     }
     if (dW != nullptr) {

@@ -211,6 +211,34 @@ static int ew_blocks(long n, int v) {
 
 }  // namespace
 
+namespace {
+// W' = W with plane K-3 replaced by W[:, K-3, :] - W[:, K-1, :]   (W: [Fin][K][Fout])
+template <bool BF16>
+__global__ void fold_w_kernel(const void* __restrict__ W, void* __restrict__ Wf, const int Fin, const int K, const int Fout) {
+    const int n = Fin * K * Fout;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int o = i % Fout, k = (i / Fout) % K, f = i / (Fout * K);
+        float v = Ew<BF16>::load1(W, i);
+        if (k == K - 3) v -= Ew<BF16>::load1(W, ((size_t)f * K + (K - 1)) * Fout + o);
+        if constexpr (BF16) static_cast<uint16_t*>(Wf)[i] = f32_to_bf16(v);
+        else static_cast<float*>(Wf)[i] = v;
+    }
+}
+}  // namespace
+
+// The top of the adjoint (and of the Clenshaw) recurrence subtracts the RAW plane K-1 from plane K-3:
+// G'_{K-3} = G_{K-3} + c L^T G'_{K-2} - G_{K-1}.  Both planes come out of one GEMM with the layer's weights, so the
+// subtraction is folded into the weights of plane K-3 (a few KB of parameters) instead of a pass over a [B, V, C] plane:
+// one epilogue operand less in that step of the recurrence (for K = 3: in its last step, which is then a one-operand step).
+int dsw_fold_w_launch(const void* W, void* Wf, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t s) {
+    if (K < 3 || !W || !Wf) return DSW_ERR_BAD_ARG;
+    const int64_t n = Fin * K * Fout;
+    const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    if (dtype == DSW_BF16) hipLaunchKernelGGL(fold_w_kernel<true>, dim3(blocks), dim3(256), 0, s, W, Wf, (int)Fin, (int)K, (int)Fout);
+    else hipLaunchKernelGGL(fold_w_kernel<false>, dim3(blocks), dim3(256), 0, s, W, Wf, (int)Fin, (int)K, (int)Fout);
+    return dsw_check_launch();
+}
+
 int dsw_relu_inplace_launch(void* y, int64_t n, int dtype, hipStream_t s) {
     if (n <= 0) return DSW_OK;
     const int vec = dsw_aligned16(y) ? 1 : 0;

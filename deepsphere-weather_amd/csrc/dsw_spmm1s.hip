@@ -75,10 +75,16 @@ __global__ __launch_bounds__(NTHREADS1, OCC) void spmm1_staged_kernel(const Hop1
     const int tid = threadIdx.x;
     const int W = P.ell_w;
     const size_t sample_bytes = (size_t)P.V * P.row_stride;
-    auto vbase = [&](const int b) __attribute__((always_inline)) {
+    struct Cursor { size_t off; int cc; };   // incremental sample offsets, see spmm1_dma_kernel
+    auto cursor_at = [&](const int b) __attribute__((always_inline)) {
         const int bs = b / P.ncc;
-        return (size_t)bs * sample_bytes + (size_t)(b - bs * P.ncc) * P.row_bytes;
+        return Cursor{(size_t)bs * sample_bytes + (size_t)(b - bs * P.ncc) * P.row_bytes, b - bs * P.ncc};
     };
+    auto advance = [&](Cursor& c) __attribute__((always_inline)) {
+        c.off += P.row_bytes;
+        if (++c.cc == P.ncc) { c.cc = 0; c.off += sample_bytes - (size_t)P.ncc * P.row_bytes; }
+    };
+    Cursor c_cur = cursor_at(b_begin);
 
     if (tid == 0) *tile_w = 2;
     for (int i = tid; i < n2; i += NTHREADS1) rows[i] = P.s2_rows[s2_off + i];
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(NTHREADS1, OCC) void spmm1_staged_kernel(const Hop1
 
     u32x4 su[NST];
     if (b_begin < b_end) {
-        const size_t sb = vbase(b_begin);
+        const size_t sb = c_cur.off;
 #pragma unroll
         for (int k = 0; k < NST; ++k) su[k] = *reinterpret_cast<const u32x4*>(P.U + sb + offU[k]);
     }
@@ -134,7 +140,8 @@ __global__ __launch_bounds__(NTHREADS1, OCC) void spmm1_staged_kernel(const Hop1
             if (lane_ok && i < n2) *reinterpret_cast<u32x4*>(bufX + (size_t)i * P.row_bytes + cb) = su[k];
         }
         __syncthreads();   // bufX(b) complete
-        const size_t sample = vbase(b);
+        const size_t sample = c_cur.off;
+        if (b + 1 < b_end) advance(c_cur);   // tail: the next-sample burst re-reads this sample (harmless)
         // burst: this sample's epilogue operands first, then the next sample's rows
         u32x4 cz[HZ ? NS2 : 1], cz2[HZ2 ? NS2 : 1];
         if constexpr (HZ) {
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(NTHREADS1, OCC) void spmm1_staged_kernel(const Hop1
             for (int k = 0; k < NS2; ++k) cz2[k] = ld16_once<u32x4>(P.Z2 + sample + offY[k]);
         }
         {
-            const size_t sb = vbase(b + 1 < b_end ? b + 1 : b);   // tail: harmless re-read
+            const size_t sb = c_cur.off;
 #pragma unroll
             for (int k = 0; k < NST; ++k) su[k] = *reinterpret_cast<const u32x4*>(P.U + sb + offU[k]);
         }
@@ -183,7 +190,8 @@ __global__ __launch_bounds__(NTHREADS1, OCC) void spmm1_staged_kernel(const Hop1
 }
 
 // LDS-DMA form of the same launch for the shape that matters (the k = 20 stencil on 64-row tiles: one output row per
-// lane group, <= 24 entries per row, rows of 16 / 32 / 64 / 128 bytes so that the wave's lanes are LDS-linear).
+// lane group, <= 24 entries per row - 32 on samplings with a few longer rows, e.g. equiangular k = 20 near the poles:
+// WREG -, rows of 16 / 32 / 64 / 128 bytes so that the wave's lanes are LDS-linear).
 //   * the staged rows travel HBM/L2 -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave instruction, no staging
 //     registers, no ds_write pass - ds_write_b128 costs 13 LDS cycles per KiB against 4 per KiB read) into a RING OF
 //     THREE buffers, two samples ahead of the gather: the first measured form (two buffers, one sample ahead) had 58 % of
@@ -219,13 +227,13 @@ static __device__ __forceinline__ void wait_vm(const int n) {
     }
 }
 
-template <bool BF16, int NST, bool HZ>
+template <bool BF16, int NST, bool HZ, int WREG>
 __global__ __launch_bounds__(NTHREADS1, 4) void spmm1_dma_kernel(const Hop1Args P) {
     static_assert(NST <= 3, "wait_vm counts up to NST + 1 operations");
+    static_assert(WREG % 8 == 0, "stencil entries are loaded and gathered in batches of 8");
     using R = Row16<BF16>;
     using VT = typename R::V;
     constexpr int N = R::N;
-    constexpr int WREG = 24;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const unsigned buf_bytes = (unsigned)P.max_n2 * (unsigned)P.row_bytes;                  // multiple of 16
     unsigned char* bufX = lds;                                                              // [3][max_n2][row_bytes]
@@ -506,26 +514,28 @@ int dsw_spmm1s_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const
     const int rpp = NTHREADS1 / A.lpr;
     const int shape = pick_shape((plan->max_n2 + rpp - 1) / rpp, (plan->tile_rows + rpp - 1) / rpp);
     const bool bf = dtype == DSW_BF16;
-    // one output row per lane group, <= 24 entries per row, LDS-linear lanes, at most one epilogue operand: the LDS-DMA kernel
+    // one output row per lane group, <= 32 entries per row, LDS-linear lanes, at most one epilogue operand: the LDS-DMA kernel
     static const char* dma_env = dsw_diag_env("DSW_H1_DMA");   // diagnostics: "0" = register-staged kernel
     const int nst_ = (plan->max_n2 + rpp - 1) / rpp;
     const size_t ldsd = hop1_dma_lds_bytes(plan, A.row_bytes, A.Z != nullptr);
-    if (!(dma_env && dma_env[0] == '0') && !A.Z2 && plan->ell_w == 24 && plan->ell_pos && plan->ell_val && (A.lpr & (A.lpr - 1)) == 0 &&
-        plan->tile_rows <= rpp && plan->tile_rows <= 64 && nst_ <= 3 && ldsd <= 80 * 1024) {
-#define DSW_H1_DMA(BF_, NST_)                                                                                        \
+    if (!(dma_env && dma_env[0] == '0') && !A.Z2 && (plan->ell_w == 24 || plan->ell_w == 32) && plan->ell_pos && plan->ell_val &&
+        (A.lpr & (A.lpr - 1)) == 0 && plan->tile_rows <= rpp && plan->tile_rows <= 64 && nst_ <= 3 && ldsd <= 80 * 1024) {
+#define DSW_H1_DMA2(BF_, NST_, W_)                                                                                   \
     do {                                                                                                             \
         if (ldsd > 64 * 1024) {                                                                                      \
-            if (hipFuncSetAttribute((const void*)spmm1_dma_kernel<BF_, NST_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd) != hipSuccess || \
-                hipFuncSetAttribute((const void*)spmm1_dma_kernel<BF_, NST_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd) != hipSuccess)   \
+            if (hipFuncSetAttribute((const void*)spmm1_dma_kernel<BF_, NST_, true, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd) != hipSuccess || \
+                hipFuncSetAttribute((const void*)spmm1_dma_kernel<BF_, NST_, false, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd) != hipSuccess)   \
                 return DSW_ERR_LAUNCH;                                                                               \
         }                                                                                                            \
-        if (A.Z) { hipLaunchKernelGGL((spmm1_dma_kernel<BF_, NST_, true>), dim3((unsigned)nwg), dim3(NTHREADS1), ldsd, stream, A); }    \
-        else { hipLaunchKernelGGL((spmm1_dma_kernel<BF_, NST_, false>), dim3((unsigned)nwg), dim3(NTHREADS1), ldsd, stream, A); }       \
+        if (A.Z) { hipLaunchKernelGGL((spmm1_dma_kernel<BF_, NST_, true, W_>), dim3((unsigned)nwg), dim3(NTHREADS1), ldsd, stream, A); }    \
+        else { hipLaunchKernelGGL((spmm1_dma_kernel<BF_, NST_, false, W_>), dim3((unsigned)nwg), dim3(NTHREADS1), ldsd, stream, A); }       \
         return dsw_check_launch();                                                                                   \
     } while (0)
+#define DSW_H1_DMA(BF_, NST_) do { if (plan->ell_w == 24) DSW_H1_DMA2(BF_, NST_, 24); else DSW_H1_DMA2(BF_, NST_, 32); } while (0)
         if (nst_ <= 2) { if (bf) DSW_H1_DMA(true, 2); else DSW_H1_DMA(false, 2); }
         else { if (bf) DSW_H1_DMA(true, 3); else DSW_H1_DMA(false, 3); }
 #undef DSW_H1_DMA
+#undef DSW_H1_DMA2
     }
     // OCC = waves per SIMD the registers must allow: two 8-wave workgroups per CU for the 64 / 128-row tiles; the
     // 256-row shapes hold 7-8 staged rows per lane and run one workgroup per CU (LDS) anyway

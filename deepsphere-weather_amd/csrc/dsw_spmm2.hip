@@ -102,10 +102,18 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && HZB && NS1 > 2) ? 2 : 4)) void s
     // "sample" b of the loops below = (real sample b / ncc, channel chunk b % ncc): wide rows are processed one
     // 128-byte channel chunk at a time (the operator acts on every channel alike), so that the staged neighbourhood is
     // as small as for a 32-channel layer whatever the layer's width
-    auto vbase = [&](const int b) __attribute__((always_inline)) {
+    // (advanced incrementally in the sample loop: a divide + 64-bit multiply per offset is ~40 scalar instructions, and
+    // the scalar unit is shared by all waves of the CU)
+    struct Cursor { size_t off; int cc; };
+    auto cursor_at = [&](const int b) __attribute__((always_inline)) {
         const int bs = b / P.ncc;
-        return (size_t)bs * sample_bytes + (size_t)(b - bs * P.ncc) * P.row_bytes;
+        return Cursor{(size_t)bs * sample_bytes + (size_t)(b - bs * P.ncc) * P.row_bytes, b - bs * P.ncc};
     };
+    auto advance = [&](Cursor& c) __attribute__((always_inline)) {
+        c.off += P.row_bytes;
+        if (++c.cc == P.ncc) { c.cc = 0; c.off += sample_bytes - (size_t)P.ncc * P.row_bytes; }
+    };
+    Cursor c_cur = cursor_at(b_begin);
 
     // ---- the tile's plan slice -> LDS, once for all samples of this workgroup.  Ordered so that nothing waits on
     // a chain of dependent global loads: (1) gather list + local row pointers (parked in bufT, free until the first
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && HZB && NS1 > 2) ? 2 : 4)) void s
 
     u32x4 su[NST];
     if (b_begin < b_end) {
-        const size_t sb = vbase(b_begin);
+        const size_t sb = c_cur.off;
 #pragma unroll
         for (int k = 0; k < NST; ++k) su[k] = *reinterpret_cast<const u32x4*>(P.U + sb + offU[k]);
     }
@@ -170,7 +178,8 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && HZB && NS1 > 2) ? 2 : 4)) void s
             if (lane_ok && i < n2) *reinterpret_cast<u32x4*>(bufX + (size_t)i * P.row_bytes + cb) = su[k];
         }
         __syncthreads();   // bufX(b) complete; every wave is past phase 2 of sample b-1 (bufT reusable)
-        const size_t sample = vbase(b);
+        const size_t sample = c_cur.off;
+        if (b + 1 < b_end) advance(c_cur);   // tail: the next-sample burst re-reads this sample (harmless)
         // burst: this sample's epilogue operands first, then the next sample's U rows
         // NS1 / NS2: slots that can hold an S1 row / a tile row (ceil(max_n1 / rpp), ceil(tile_rows / rpp))
         u32x4 cz1[HZA ? NS1 : 1], cz1b[(HZA && HZB) ? NS1 : 1], cz2[HZ2 ? NS2 : 1];
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(NTHREADS, ((HZA && HZB && NS1 > 2) ? 2 : 4)) void s
             for (int k = 0; k < NS2; ++k) cz2[k] = ld16_once<u32x4>(P.Z2 + sample + offZ2[k]);
         }
         {
-            const size_t sb = vbase(b + 1 < b_end ? b + 1 : b);   // tail: harmless re-read
+            const size_t sb = c_cur.off;
 #pragma unroll
             for (int k = 0; k < NST; ++k) su[k] = *reinterpret_cast<const u32x4*>(P.U + sb + offU[k]);
         }

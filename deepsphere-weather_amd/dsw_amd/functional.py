@@ -104,8 +104,10 @@ class CsrOperator:
                             cap1 = int((80 * 1024 - 2048) / (128 + 6 * w + 1.8 * 128))
                             tiles = hop2.cluster_tiles(host(0), host(1), rows, max_n1=cap1, max_n2=int(1.8 * cap1))
                         elif clustered:
-                            # one hop: tile + 1-ring staged, ELL of the tile rows only
-                            cap1 = int((80 * 1024 - 2560 - rows * (6 * w + 4)) / 132)
+                            # one hop: tile + 1-ring staged; LDS-DMA form (stencils of <= 32 entries): a ring of three
+                            # buffers of 128-byte rows + 16 KiB of epilogue rows; generic form: one buffer + ELL of the tile
+                            cap1 = (80 * 1024 - 16 * 1024) // (3 * 128) if w <= 32 and rows <= 64 else \
+                                int((80 * 1024 - 2560 - rows * (6 * w + 4)) / 132)
                             tiles = hop2.cluster_tiles(host(0), host(1), rows, max_n1=cap1)
                         self._plans_by_rows[key] = hop2.build_hop2_plan(host(0), host(1), host(2), rows, tiles=tiles, hops=hops)
                     except ValueError:
@@ -114,21 +116,28 @@ class CsrOperator:
 
             dense = self.nnz >= STAGED_MIN_ROW_LEN * self.shape[0]
             if HOP_MODE == "staged" or (HOP_MODE == "auto" and dense):
-                # staged one-hop plan: the largest tile that leaves two workgroups on a CU; consecutive rows first
-                # (HEALPix nested order), else tiles clustered from the graph
+                # staged one-hop plan (two workgroups per CU): tiles of consecutive rows when those are compact (HEALPix
+                # nested order: tile + 1-ring = 2.2-2.4x the tile at k = 20), else tiles clustered from the graph (ring
+                # order, equiangular row-major: a strip of 64 consecutive rows drags in 5x its own rows)
+                def fits(cand):
+                    return cand is not None and cand.lds_bytes(row_bytes) <= 80 * 1024 and cand.max_n2 * row_bytes <= 65535
+
+                def staged_rows(cand):    # rows staged per output row
+                    return float(cand.tile_meta[:, 2].sum()) / float(cand.tile_meta[:, 1].sum())
+
                 for rows in STAGED_TILE_ROWS:
                     if rows > self.shape[0]:
                         continue
                     cand = host_plan(rows, False, 1)
-                    if cand is not None and cand.lds_bytes(row_bytes) <= 80 * 1024 and cand.max_n2 * row_bytes <= 65535:
+                    if fits(cand):
                         plan = cand
                         break
-                if plan is None:
+                if (plan is None or staged_rows(plan) > 3.0):
                     for rows in STAGED_TILE_ROWS:
                         if self.shape[0] < MIN_CLUSTERED_TILES * rows:
                             continue
                         cand = host_plan(rows, True, 1)
-                        if cand is not None and cand.lds_bytes(row_bytes) <= 80 * 1024 and cand.max_n2 * row_bytes <= 65535:
+                        if fits(cand) and (plan is None or staged_rows(cand) < staged_rows(plan)):
                             plan = cand
                             break
 

@@ -86,16 +86,16 @@ class Hop2Plan:
         s += ((self.max_n2 + 3) & ~3) * 4 + 16            # gather list + the tile's loop length
         return (s + 15) & ~15
 
-    ELL_ROWS, ELL_W = 64, 24   # shape the LDS-DMA kernel keeps in registers: one row per lane group, 24 entries
+    ELL_ROWS, ELL_WS = 64, (24, 32)   # shapes the LDS-DMA kernel keeps in registers: one row per lane group, 24 / 32 entries
 
     def add_ell(self):
         """Padded ELL image of the tile rows' stencils (hops = 1 plans with <= 64 rows per tile and <= 24 entries per
-        row): what the LDS-DMA kernel loads straight into registers - 9 independent 16-byte loads per lane instead of a
+        row - 32 when a few rows are longer): what the LDS-DMA kernel loads straight into registers - 9 independent 16-byte loads per lane instead of a
         CSR -> ELL expansion through LDS with two workgroup barriers in every workgroup's prologue.  tile_meta[t][5]
         becomes the tile's longest row (the kernel's gather length; explicit tiles keep their row count in [1])."""
-        if self.hops != 1 or self.tile_rows > self.ELL_ROWS or self.max_row_len > self.ELL_W or self.max_n1 > self.ELL_ROWS:
+        if self.hops != 1 or self.tile_rows > self.ELL_ROWS or self.max_row_len > self.ELL_WS[-1] or self.max_n1 > self.ELL_ROWS:
             return self
-        R, W = self.ELL_ROWS, self.ELL_W
+        R, W = self.ELL_ROWS, min(w for w in self.ELL_WS if w >= self.max_row_len)
         pos = np.zeros((self.n_tiles, R, W), dtype=np.uint16)
         pos[:] = np.arange(R, dtype=np.uint16)[None, :, None]          # padding: the row itself, weight 0
         val = np.zeros((self.n_tiles, R, W), dtype=np.float32)
