@@ -499,24 +499,39 @@ def launch_ranks(n, argv):
                 ("eager launches", {"DSW_BENCH_COLLECTIVES": "eager", "DSW_BENCH_NO_GRAPH": "1"})]
     if os.environ.get("DSW_BENCH_COLLECTIVES") == "eager":
         attempts = attempts[1:]
+    import tempfile
+    import time
+
     for i, (what, extra) in enumerate(attempts):
-        sock = socket.socket()
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-        sock.close()
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
-        env = dict(os.environ, **extra)
-        env["DSW_BENCH_LAUNCHER"] = "bench.py self-launch, attempt %d: %s" % (i + 1, what)
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
-        try:
-            out, _ = proc.communicate(timeout=limit)
-            rc = proc.returncode
-        except subprocess.TimeoutExpired:
-            os.killpg(proc.pid, signal.SIGKILL)
-            out, _ = proc.communicate()
-            rc = -9
+        for port_try in range(3):
+            # the probe socket is closed before torchrun binds the port (unavoidable: torchrun takes a number, not a
+            # socket): if somebody else grabs it in between, the rendezvous fails at once and a fresh port is tried
+            sock = socket.socket()
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+            sock.close()
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+            env = dict(os.environ, **extra)
+            env["DSW_BENCH_LAUNCHER"] = "bench.py self-launch, attempt %d: %s" % (i + 1, what)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            t0 = time.time()
+            with tempfile.TemporaryFile(mode="w+") as errf:
+                proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=errf, text=True, start_new_session=True)
+                try:
+                    out, _ = proc.communicate(timeout=limit)
+                    rc = proc.returncode
+                except subprocess.TimeoutExpired:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                    out, _ = proc.communicate()
+                    rc = -9
+                errf.seek(0)
+                err = errf.read()
+            sys.stderr.write(err)
+            port_taken = rc != 0 and time.time() - t0 < 60 and ("address already in use" in err.lower() or "EADDRINUSE" in err)
+            if not port_taken:
+                break
+            print("bench.py: port %d was taken before torchrun could bind it; trying another" % port, file=sys.stderr, flush=True)
         lines = [ln for ln in (out or "").splitlines() if ln.startswith("{") and '"metric"' in ln]
         if rc == 0 and lines:
             print(lines[-1], flush=True)
@@ -792,6 +807,10 @@ def main():
             "batch_per_gpu": B, "global_batch": B * world, "nodes": V,
             "parallelism": "dp%d (batch shards, flat-bucket %s grad all-reduce)" % (
                 world, "RCCL" if not dist.is_initialized() or dist.get_backend() == "nccl" else dist.get_backend()),
+            # N = 1 and N > 1 do not run byte-identical steps: say which one this line timed
+            "grad_handling": ("parameter gradients live in one flat bucket (one memset per step), the weight-gradient kernels "
+                              "add into it, all-reduced in place" if bucket.active() else
+                              "zero_grad(set_to_none=True) + autograd's gradient tensors (no exchange in a one-rank world)"),
             "launch": (("hip graph replay, %d steps per graph" % GRAPH_STEPS if graph_multi is not None
                         else "hip graph replay of one fwd+bwd" if graph is not None else "eager")
                        + ("" if not bucket.active() else

@@ -604,6 +604,14 @@ def grad_accumulators(weight, bias):
     ab = None if bias is None else getattr(bias, "_dsw_grad_acc", None)
     if bias is not None and ab is None:
         return None
+    # The pointer is only as good as the bucket that set it: it must still BE the parameter's gradient (a second bucket,
+    # `zero_grad(set_to_none=True)`, `.to()` / `.half()` after attach all replace `p.grad`) and have the parameter's layout
+    # (the kernels write the parameter's element order).  Anything else falls back to returning dW / db to autograd.
+    if weight.grad is not aw or aw.shape != weight.shape or aw.stride() != weight.stride() or aw.dtype != weight.dtype \
+            or aw.device != weight.device:
+        return None
+    if bias is not None and (bias.grad is not ab or ab.shape != bias.shape or ab.dtype != bias.dtype):
+        return None
     return aw, ab
 
 
@@ -910,7 +918,9 @@ def cheb_conv(op: CsrOperator, x: torch.Tensor, weight: torch.Tensor, bias=None,
             f"operator shape {op.shape} does not match the {x.shape[1]} nodes of the input"
         )
     _check_dtype(x, weight, bias)
-    return _ChebConvFn.apply(x, weight, bias, op, activation == "relu", grad_accumulators(weight, bias))
+    # (direct accumulation: the kernels write dW in the contiguous [Fin, K, Fout] order)
+    acc = grad_accumulators(weight, bias) if weight.is_contiguous() else None
+    return _ChebConvFn.apply(x, weight, bias, op, activation == "relu", acc)
 
 
 def dense_mix(x: torch.Tensor, weight: torch.Tensor, bias=None, acc=None) -> torch.Tensor:

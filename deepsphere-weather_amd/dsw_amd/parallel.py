@@ -154,6 +154,13 @@ class GradBucket:
         self._launched = [False] * len(self.chunks)
         self._works = []
         self._hooks = []
+        self._direct = False
+        self._dirty = False       # a backward ran inside no_sync(): the hooks did not count, finish() sends everything
+        # a bucket built earlier on the same parameters may have left its direct-accumulation pointers behind: the
+        # kernels would keep adding into THAT buffer while p.grad is a view of this one
+        for p in self.params:
+            if hasattr(p, "_dsw_grad_acc"):
+                del p._dsw_grad_acc
         if attach:
             self.attach()
 
@@ -161,6 +168,8 @@ class GradBucket:
     def attach(self):
         for p in self.params:
             p.grad = self.views[p]
+            if hasattr(p, "_dsw_grad_acc") and p._dsw_grad_acc is not self.views[p]:
+                del p._dsw_grad_acc
         if self.overlap and not self._hooks:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._ready))
@@ -177,9 +186,36 @@ class GradBucket:
             raise RuntimeError("direct accumulation needs an attached bucket")
         for p in self.params:
             if enable:
+                # call it after the last .to() / re-layout of the model: the view has the strides the parameter had when
+                # the bucket was built; `functional.grad_accumulators` re-checks identity and strides on every use and falls
+                # back to autograd's accumulation when they no longer match
                 p._dsw_grad_acc = self.views[p]
             elif hasattr(p, "_dsw_grad_acc"):
                 del p._dsw_grad_acc
+        self._direct = bool(enable)
+        return self
+
+    def detach(self):
+        """Give the parameters ordinary gradient tensors back (copies of the bucket's content) and remove the hooks and the
+        direct-accumulation pointers: the inverse of ``attach()`` + ``direct_accumulation()``."""
+        self.direct_accumulation(False)
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for p in self.params:
+            if p.grad is self.views[p]:
+                p.grad = self.views[p].clone()
+        self.attached = False
+        return self
+
+    def reset(self):
+        """Forget a half-finished exchange (e.g. a graph capture that died inside ``finish()``): no chunk counts as launched,
+        nothing is waited for.  The caller synchronises the device first."""
+        self._works = []
+        self._launched = [False] * len(self.chunks)
+        self._pending = [len(ps) for _, _, ps in self.chunks]
+        self._dirty = False
+        self.capturing = False
         return self
 
     def zero(self):
@@ -202,13 +238,20 @@ class GradBucket:
                 "GradBucket: a second backward() produced gradients for a chunk whose all-reduce was already launched "
                 "(parameter of shape %s). One backward() per finish(); accumulate several backwards inside "
                 "`with bucket.no_sync():` and call finish() afterwards." % (tuple(p.shape),))
+        if self._defer:
+            # accumulation block: count nothing (a later backward outside the block must see every parameter of the chunk
+            # again before the chunk may go out); finish() sends whatever has not been launched
+            self._dirty = True
+            return
         self._pending[ci] -= 1
-        if self._pending[ci] == 0 and self.overlap and not self._defer and not self.capturing and self.active():
+        if self._pending[ci] == 0 and self.overlap and not self._dirty and not self.capturing and self.active():
             self._launch(ci)
 
     def no_sync(self):
         """Context manager for gradient accumulation: backwards inside the block only accumulate into the bucket (no
-        collective is enqueued by the hooks); the next ``finish()`` averages the accumulated gradients in one go."""
+        collective is enqueued by the hooks - nor by a backward AFTER the block, whose hooks would otherwise see a chunk
+        "complete" that still holds local-only contributions); the next ``finish()`` averages the accumulated gradients in
+        one go.  With ``direct_accumulation`` the same holds for the parameters the kernels add to."""
         import contextlib
 
         @contextlib.contextmanager
@@ -255,6 +298,7 @@ class GradBucket:
         self._works = []
         self._launched = [False] * len(self.chunks)
         self._pending = [len(ps) for _, _, ps in self.chunks]
+        self._dirty = False
 
     __call__ = finish
 

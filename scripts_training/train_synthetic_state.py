@@ -179,8 +179,22 @@ class Trainer:
             print("trainer: HIP graph capture unavailable (%s: %s); stepping eagerly" % (type(exc).__name__, exc),
                   file=sys.stderr)
             self.graph = None
-            self.bucket.capturing = False
             torch.cuda.synchronize()
+            # a capture that died inside finish() leaves chunks marked as launched and works of the aborted recording
+            # behind: the first eager backward would raise "a second backward()..." 
+            self.bucket.reset()
+        if self.distributed:
+            # ALL ranks replay the graph or NONE does: a rank that fell back issues its chunk all-reduces in hook order,
+            # the others replay them in index order from their graphs - mismatched collectives otherwise
+            import torch.distributed as dist
+
+            ok = torch.tensor([1 if self.graph is not None else 0], device=self.x.device, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and self.graph is not None:
+                print("trainer: another rank could not capture its step graph; stepping eagerly on all ranks", file=sys.stderr)
+                self.graph = None
+                torch.cuda.synchronize()
+                self.bucket.reset()
         with torch.no_grad():
             for p, v in zip(self.model.parameters(), saved):
                 p.copy_(v)

@@ -220,7 +220,47 @@ def _accumulate_worker(rank, world, port, out):
         model(xs[1]).sum().backward()
         launched_inside = sum(bucket._launched)
     bucket.finish()
-    out[rank] = (raised, launched_inside, [p.grad.clone() for p in model.parameters()])
+    grads_acc = [p.grad.clone() for p in model.parameters()]
+    # (3) ADVICE r3: the usual DDP pattern - first backward inside no_sync(), the LAST one outside.  The outside backward
+    # must not send a chunk early (its hooks would see "complete" chunks that still hold local-only sums) nor raise.
+    bucket.zero()
+    with bucket.no_sync():
+        model(xs[0]).sum().backward()
+    model(xs[1]).sum().backward()
+    launched_after = sum(bucket._launched)
+    bucket.finish()
+    grads_ddp = [p.grad.clone() for p in model.parameters()]
+    # (4) reset() after a half-finished exchange: the next step behaves like the first
+    bucket.zero()
+    model(xs[0]).sum().backward()
+    for w in bucket._works:
+        w.wait()
+    bucket.reset()
+    assert not any(bucket._launched) and bucket._works == []
+    bucket.zero()
+    with bucket.no_sync():
+        model(xs[0]).sum().backward()
+        model(xs[1]).sum().backward()
+    bucket.finish()
+    grads_reset = [p.grad.clone() for p in model.parameters()]
+    # (5) a second bucket on the same parameters clears the first one's direct-accumulation pointers, and
+    # `grad_accumulators` refuses a pointer that is no longer the parameter's gradient
+    from dsw_amd.functional import grad_accumulators
+    lin = model[0]
+    bucket.direct_accumulation()
+    ok_before = grad_accumulators(lin.weight, lin.bias) is not None
+    bucket2 = GradBucket(model.parameters(), chunk_bytes=100, overlap=False)
+    cleared = not hasattr(lin.weight, "_dsw_grad_acc")
+    bucket2.direct_accumulation()
+    ok_second = grad_accumulators(lin.weight, lin.bias) is not None and lin.weight.grad is bucket2.views[lin.weight]
+    lin.weight.grad = None                       # optimizer.zero_grad(set_to_none=True)
+    refused = grad_accumulators(lin.weight, lin.bias) is None
+    bucket2.zero()                               # re-attaches the views
+    ok_again = grad_accumulators(lin.weight, lin.bias) is not None
+    bucket2.detach()
+    detached = not hasattr(lin.weight, "_dsw_grad_acc") and lin.weight.grad is not bucket2.views[lin.weight]
+    out[rank] = (raised, launched_inside, grads_acc, launched_after, grads_ddp, grads_reset,
+                 (ok_before, cleared, ok_second, refused, ok_again, detached))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -239,9 +279,12 @@ def test_two_rank_gloo_bucket_reentry_raises_and_no_sync_accumulates():
         for _ in range(2):
             (ref(torch.randn(3, 6, generator=g).double()).sum() / world).backward()
     for r in range(world):
-        raised, launched_inside, grads = out[r]
-        assert raised and launched_inside == 0
-        for got, want in zip(grads, ref.parameters()):
-            np.testing.assert_allclose(got.numpy(), want.grad.numpy(), rtol=0, atol=2e-6)
-    for a, b in zip(out[0][2], out[1][2]):
-        assert torch.equal(a, b)
+        raised, launched_inside, grads, launched_after, grads_ddp, grads_reset, flags = out[r]
+        assert raised and launched_inside == 0 and launched_after == 0
+        assert all(flags), flags
+        for variant in (grads, grads_ddp, grads_reset):
+            for got, want in zip(variant, ref.parameters()):
+                np.testing.assert_allclose(got.numpy(), want.grad.numpy(), rtol=0, atol=2e-6)
+    for k in (2, 4, 5):
+        for a, b in zip(out[0][k], out[1][k]):
+            assert torch.equal(a, b)
