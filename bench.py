@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--knn", type=int, default=8, help="neighbours of the HEALPix k-NN stencil (8 or 20)")
     ap.add_argument("--min-timed-ms", type=float, default=1500.0,
                     help="repeat the timed region (exactly --steps steps each) until this much has been timed; median reported")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="STRONG scaling: this many samples in total, sharded over the ranks with dsw_amd.parallel.shard_batch "
+                         "(ragged and empty shards allowed); default: the workload's batch PER GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
@@ -594,6 +597,11 @@ def main():
     dtype = torch.bfloat16 if wl["dtype"] == "bf16" else torch.float32
     V = wl["nlat"] * wl["nlon"] if args.workload == "c5" else 12 * wl["nside"] ** 2
     B = wl["batch"]
+    if args.global_batch is not None:
+        from dsw_amd.parallel import shard_batch
+
+        lo, hi = shard_batch(args.global_batch, rank, world)   # contiguous slices, ragged tail, empty shards when B < world
+        B = hi - lo
     torch.manual_seed(1234 + rank)
 
     if args.workload == "unet":
@@ -786,12 +794,13 @@ def main():
     elapsed = regions[len(regions) // 2]
 
     ms = elapsed / args.steps * 1e3
-    units = B * V * wl["fin"] * world  # node-channels through the path per step, whole job
+    # node-channels through the path per step, whole job
+    units = (args.global_batch if args.global_batch is not None else B * world) * V * wl["fin"]
     out = {
         "metric": "HEALPix nodes*channels/sec through ConvCheb K=%d (fwd+bwd)" % wl["K"],
         "value": units / (elapsed / args.steps), "unit": "nodes*channels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "weak" if args.global_batch is None else "strong", "vs_baseline": None,
         "dtype": wl["dtype"], "data": "synthetic",
         "timing": "median of %d back-to-back timed regions of exactly %d steps each (barrier + synchronize around every region, max over ranks)" % (n_regions, args.steps),
         "region_ms": {"n": n_regions, "min": round(regions[0] * 1e3, 4), "median": round(elapsed * 1e3, 4),
@@ -804,7 +813,7 @@ def main():
                 "c5": "equiangular 200x400 (V=80000, k=20, irregular degree) ConvCheb K=3 32ch + interp pooling to HEALPix nside=32 and back, B=8/GPU, fp32",
             }[args.workload],
             "knn": 20 if args.workload == "c5" else args.knn if args.workload != "unet" else (args.knn if args.knn != 8 else 20),
-            "batch_per_gpu": B, "global_batch": B * world, "nodes": V,
+            "batch_per_gpu": B, "global_batch": args.global_batch if args.global_batch is not None else B * world, "nodes": V,
             "parallelism": "dp%d (batch shards, flat-bucket %s grad all-reduce)" % (
                 world, "RCCL" if not dist.is_initialized() or dist.get_backend() == "nccl" else dist.get_backend()),
             # N = 1 and N > 1 do not run byte-identical steps: say which one this line timed

@@ -27,7 +27,6 @@ int dsw_relu_inplace_launch(void* y, int64_t n, int dtype, hipStream_t s);
 int dsw_fold_w_launch(const void* W, void* Wf, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t s);
 int dsw_mix_dgrad_launch(const void* dY, const void* W, void* G0, void* Grest, int64_t N, int64_t Fin,
                          int64_t Fout, int64_t K, int dtype, hipStream_t stream, const DswEpiExtra* extra = nullptr);
-void dsw_wgrad_set_accumulate(int on);
 int dsw_rezero_param_grads_launch(const void* W, const void* bias, const void* dW_raw, const void* db_raw, const void* scale,
                                   void* dW, void* db, void* dscale, int64_t n_w, int64_t n_b, void* workspace, int dtype,
                                   hipStream_t stream);
@@ -40,15 +39,15 @@ int dsw_spmm1s_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const
                       int64_t B, int64_t C, float a, float b, float c, int dtype, hipStream_t stream, int stream_out);
 int dsw_spmm1s_supported(const dsw_hop2_plan* plan, int64_t C, int dtype);
 int dsw_wgrad_launch(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
-                     int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream);
+                     int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int accumulate);
 int dsw_wgrad_launch_ex(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
                         int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
-                        int64_t K_out, int64_t k_off);
+                        int64_t K_out, int64_t k_off, int accumulate);
 int dsw_wgrad_mixfirst_launch(const void* X, const void* dY, const void* D, void* dW, void* db, float* partial,
-                              int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream);
+                              int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int accumulate);
 int dsw_bwd_gemm_fused_try(const void* X, const void* T, const void* W, const void* dY, void* dW, void* db, void* G0,
                            void* Grest, float* partial, int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype,
-                           hipStream_t stream, int* rc);
+                           hipStream_t stream, int* rc, int accumulate);
 int dsw_zmix_launch(const void* X, const void* W, const void* bias, void* Z0, void* Zrest, int64_t N, int64_t Fin,
                     int64_t Fout, int64_t K, int dtype, hipStream_t stream, const DswEpiExtra* extra = nullptr);
 int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X, const void* W, const void* bias, void* Y,
@@ -354,7 +353,7 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
                  int64_t nnz, const void* X, const void* T, const void* W, const void* dY, void* dX, void* dW,
                  void* db, void* workspace, int64_t workspace_bytes, int64_t B, int64_t Fin, int64_t Fout,
                  int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan_t, const void* scale,
-                 const void* dX_add, int64_t ld_add) {
+                 const void* dX_add, int64_t ld_add, int accumulate) {
     if (dX_add != nullptr && ld_add < Fin) return DSW_ERR_BAD_ARG;
     const bool extras = scale != nullptr || dX_add != nullptr;
     const DswEpiExtra ex = {scale, dX_add, ld_add, 0};
@@ -382,7 +381,7 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
         int rcm = dsw_cheb_basis_fwd(rowptr_t, colind_t, vals_t, V, nnz, dY, D, B, Fout, K, dtype, stream, plan_t);
         if (rcm == DSW_OK && dX != nullptr) rcm = dsw_zdgrad_launch(dY, D, W, dX, N, Fin, Fout, K, dtype, s, extras ? &ex : nullptr);
         if (rcm == DSW_OK && dW != nullptr)
-            rcm = dsw_wgrad_mixfirst_launch(X, dY, D, dW, db, part, N, Fin, Fout, K, dtype, s);
+            rcm = dsw_wgrad_mixfirst_launch(X, dY, D, dW, db, part, N, Fin, Fout, K, dtype, s, accumulate);
         return rcm;
     }
     const int64_t plane = N * Fin * elem_size(dtype);
@@ -405,7 +404,7 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
         // small aligned fp32 layers: dgrad planes and dW partials from ONE pass over dY (dsw_wgrad_x3.hip, FUSE)
         if (K > 1 && !rowptr_t) return DSW_ERR_BAD_ARG;
         int rcf = DSW_OK;
-        if (dsw_bwd_gemm_fused_try(X, T, Wd, dY, dW, db, dX, G, partial, N, Fin, Fout, K, dtype, s, &rcf)) {
+        if (dsw_bwd_gemm_fused_try(X, T, Wd, dY, dW, db, dX, G, partial, N, Fin, Fout, K, dtype, s, &rcf, accumulate)) {
             if (rcf != DSW_OK) return rcf;
             if (K > 1)
                 rcf = cheb_basis_adj_impl(rowptr_t, colind_t, vals_t, V, nnz, dX, G, B, Fin, K, dtype, stream, plan_t,
@@ -424,7 +423,7 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
         if (rc != DSW_OK) return rc;
     }
     if (dW != nullptr) {
-        rc = dsw_wgrad_launch(X, T, dY, dW, db, partial, N, Fin, Fout, K, dtype, s);
+        rc = dsw_wgrad_launch(X, T, dY, dW, db, partial, N, Fin, Fout, K, dtype, s, accumulate);
     }
     return rc;
 }
@@ -434,7 +433,7 @@ int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* 
                  void* db, void* workspace, int64_t workspace_bytes, int64_t B, int64_t Fin, int64_t Fout,
                  int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan_t) {
     return cheb_bwd_impl(rowptr_t, colind_t, vals_t, V, nnz, X, T, W, dY, dX, dW, db, workspace, workspace_bytes, B, Fin,
-                         Fout, K, dtype, stream, plan_t, nullptr, nullptr, 0);
+                         Fout, K, dtype, stream, plan_t, nullptr, nullptr, 0, 0);
 }
 
 int dsw_cheb_bwd_res(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t, int64_t V,
@@ -443,11 +442,8 @@ int dsw_cheb_bwd_res(const int32_t* rowptr_t, const int32_t* colind_t, const flo
                      int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan_t, const void* scale,
                      const void* dX_add, int64_t ld_add, int accumulate_dw) {
     if (accumulate_dw && B * V == 0) return DSW_OK;        // an empty shard adds nothing
-    dsw_wgrad_set_accumulate(accumulate_dw ? 1 : 0);
-    const int rc = cheb_bwd_impl(rowptr_t, colind_t, vals_t, V, nnz, X, T, W, dY, dX, dW, db, workspace, workspace_bytes, B,
-                                 Fin, Fout, K, dtype, stream, plan_t, scale, dX_add, ld_add);
-    dsw_wgrad_set_accumulate(0);
-    return rc;
+    return cheb_bwd_impl(rowptr_t, colind_t, vals_t, V, nnz, X, T, W, dY, dX, dW, db, workspace, workspace_bytes, B,
+                         Fin, Fout, K, dtype, stream, plan_t, scale, dX_add, ld_add, accumulate_dw ? 1 : 0);
 }
 
 int64_t dsw_rezero_param_grads_workspace_bytes(void) { return dsw_rezero_param_grads_ws_bytes_impl(); }

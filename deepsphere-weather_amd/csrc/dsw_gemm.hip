@@ -29,7 +29,7 @@ int dsw_narrow_dgrad_try(const void* dY, const void* D, const void* W, void* dX,
                          int64_t K, int dtype, hipStream_t stream, int* rc);
 int dsw_narrow_wgrad_try(const void* X, const void* dY, const void* D, void* dW, void* db, float* partial,
                          int64_t max_blocks, int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype,
-                         hipStream_t stream, int* rc);
+                         hipStream_t stream, int* rc, int accumulate);
 int64_t dsw_wgrad_slabs(int64_t N, int64_t Fin, int64_t Fout, int64_t K);
 
 // wgrad on the bf16 matrix pipe (dsw_wgrad_x3.hip); returns 1 if it took the launch
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(32 * NG) void cheb_wgrad_reduce_kernel(const float*
 
 // ------------------------------- host-side launchers (internal) ------------------------------
 int dsw_wgrad_reduce_launch(const float* partial, int64_t S, int64_t Fin, int64_t Fout, int64_t K, void* dW, void* db,
-                            int64_t K_out, int64_t k_off, int db_cols, int dtype, hipStream_t stream);
+                            int64_t K_out, int64_t k_off, int db_cols, int dtype, hipStream_t stream, int accumulate);
 template <bool BF16, int NT>
 static int launch_ts_gemm_nt(const TsGemmParams& P, int col_tiles, hipStream_t stream) {
     constexpr int BNT = 32 * NT;
@@ -724,11 +724,11 @@ int64_t dsw_wgrad_slabs(int64_t N, int64_t Fin, int64_t Fout, int64_t K) {
 // wgrad has K_out = K, k_off = 0; the mix-first backward issues one K = 1 launch per Chebyshev order)
 int dsw_wgrad_launch_ex(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
                         int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
-                        int64_t K_out, int64_t k_off);
+                        int64_t K_out, int64_t k_off, int accumulate);
 
 int dsw_wgrad_launch(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
-                     int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream) {
-    return dsw_wgrad_launch_ex(X, T, dY, dW, db, partial, N, Fin, Fout, K, dtype, stream, K, 0);
+                     int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int accumulate) {
+    return dsw_wgrad_launch_ex(X, T, dY, dW, db, partial, N, Fin, Fout, K, dtype, stream, K, 0, accumulate);
 }
 
 // dy_planes > 1 (narrow mix-first layers, K * F0 <= 64): the dY side is `dy_planes` planes of [N, F0] (plane 0 = dY, the
@@ -736,23 +736,23 @@ int dsw_wgrad_launch(const void* X, const void* T, const void* dY, void* dW, voi
 // K must be 1 - so that dW[f, k, o] = sum_n X[n, f] D_k[n, o] comes out of one pass over X, already in [Fin, K, F0] order.
 static int dsw_wgrad_launch_impl(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
                                  int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
-                                 int64_t K_out, int64_t k_off, const void* dY1, int dy_planes);
+                                 int64_t K_out, int64_t k_off, const void* dY1, int dy_planes, int accumulate);
 
 int dsw_wgrad_launch_ex(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
                         int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
-                        int64_t K_out, int64_t k_off) {
-    return dsw_wgrad_launch_impl(X, T, dY, dW, db, partial, N, Fin, Fout, K, dtype, stream, K_out, k_off, nullptr, 1);
+                        int64_t K_out, int64_t k_off, int accumulate) {
+    return dsw_wgrad_launch_impl(X, T, dY, dW, db, partial, N, Fin, Fout, K, dtype, stream, K_out, k_off, nullptr, 1, accumulate);
 }
 
 static int dsw_wgrad_launch_impl(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
                                  int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
-                                 int64_t K_out, int64_t k_off, const void* dY1, int dy_planes) {
+                                 int64_t K_out, int64_t k_off, const void* dY1, int dy_planes, int accumulate) {
     if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     if (N > 0 && K == 1 && K_out == 1 && k_off == 0 && dy_planes <= 1 && Fout <= 16) {   // narrow dense map (residual linear)
         int rcn = DSW_OK;
         if (dsw_narrow_wgrad_try(X, dY, nullptr, dW, db, partial, dsw_wgrad_slabs(N, Fin, Fout, 1), N, Fin, Fout, 1, dtype,
-                                 stream, &rcn))
+                                 stream, &rcn, accumulate))
             return rcn;
     }
     const int es = dtype == DSW_BF16 ? 2 : 4;
@@ -820,19 +820,16 @@ static int dsw_wgrad_launch_impl(const void* X, const void* T, const void* dY, v
     }
 reduce:
     const int db_cols = dy_planes > 1 ? (int)(Fout / dy_planes) : (int)Fout;
-    return dsw_wgrad_reduce_launch(partial, S, Fin, Fout, K, dW, db, K_out, k_off, db_cols, dtype, stream);
+    return dsw_wgrad_reduce_launch(partial, S, Fin, Fout, K, dW, db, K_out, k_off, db_cols, dtype, stream, accumulate);
 }
 
 // partial [S][K * Fin + 1][Fout] -> dW / db (used by dsw_narrow.hip as well)
-// Set by the C-ABI entry point for the duration of one call on the calling thread (dsw_cheb_bwd_res, accumulate_dw): the
-// reduce stage of EVERY weight-gradient path of that call adds to dW / db instead of overwriting them.
-static thread_local int g_wgrad_accumulate = 0;
-void dsw_wgrad_set_accumulate(int on) { g_wgrad_accumulate = on; }
-
+// accumulate (dsw_cheb_bwd_res, accumulate_dw; an explicit argument of every weight-gradient launcher): the reduce stage
+// adds to dW / db instead of overwriting them.
 int dsw_wgrad_reduce_launch(const float* partial, int64_t S, int64_t Fin, int64_t Fout, int64_t K, void* dW, void* db,
-                            int64_t K_out, int64_t k_off, int db_cols, int dtype, hipStream_t stream) {
+                            int64_t K_out, int64_t k_off, int db_cols, int dtype, hipStream_t stream, int accumulate) {
     const long total = (long)(K * Fin + 1) * Fout;
-    const int acc = g_wgrad_accumulate;
+    const int acc = accumulate ? 1 : 0;
     dim3 rgrid((unsigned)((total + 31) / 32));
     if (total <= 16384 && S > 64) {   // few outputs (<= 512 blocks), many slabs: 32 slab groups per block
         if (dtype == DSW_F32)
@@ -857,11 +854,11 @@ int dsw_wgrad_reduce_launch(const float* partial, int64_t S, int64_t Fin, int64_
 // plain K = 1 wgrad per Chebyshev order.
 int dsw_wgrad_launch_ex(const void* X, const void* T, const void* dY, void* dW, void* db, float* partial,
                         int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
-                        int64_t K_out, int64_t k_off);
+                        int64_t K_out, int64_t k_off, int accumulate);
 static int64_t wgrad_max_slabs(int64_t Fin, int64_t Fout, int64_t K);
 
 int dsw_wgrad_mixfirst_launch(const void* X, const void* dY, const void* D, void* dW, void* db, float* partial,
-                              int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream) {
+                              int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int accumulate) {
     if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     const int es = dtype == DSW_BF16 ? 2 : 4;
@@ -880,22 +877,22 @@ int dsw_wgrad_mixfirst_launch(const void* X, const void* dY, const void* D, void
         if (aligned && dsw_wgrad_x3_try_launch(P, dtype == DSW_BF16 ? 1 : 0, wgrad_max_slabs(Fin, Fout, K), &S3, stream,
                                                &rc3)) {
             if (rc3 != DSW_OK) return rc3;
-            return dsw_wgrad_reduce_launch(partial, S3, Fin, Fout, K, dW, db, K, 0, 1 << 30, dtype, stream);
+            return dsw_wgrad_reduce_launch(partial, S3, Fin, Fout, K, dW, db, K, 0, 1 << 30, dtype, stream, accumulate);
         }
     }
     if (N > 0 && K > 1 && K * Fout <= 16) {  // a handful of output columns: vector-ALU kernel (dsw_narrow.hip)
         int rcn = DSW_OK;
         if (dsw_narrow_wgrad_try(X, dY, D, dW, db, partial, dsw_wgrad_slabs(N, Fin, K * Fout, 1), N, Fin, Fout, K, dtype,
-                                 stream, &rcn))
+                                 stream, &rcn, accumulate))
             return rcn;
     }
     if (N > 0 && K > 1 && K * Fout <= BN)   // narrow output (e.g. the model's last layer, 64 -> 2): all K planes in ONE pass over X
-        return dsw_wgrad_launch_impl(X, nullptr, dY, dW, db, partial, N, Fin, K * Fout, 1, dtype, stream, 1, 0, D, (int)K);
+        return dsw_wgrad_launch_impl(X, nullptr, dY, dW, db, partial, N, Fin, K * Fout, 1, dtype, stream, 1, 0, D, (int)K, accumulate);
     int rc = DSW_OK;
     const size_t dplane = (size_t)N * Fout * es;
     for (int64_t k = 0; k < K && rc == DSW_OK; ++k)
         rc = dsw_wgrad_launch_ex(X, nullptr, k == 0 ? dY : static_cast<const void*>(static_cast<const char*>(D) + (k - 1) * dplane),
-                                 dW, k == 0 ? db : nullptr, partial, N, Fin, Fout, 1, dtype, stream, K, k);
+                                 dW, k == 0 ? db : nullptr, partial, N, Fin, Fout, 1, dtype, stream, K, k, accumulate);
     return rc;
 }
 
@@ -906,7 +903,7 @@ int dsw_wgrad_dgrad_fused_try_launch(WgradParams& P, int bf16, int64_t max_slabs
 
 int dsw_bwd_gemm_fused_try(const void* X, const void* T, const void* W, const void* dY, void* dW, void* db, void* G0,
                            void* Grest, float* partial, int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype,
-                           hipStream_t stream, int* rc) {
+                           hipStream_t stream, int* rc, int accumulate) {
     if ((dtype != DSW_F32 && dtype != DSW_BF16) || N <= 0 || !dW || !G0) return 0;
     WgradParams P{};
     P.X = X; P.T = T; P.plane_stride = (size_t)N * Fin; P.dY = dY; P.partial = partial;
@@ -922,6 +919,6 @@ int dsw_bwd_gemm_fused_try(const void* X, const void* T, const void* W, const vo
     int64_t S = 0;
     if (!dsw_wgrad_dgrad_fused_try_launch(P, dtype == DSW_BF16 ? 1 : 0, wgrad_max_slabs(Fin, Fout, K), &S, stream, rc)) return 0;
     if (*rc != DSW_OK) return 1;
-    *rc = dsw_wgrad_reduce_launch(partial, S, Fin, Fout, K, dW, db, K, 0, 1 << 30, dtype, stream);
+    *rc = dsw_wgrad_reduce_launch(partial, S, Fin, Fout, K, dW, db, K, 0, 1 << 30, dtype, stream, accumulate);
     return 1;
 }

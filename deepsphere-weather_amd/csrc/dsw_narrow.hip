@@ -14,7 +14,7 @@
 #include "../../include/dsw_hip.h"
 
 int dsw_wgrad_reduce_launch(const float* partial, int64_t S, int64_t Fin, int64_t Fout, int64_t K, void* dW, void* db,
-                            int64_t K_out, int64_t k_off, int db_cols, int dtype, hipStream_t stream);
+                            int64_t K_out, int64_t k_off, int db_cols, int dtype, hipStream_t stream, int accumulate);
 
 namespace {
 
@@ -264,7 +264,7 @@ int dsw_narrow_dgrad_try(const void* dY, const void* D, const void* W, void* dX,
 // `max_blocks`: slabs the caller's partial buffer holds ([max_blocks][Fin + 1][K * Fout] floats)
 int dsw_narrow_wgrad_try(const void* X, const void* dY, const void* D, void* dW, void* db, float* partial,
                          int64_t max_blocks, int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype,
-                         hipStream_t stream, int* rc) {
+                         hipStream_t stream, int* rc, int accumulate) {
     if (!narrow_ok(X, dW, N, Fin, Fout, K, dtype) || !dY || (K > 1 && !D) || !partial || max_blocks < 1) return 0;
     const int rpb = NTH / (int)(Fin / 4);
     const size_t lds = (size_t)rpb * (Fin + 1) * K * Fout * 4;
@@ -281,6 +281,6 @@ int dsw_narrow_wgrad_try(const void* X, const void* dY, const void* D, void* dW,
     *rc = dsw_check_launch();
     if (*rc != DSW_OK) return 1;
     // partial rows are (f, j = q * Fout + o) = dW's own [Fin, K, Fout] order: reduce as a K = 1 layer of width K * Fout
-    *rc = dsw_wgrad_reduce_launch(partial, blocks, Fin, K * Fout, 1, dW, db, 1, 0, (int)Fout, dtype, stream);
+    *rc = dsw_wgrad_reduce_launch(partial, blocks, Fin, K * Fout, 1, dW, db, 1, 0, (int)Fout, dtype, stream, accumulate);
     return 1;
 }

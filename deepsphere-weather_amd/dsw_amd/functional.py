@@ -441,16 +441,20 @@ class _HipBackend:
         _native.check(rc, "dsw_cheb_bwd_res")
         return dx, dw, db
 
-    _rpg_ws = {}   # device -> the (zero-initialised, self-re-arming) ticket + partials workspace of dsw_rezero_param_grads
+    # (device, stream) -> the (zero-initialised, self-re-arming) ticket + partials workspace of dsw_rezero_param_grads.
+    # One per STREAM: calls sharing a workspace must be stream-ordered (include/dsw_hip.h), and backward branches may run on
+    # side streams (GradBucket's overlap mode, forked residual branches) - a per-device workspace raced there.
+    _rpg_ws = {}
 
     def rezero_param_grads(self, w, bias, dw_raw, db_raw, scale):
         lib = _native.load()
         ds = torch.empty_like(scale)
         nb = 0 if bias is None else bias.numel()
-        ws = self._rpg_ws.get(w.device)
+        key = (w.device, _stream(w))
+        ws = self._rpg_ws.get(key)
         if ws is None:
-            ws = self._rpg_ws[w.device] = torch.zeros(int(lib.dsw_rezero_param_grads_workspace_bytes()), dtype=torch.uint8,
-                                                      device=w.device)
+            ws = self._rpg_ws[key] = torch.zeros(int(lib.dsw_rezero_param_grads_workspace_bytes()), dtype=torch.uint8,
+                                                 device=w.device)
         with torch.cuda.device(w.device):
             rc = lib.dsw_rezero_param_grads(w.data_ptr(), _ptr(bias), dw_raw.data_ptr(), _ptr(db_raw) if nb else None,
                                             scale.data_ptr(), dw_raw.data_ptr(), _ptr(db_raw) if nb else None, ds.data_ptr(),

@@ -1175,6 +1175,57 @@ def test_bench_two_ranks_self_launched():
     assert "roofline" not in out and "cpu_baseline" not in out          # N = 1 legs only
 
 
+@pytest.mark.parametrize("ranks,global_batch", [(4, 6), (8, 5)])
+def test_bench_many_ranks_ragged_and_empty_shards(ranks, global_batch):
+    """the N > 1 path with 4 and 8 ranks before the driver's 8-GPU box sees it - one GPU here, so the
+    ranks share it over gloo.  `--global-batch` shards with shard_batch: 6 over 4 ranks = 2, 2, 1, 1 (ragged), 5 over 8
+    ranks = five ranks with one sample and three EMPTY shards, whose backward must contribute exact zeros to the
+    exchange.  Every rank ends with bit-identical, non-zero averaged gradients."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["DSW_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--global-batch", str(global_batch),
+                        "--steps", "6", "--warmup", "1", "--min-timed-ms", "20"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == ranks and out["scaling"] == "strong" and out["config"]["global_batch"] == global_batch
+    assert out["grad_sync"]["identical"] and out["grad_sync"]["grad_l2"] > 0, out["grad_sync"]
+    assert out["allreduce"]["bytes"] == 4 * (32 * 3 * 64 + 64)
+    assert out["value"] == pytest.approx(global_batch * 49152 * 32 / (out["ms_per_step"] * 1e-3), rel=1e-6)
+
+
+def test_bench_one_gpu_line_is_the_same_under_torchrun():
+    """`python bench.py --gpus 1` and the driver-style `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`
+    must print the same kind of line (same keys, same config apart from the launcher note, N = 1 legs present in both)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    args = ["--gpus", "1", "--steps", "10", "--warmup", "2", "--min-timed-ms", "50", "--no-cpu-baseline"]
+    plain = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=900)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    tr = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                         "127.0.0.1", "--master-port", "29731", os.path.join(root, "bench.py"), *args],
+                        env=env, capture_output=True, text=True, timeout=900)
+    assert tr.returncode == 0, tr.stderr[-2000:]
+    a, b = (json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]) for r in (plain, tr))
+    assert sorted(a) == sorted(b), (sorted(a), sorted(b))
+    assert a["n_gpus"] == b["n_gpus"] == 1 and a["scaling"] == b["scaling"] == "weak"
+    ca, cb = dict(a["config"]), dict(b["config"])
+    ca.pop("launcher", None); cb.pop("launcher", None)
+    assert ca == cb, (ca, cb)
+    assert "roofline" in a and "roofline" in b and sorted(a["roofline"]) == sorted(b["roofline"])
+    assert abs(a["ms_per_step"] - b["ms_per_step"]) <= 0.15 * a["ms_per_step"]
+
+
 def test_bench_one_rank_world_captures_the_exchange():
     """The RCCL exchange recorded INTO the step graph (what N > 1 runs replay): a one-rank RCCL world on this box
     (DSW_FORCE_GRAD_SYNC=1).  The captured graph must reproduce the eager step + all-reduce, and the bench must say which
