@@ -206,11 +206,21 @@ def test_unet_nside32_batch8_vs_cpu_restatement():
     # ReLU ties: of ~4e8 pre-activations a handful (|z| ~ 1e-7) fall on the other side of zero in a second correct fp32
     # evaluation; on the 768-node level one of them moves a weight-gradient element by 1e-5 .. 1e-4.  The device run
     # takes the reference run's decision for exactly those elements (they must be < 1e-4, else the hook raises)
+    # first an UN-PINNED device run against the same checker with a loose gate: the pinning below must matter for the tie
+    # elements only - without it the forward agrees as tightly as with it, and the gradients to 1e-3 (one flipped decision
+    # with |z| ~ 1e-7 on the 768-node level moves a weight-gradient element by up to ~1e-4 of the tensor's maximum)
+    model = model.to(DEV)
+    y_un, loss_un, g_un = run(model, DEV)
+    un = {"y": orc.max_rel_err(y_un, y_ref), "loss": abs(loss_un - loss_ref) / max(1.0, abs(loss_ref)),
+          "grads": max(orc.max_rel_err(g_un[n], g_ref[n]) for n in names)}
+    print("un-pinned device run vs the fp64-backed run:", un)
+    assert un["y"] <= 1e-5 and un["loss"] <= 1e-5 and un["grads"] <= 1e-3, un
     flipped, handles = pin_relu_masks(model, masks)
-    y_dev, loss_dev, g_dev = run(model.to(DEV), DEV)
+    y_dev, loss_dev, g_dev = run(model, DEV)
     for h in handles:
         h.remove()
     print("ReLU decisions that differed between the fp64-backed and the device run:", flipped)
+    assert flipped["n"] <= max(8, 2e-7 * flipped["total"]), flipped
     # weight tensors [Fin, K, Fout] / [Fout, Fin] vs the 1-D ones (biases, ReZero scalars): the latter are plain sums of
     # ~1e6 signed products whose fp32 evaluation cancels heavily - the reference's own fp32 CPU path is 1.2e-4 off fp64
     # there (recorded as torch32_vs_f64_*), so they get the looser bound

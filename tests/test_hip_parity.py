@@ -982,7 +982,7 @@ def test_unet_variants_vs_oracle_backed_run(bn_before_act, pool_method):
     flipped, _h = pin_relu_masks(model, masks)
     y_dev, g_dev = run(model.to(DEV), DEV)
     print("ReLU decisions that differed (|z| < 1e-4):", flipped)
-    assert flipped["n"] <= 8, flipped
+    assert flipped["n"] <= max(8, 2e-6 * flipped["total"]), flipped
     assert set(g_dev) == set(g_ref)
     if pool_method == "maxval":
         # an arg-max is discontinuous: where two candidates tie to within fp32 rounding, the fp32 device run and the

@@ -528,12 +528,15 @@ def _relu_output_modules(model):
     return out
 
 
-def record_relu_masks(model):
-    """Forward hooks that keep the sign pattern of every ReLU output (per module and call).  Returns (masks, handles)."""
+def record_relu_masks(model, tiny=1e-4):
+    """Forward hooks that keep, per module and call, the sign pattern of every ReLU output AND which outputs are below
+    `tiny` (for a positive output the ReLU result IS the pre-activation: a second run that puts such an element at zero
+    is off by at least that much).  Returns (masks, handles); masks[name][call] = (positive, small)."""
     masks, handles = {}, []
     for name, mod in _relu_output_modules(model):
         def hook(_m, _a, out, name=name):
-            masks.setdefault(name, []).append((out.detach() > 0).cpu())
+            o = out.detach()
+            masks.setdefault(name, []).append(((o > 0).cpu(), (o < tiny).cpu()))
         handles.append(mod.register_forward_hook(hook))
     return masks, handles
 
@@ -543,22 +546,28 @@ def pin_relu_masks(model, masks, tiny=1e-4):
     evaluations of a network agree to ~1e-6 per element, which still leaves the odd pre-activation with |z| ~ 1e-7 on
     different sides of zero; on a 48- or 192-node level ONE such element moves a weight gradient by 1e-2 (measured:
     uconv2.convblock1, |z| = 7e-7 -> 6e-2), so an element-wise gradient comparison would test the dice, not the kernels.
-    Only elements whose two evaluations disagree in sign are touched, and they must be smaller than `tiny` (else the
-    runs really differ and the hook raises).  Returns a counter of the decisions that differed."""
-    flipped = {"n": 0, "max_abs": 0.0}
+    Only elements whose two evaluations disagree in sign are touched, and BOTH evaluations must be smaller than `tiny`
+    there, else the runs really differ and the hook raises: where this run is positive and the recorded one was not, its
+    own value is checked; where this run is at zero and the recorded one was positive - this run's PRE-activation was
+    negative by an unknown amount, invisible in its ReLU output - the recorded value must have been below
+    `tiny`.  Returns a counter of the decisions that differed (callers bound "n" against "total")."""
+    flipped = {"n": 0, "max_abs": 0.0, "total": 0}
     handles = []
     for name, mod in _relu_output_modules(model):
         state = {"call": 0}
 
         def hook(_m, _a, out, name=name, state=state):
-            want = masks[name][state["call"]].to(out.device)
+            want, small = (t.to(out.device) for t in masks[name][state["call"]])
             state["call"] += 1
             y = out.data                          # .data: not an autograd-visible edit of the saved ReLU output
             dis = (y > 0) != want
+            flipped["total"] += y.numel()
             n = int(dis.sum())
             if n:
                 mag = float(y[dis].abs().max())
                 assert mag < tiny, (name, n, mag)
+                # this run at zero, the recorded run positive: the recorded value bounds how negative this run may have been
+                assert bool(small[dis & want].all()), (name, "a pre-activation is negative here and was >= %g in the checker run" % tiny)
                 flipped["n"] += n
                 flipped["max_abs"] = max(flipped["max_abs"], mag)
                 y[dis & want] = 1e-30
@@ -591,6 +600,11 @@ def pin_g9_ties(model, g):
                 pos = torch.from_numpy(rows[:, 3].astype(bool)).to(out.device)
                 cur = flat[idx]
                 flipped["n"] += int(((cur > 0) != pos).sum())
+                flipped["ties"] = flipped.get("ties", 0) + len(rows)
+                # the fixture lists an element only because the reference's |z| was < 1e-4: whatever this run computed there
+                # must be just as small when it is positive (a zero here can hide a negative pre-activation of any size only
+                # if the reference itself was within 1e-4 of zero - which is what makes it a listed tie)
+                assert float(cur.abs().max()) < 1e-3, float(cur.abs().max())
                 flat[idx] = torch.where(pos, cur.clamp_min(1e-30), torch.zeros_like(cur))
         handles.append(block.register_forward_hook(hook))
     return flipped, handles
