@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--global-batch", type=int, default=None,
                     help="STRONG scaling: this many samples in total, sharded over the ranks with dsw_amd.parallel.shard_batch "
                          "(ragged and empty shards allowed); default: the workload's batch PER GPU (weak scaling)")
+    ap.add_argument("--pmc-leg", default=None, choices=["fwd", "adj", "pool"],
+                    help="profiling aid (tools/pmc_traffic.sh): run ONLY that leg of the roofline measurement - the forward "
+                         "recurrence, the adjoint recurrence or the pooling products of the workload - and exit; every "
+                         "dispatch of the run then belongs to the leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
@@ -151,7 +155,19 @@ def _native_lib():
     return _native.load()
 
 
-def roofline_leg(layer, x, steps, warmup, traffic_key=None):
+def _traffic(traffic_key, leg):
+    """Committed PMC measurement of one leg (profiles/spmm_traffic.json, tools/pmc_traffic.sh): HBM bytes per call of the
+    leg and the launches it made, or None."""
+    tpath = os.path.join(REPO, "profiles", "spmm_traffic.json")
+    if not traffic_key or not os.path.exists(tpath):
+        return None
+    try:
+        return json.load(open(tpath)).get(traffic_key, {}).get(leg)
+    except Exception:
+        return None
+
+
+def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None):
     """Time exactly the SpMM launches of one fwd+bwd (K-1 basis hops + K-1 adjoint hops)."""
     from dsw_amd import functional as F_
 
@@ -186,6 +202,12 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None):
         fwd()
         adj()
 
+    if pmc_leg in ("fwd", "adj"):     # profiling aid: this leg only
+        fn = fwd if pmc_leg == "fwd" else adj
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return {"pmc_leg": pmc_leg, "calls": steps}
     for _ in range(warmup):
         launches()
     torch.cuda.synchronize()
@@ -203,22 +225,16 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None):
             reps.append(t0.elapsed_time(t1) * 1e-3 / steps)
         return sorted(reps)[1]
 
-    hops = 2 * (K - 1)                      # operator applications per step (forward + adjoint)
     pairs = (K - 1 + 1) // 2                # launches of a pairwise-fused recurrence
-    n_launch = ((K - 1) if pp is None else pairs) + ((K - 1) if ppt is None else pairs)
-    avg_s = timed(launches) / n_launch
+
+    def n_launches(plan):                   # launches of one recurrence: plain hops, staged hops (hops == 1) or fused pairs
+        return (K - 1) if (plan is None or plan.hops == 1) else pairs
+
+    n_fwd, n_adj = n_launches(_k1), n_launches(_k2)
     fwd_b, bwd_b = spmm_algorithmic_bytes(E, Lb, K)
-    bytes_per_launch = (fwd_b + bwd_b) / n_launch
-    achieved = bytes_per_launch / avg_s / 1e9
-    # forward recurrence alone (the north-star gate)
+    # the two recurrences, each alone: the forward one is the north-star gate, the adjoint one runs in every step
     fwd_s = timed(fwd)
-    traffic = None   # HBM bytes per launch from the PMC passes (tools/prof_pmc.sh + tools/make_traffic_json.py)
-    tpath = os.path.join(REPO, "profiles", "spmm_traffic.json")
-    if traffic_key and os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(traffic_key, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    adj_s_leg = timed(adj)
     out_mfma = mfma_leg(layer, x, T, steps)
     # whole forward through the C ABI (dsw_cheb_fwd): at the north-star shape ONE launch (two hops + channel mix,
     # dsw_fwd3.hip); its algorithmic bytes = the forward recurrence (5E + 2Lb for K = 3) + the mix (K E in, N Fout s out)
@@ -287,40 +303,139 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None):
 
         in_step = [
             entry("forward (dsw_cheb_fwd)", "cheb3_fwd_fused: hops + channel mix + bias in ONE launch where the shape has "
-                  "it (fp32, K=3, 32-channel chunks), else spmm2_fused / spmm_csr hops + ts_gemm* mix", wf_s, wf_bytes,
+                  "it (fp32, K=3, 32-channel chunks), else spmm2_fused / spmm1_dma / spmm_csr hops + ts_gemm* mix", wf_s, wf_bytes,
                   {"compulsory_bytes": out_fwd["compulsory_bytes"]}),
             entry("backward GEMM pass (dsw_cheb_bwd minus its adjoint launches)",
                   "cheb_wgrad_x3<FUSE> (dW partials + db + dgrad planes in one pass) or cheb_wgrad* + ts_gemm* dgrad, "
                   "+ cheb_wgrad_reduce", gemm_s, gemm_bytes,
                   {"flops": gemm_flops, "TFLOPs": round(gemm_flops / gemm_s / 1e12, 1),
                    "bytes_note": "K basis planes + dY read once, K dgrad planes written (separate launches re-read dY)"}),
-            entry("adjoint recurrence (dsw_cheb_basis_adj)", "spmm2_fused adjoint pair(s)" if ppt is not None
-                  else "spmm_csr x%d" % (K - 1), adj_s, bwd_b),
+            entry("adjoint recurrence (dsw_cheb_basis_adj)", "spmm_csr x%d" % (K - 1) if ppt is None else
+                  "spmm1_dma / spmm1_staged x%d" % (K - 1) if _k2.hops == 1 else "spmm2_fused adjoint pair(s)", adj_s, bwd_b),
         ]
         tot = wf_s + bwd_s
         for d in in_step:
             d["share_of_fwd_bwd"] = round(d["avg_us"] * 1e-6 / tot, 3)
+    # ---- the headline entry: the SpMM recurrence launches that a timed step really makes --------------------------------
+    # the adjoint recurrence always; the forward recurrence only where the step launches it (not at the north-star shape,
+    # whose forward is ONE launch with the hops inside - that kernel is in_step[0] and whole_forward)
+    fwd_path = int(lib.dsw_cheb_fwd_path(ppf, C, Fout, K, dcode))
+    path_names = {0: "plain hops + GEMM", 1: "fused hop pairs + GEMM", 2: "staged hops + GEMM", 3: "one launch (hops + channel mix)",
+                  4: "mix-first (recurrence on the output channels)"}
+    fwd_rec_in_step = fwd_path in (0, 1, 2)
+    legs = [("adj", n_adj, adj_s_leg, bwd_b)] + ([("fwd", n_fwd, fwd_s, fwd_b)] if fwd_rec_in_step else [])
+    n_in = sum(l[1] for l in legs)
+    t_in = sum(l[2] for l in legs)
+    b_in = sum(l[3] for l in legs)
+    achieved = b_in / t_in / 1e9
+    moved = [_traffic(traffic_key, l[0]) for l in legs]
+    traffic = None if any(m is None for m in moved) else sum(m["hbm_bytes_per_call"] for m in moved) / n_in
+    kname = lambda plan, tr: ("spmm_csr_rowsplit x%d" % (K - 1) if plan is None else
+                              "spmm1_dma / spmm1_staged x%d (one staged launch per hop)" % (K - 1) if plan.hops == 1 else
+                              "spmm2_fused x%d (hops pairwise in one launch)" % pairs) + (" on L^T" if tr else "")
+
+    def rec_entry(leg, plan, tr, n, sec, nbytes):
+        m = _traffic(traffic_key, leg)
+        d = {"kernels": kname(plan, tr), "launches": n, "us": round(sec * 1e6, 2), "algorithmic_bytes": int(nbytes),
+             "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4),
+             # a launch that keeps an intermediate plane on chip moves fewer bytes than SURVEY 8d's unfused pass count: the
+             # fraction by algorithmic bytes may then exceed what the memory system delivered - bytes_moved says what it did
+             "fused": bool(plan is not None and plan.hops != 1),
+             "bytes_moved": None if m is None else int(m["hbm_bytes_per_call"]),
+             "frac_counter": None if m is None else round(m["hbm_bytes_per_call"] / sec / 1e9 / HBM_PEAK_GBS, 4)}
+        return d
+
     return {
         "bound": "hbm",
-        "kernel": ("SpMM recurrence launches (the north-star gate): forward %s + adjoint %s, %d launches; the ADJOINT "
-                   "launches are in every timed step, the forward launches only where the one-launch forward does not "
-                   "apply - what a step really runs is listed under in_step" % (
-                       "spmm2_fused" if pp is not None else "spmm_csr x%d" % (K - 1),
-                       "spmm2_fused" if ppt is not None else "spmm_csr x%d" % (K - 1), n_launch)),
+        "kernel": "SpMM recurrence launches of a timed step: adjoint recurrence (%s)%s; forward path of this layer: %s" % (
+            kname(_k2, True), (" + forward recurrence (%s)" % kname(_k1, False)) if fwd_rec_in_step else "", path_names.get(fwd_path)),
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "fused": any(p is not None and p.hops != 1 for p in ((_k2, _k1) if fwd_rec_in_step else (_k2,))),
+        "traffic": None if traffic is None else int(traffic),
+        "frac_counter": None if traffic is None else round(traffic * n_in / t_in / 1e9 / HBM_PEAK_GBS, 4),
         "traffic_source": (None if traffic is None else
-                           "profiles/spmm_traffic.json: HBM bytes per launch from separate rocprofv3 --pmc passes "
-                           "(2 x FETCH_SIZE + WRITE_SIZE, tools/prof_pmc.sh); a committed measurement, not read in this run"),
-        "real_traffic_GBs": (None if traffic is None else round(traffic / avg_s / 1e9, 1)),
-        "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 2),
+                           "profiles/spmm_traffic.json: HBM bytes per launch from separate rocprofv3 --pmc passes over exactly "
+                           "these launches (2 x FETCH_SIZE + WRITE_SIZE, tools/pmc_traffic.sh); a committed measurement, not "
+                           "read in this run"),
+        "bytes_per_launch": int(b_in / n_in), "avg_launch_us": round(t_in / n_in * 1e6, 2), "launches": n_in,
         "launch_timing": "HIP events on the launch stream; median of 3 regions of %d back-to-back calls" % steps,
+        "definition": "achieved = SURVEY 8d algorithmic bytes of these launches / their time; frac_counter = measured HBM bytes / "
+                      "the same time / 8 TB/s",
+        "forward_recurrence": dict(rec_entry("fwd", _k1, False, n_fwd, fwd_s, fwd_b), in_step=fwd_rec_in_step,
+                                   note="north-star gate: >= 0.60 of 8 TB/s on the K = 3 forward recurrence"),
+        "adjoint_recurrence": dict(rec_entry("adj", _k2, True, n_adj, adj_s_leg, bwd_b), in_step=True),
         "fwd_recurrence_us": round(fwd_s * 1e6, 2),
         "fwd_recurrence_frac": round(fwd_b / fwd_s / 1e9 / HBM_PEAK_GBS, 4),
         "in_step": in_step,
         "mfma": out_mfma,
         "whole_forward": out_fwd,
     }
+
+
+def pooling_leg(model, run_forward, steps, traffic_key=None, pmc_leg=None):
+    """The interpolation-pooling products of the workload (RemapBlock: pool / unpool and their transposed backward), each
+    with its own shape: bytes = input rows + output rows + operator (int32 column + fp32 value per entry + row pointers),
+    time = HIP events around `steps` back-to-back calls.  north_star names this kernel; the U-Net has 4 distinct products
+    (x2 directions), workload c5 the cross-sampling pair."""
+    from dsw_amd import functional as F_
+    from modules.layers import RemapBlock
+
+    seen = []
+    hooks = []
+    for name, mod in model.named_modules():
+        if isinstance(mod, RemapBlock):
+            def hook(m, args, out, name=name):
+                seen.append((name, m, tuple(args[0].shape), args[0].dtype))
+            hooks.append(mod.register_forward_hook(hook))
+    with torch.no_grad():
+        run_forward()
+    for h in hooks:
+        h.remove()
+    stream = torch.cuda.current_stream()
+    entries, calls = [], []
+    for name, mod, shape, dt in seen:
+        op = F_.get_operator(mod.remap_matrix)
+        opt = op.transpose()
+        B, Vs, C = shape
+        xs = torch.randn(shape, device=mod.remap_matrix.device, dtype=dt)
+        dy = torch.randn((B, op.shape[0], C), device=xs.device, dtype=dt)
+        es = xs.element_size()
+        for what, o, t in (("forward", op, xs), ("backward (transposed matrix)", opt, dy)):
+            calls.append((name, what, o, t))
+            nbytes = (t.numel() + B * o.shape[0] * C) * es + o.nnz * 8 + 4 * (o.shape[0] + 1)
+            entries.append({"layer": name, "product": what, "rows_out": o.shape[0], "rows_in": o.shape[1], "channels": C,
+                            "nnz_per_row": round(o.nnz / o.shape[0], 1), "algorithmic_bytes": int(nbytes)})
+    if pmc_leg == "pool":
+        for _ in range(steps):
+            for _n, _w, o, t in calls:
+                F_.sparse_remap(o, t)
+        torch.cuda.synchronize()
+        return {"pmc_leg": "pool", "calls": steps}
+    tot_s = tot_b = 0.0
+    for e, (_n, _w, o, t) in zip(entries, calls):
+        for _ in range(3):
+            F_.sparse_remap(o, t)
+        torch.cuda.synchronize()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record(stream)
+        for _ in range(steps):
+            F_.sparse_remap(o, t)
+        t1.record(stream)
+        torch.cuda.synchronize()
+        sec = t0.elapsed_time(t1) * 1e-3 / steps
+        e["us"] = round(sec * 1e6, 2)
+        e["frac"] = round(e["algorithmic_bytes"] / sec / 1e9 / HBM_PEAK_GBS, 4)
+        tot_s += sec
+        tot_b += e["algorithmic_bytes"]
+    m = _traffic(traffic_key, "pool")
+    return {"kernel": "spmm_csr_rowsplit (+ the whole-wave path for rows beyond 64 entries): RemapBlock products",
+            "bound": "hbm", "products": entries, "us_per_step": round(tot_s * 1e6, 2), "algorithmic_bytes": int(tot_b),
+            "frac": round(tot_b / max(tot_s, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
+            "bytes_moved": None if m is None else int(m["hbm_bytes_per_call"]),
+            "frac_counter": None if m is None else round(m["hbm_bytes_per_call"] / max(tot_s, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
+            "note": "tensors of these products are 2-50 MB: they live in the 256 MB Infinity Cache between the layers, so the "
+                    "counter bytes can be far below the algorithmic ones"}
 
 
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # dense matrix peaks of MI355X (MI355X_MICROARCH.md)
@@ -544,6 +659,23 @@ def launch_ranks(n, argv):
     return 1
 
 
+def roofline_target(args, model, x, B, V, device):
+    """The SpMM recurrence the roofline entry is measured on: the workload's dominant ConvCheb layer (whole-model
+    workloads: the layer with the most node-channels) with activations of its own shape, and the key of its committed
+    counter measurement in profiles/spmm_traffic.json."""
+    if args.workload == "unet":
+        rl_layer, rl_what = model.conv1.convblock2.conv, "conv1.convblock2.conv (V=%d, 64->128)" % V
+        rl_x = torch.randn(B, V, rl_layer.in_channels, device=device)
+    elif args.workload == "c5":
+        rl_layer, rl_what = model.conv_fine, "conv_fine (equiangular V=%d, 32->32)" % V
+        rl_x = x.detach()
+    else:
+        rl_layer, rl_what, rl_x = model, None, x.detach()
+    tkey = (args.workload if (rl_what is not None or args.knn == 8)
+            else "ns_k20" if (args.workload == "ns" and args.knn == 20) else None)
+    return rl_layer, rl_what, rl_x, tkey
+
+
 def _arm_watchdog(rank, world, limit=None, what="the run"):
     """A rank of an N > 1 run that is still alive after DSW_BENCH_TIMEOUT seconds (a collective that never completes)
     exits with an error instead of holding the node: the launcher (ours, or torchrun) then tears the job down.  Also
@@ -640,6 +772,14 @@ def main():
             x.grad = None
             model(x).backward(gy)
 
+    if args.pmc_leg is not None:       # profiling aid (tools/pmc_traffic.sh): one leg of the roofline measurement, no line
+        rl_layer, _what, rl_x, _tkey = roofline_target(args, model, x, B, V, device)
+        if args.pmc_leg == "pool":
+            res = pooling_leg(model, lambda: model(x.detach()), 20, pmc_leg="pool") if args.workload in ("unet", "c5") else {}
+        else:
+            res = roofline_leg(rl_layer, rl_x, 20, 0, pmc_leg=args.pmc_leg)
+        print(json.dumps(res), flush=True)
+        return
     # N > 1: the parameter gradients live in one flat bucket (no pack / unpack copies around the collective); RCCL averages
     # it in place.  The exchange is part of the step: captured INTO the step graph when RCCL is the backend, issued
     # right after the replay otherwise (gloo, or DSW_BENCH_COLLECTIVES=eager).
@@ -872,22 +1012,15 @@ def main():
         out["per_step_us"] = {"n": n_ev, "median": round(us[n_ev // 2], 1), "p10": round(us[n_ev // 10], 1),
                               "p90": round(us[(9 * n_ev) // 10], 1)}
     if rank == 0 and world == 1:
-        # the SpMM recurrence of the workload's dominant ConvCheb layer (whole-model workloads: the layer with the
-        # most node-channels) with its own activations; cpu_baseline = the oracle's torch restatement of the SAME workload
-        if args.workload == "unet":
-            rl_layer, rl_what = model.conv1.convblock2.conv, "conv1.convblock2.conv (V=%d, 64->128)" % V
-            rl_x = torch.randn(B, V, rl_layer.in_channels, device=device)
-        elif args.workload == "c5":
-            rl_layer, rl_what = model.conv_fine, "conv_fine (equiangular V=%d, 32->32)" % V
-            rl_x = x.detach()
-        else:
-            rl_layer, rl_what, rl_x = model, None, x.detach()
+        # roofline: the SpMM recurrence of the workload's dominant ConvCheb layer; cpu_baseline: the oracle's torch
+        # restatement of the SAME workload
+        rl_layer, rl_what, rl_x, tkey = roofline_target(args, model, x, B, V, device)
         if not args.no_roofline:
-            out["roofline"] = roofline_leg(rl_layer, rl_x, max(10, args.steps), 5,
-                                           traffic_key=(args.workload if (rl_what is not None or args.knn == 8)
-                                                        else "ns_k20" if (args.workload == "ns" and args.knn == 20) else None))
+            out["roofline"] = roofline_leg(rl_layer, rl_x, max(10, args.steps), 5, traffic_key=tkey)
             if rl_what is not None:
                 out["roofline"]["kernel"] += "; layer " + rl_what
+            if args.workload in ("unet", "c5"):
+                out["roofline"]["pooling"] = pooling_leg(model, lambda: model(x.detach()), max(10, args.steps), traffic_key=tkey)
         if not args.no_cpu_baseline:
             if args.workload == "unet":
                 out["cpu_baseline"] = cpu_baseline_unet(model, wl, V)

@@ -53,6 +53,7 @@ int dsw_zmix_launch(const void* X, const void* W, const void* bias, void* Z0, vo
 int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X, const void* W, const void* bias, void* Y,
                             void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
                             int* rc, int relu);
+int dsw_cheb3_fwd_fused_eligible(const dsw_hop2_plan* plan, int64_t Fin, int64_t Fout, int64_t K, int dtype);
 int dsw_zdgrad_launch(const void* dY, const void* D, const void* W, void* dX, int64_t N, int64_t Fin, int64_t Fout,
                       int64_t K, int dtype, hipStream_t stream, const DswEpiExtra* extra = nullptr);
 
@@ -241,6 +242,16 @@ int dsw_cheb_mix_fwd(const void* X, const void* T, const void* W, const void* bi
 }
 
 int dsw_cheb_mix_first(int64_t Fin, int64_t Fout, int64_t K) { return mix_first(Fin, Fout, K) ? 1 : 0; }
+
+int dsw_cheb_fwd_path(const dsw_hop2_plan* plan, int64_t Fin, int64_t Fout, int64_t K, int dtype) {
+    if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
+    if (Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
+    if (mix_first(Fin, Fout, K)) return DSW_FWD_MIX_FIRST;
+    if (dsw_cheb3_fwd_fused_eligible(plan, Fin, Fout, K, dtype)) return DSW_FWD_ONE_LAUNCH;
+    if (K > 1 && plan != nullptr && dsw_spmm1s_supported(plan, Fin, dtype)) return DSW_FWD_STAGED_HOPS;
+    if (K > 2 && plan != nullptr && dsw_spmm2_supported(plan, Fin, dtype)) return DSW_FWD_FUSED_PAIRS;
+    return DSW_FWD_PLAIN_HOPS;
+}
 
 static int cheb_fwd_impl(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V, int64_t nnz,
                          const void* X, const void* W, const void* bias, void* Y, void* T, int64_t B, int64_t Fin,

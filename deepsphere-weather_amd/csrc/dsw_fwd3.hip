@@ -369,23 +369,29 @@ int launch_ncb(const Fwd3Args& A, long nwg, size_t lds, hipStream_t stream) {
 
 }  // namespace
 
-// Runs the whole forward in one launch if the shape / plan allow it.  Returns 1 if it took the call (*rc = status),
-// 0 if the caller must use the generic sequence (basis launches + channel-mix GEMM).
-int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X, const void* W, const void* bias, void* Y,
-                            void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
-                            int* rc, int relu) {
+// 1 if the one-launch forward exists for this layer shape and plan (pointer alignment aside)
+int dsw_cheb3_fwd_fused_eligible(const dsw_hop2_plan* plan, int64_t Fin, int64_t Fout, int64_t K, int dtype) {
     static const char* env = dsw_diag_env("DSW_FWD_FUSED");   // "0": generic sequence (diagnostics / A-B)
     if (env && env[0] == '0') return 0;
     if (dtype != DSW_F32 || K != 3 || Fin != 32 || (Fout != 32 && Fout != 64)) return 0;   // (Fout = 128 compiles but spills)
     if (!plan || plan->tile_rows != 64 || !dsw_spmm2_supported(plan, Fin, dtype)) return 0;
     if (plan->max_n2 > 255) return 0;                       // u8 list positions in the ELL
+    if (fwd3_lds_bytes(plan) > 80 * 1024) return 0;         // two workgroups per CU or not at all
+    const int nst = (plan->max_n2 + RPP - 1) / RPP, ns1 = (plan->max_n1 + RPP - 1) / RPP;
+    return (nst > 4 || ns1 > nst) ? 0 : 1;
+}
+
+// Runs the whole forward in one launch if the shape / plan allow it.  Returns 1 if it took the call (*rc = status),
+// 0 if the caller must use the generic sequence (basis launches + channel-mix GEMM).
+int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X, const void* W, const void* bias, void* Y,
+                            void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
+                            int* rc, int relu) {
+    if (!dsw_cheb3_fwd_fused_eligible(plan, Fin, Fout, K, dtype)) return 0;
     if (!dsw_aligned16(X) || !dsw_aligned16(Y) || !dsw_aligned16(W) || (bias && !dsw_aligned16(bias)) ||
         (T && !dsw_aligned16(T)))
         return 0;
     const size_t lds = fwd3_lds_bytes(plan);
-    if (lds > 80 * 1024) return 0;                          // two workgroups per CU or not at all
     const int nst = (plan->max_n2 + RPP - 1) / RPP, ns1 = (plan->max_n1 + RPP - 1) / RPP;
-    if (nst > 4 || ns1 > nst) return 0;
     if (V <= 0 || B <= 0) { *rc = DSW_OK; return 1; }
     Fwd3Args A;
     A.tile_meta = plan->tile_meta; A.s2_rows = plan->s2_rows; A.lrowptr = plan->lrowptr;

@@ -155,6 +155,20 @@ int dsw_cheb_mix_fwd(const void* X, const void* T, const void* W, const void* bi
  * (rows of Fout vs Fin channels) and to know whether T comes back as the basis. */
 int dsw_cheb_mix_first(int64_t Fin, int64_t Fout, int64_t K);
 
+/* Which launch sequence dsw_cheb_fwd takes for a layer shape and plan (pointer alignment aside) - what a profile of a
+ * training step should be read against:
+ *   DSW_FWD_PLAIN_HOPS   one dsw_spmm_csr launch per hop, then the channel-mix GEMM
+ *   DSW_FWD_FUSED_PAIRS  hops pairwise in the two-hop kernel (plan->hops == 2), then the GEMM
+ *   DSW_FWD_STAGED_HOPS  one staged launch per hop (plan->hops == 1: dense stencils), then the GEMM
+ *   DSW_FWD_ONE_LAUNCH   both hops AND the channel mix in one launch (fp32, K = 3, Fin = 32, Fout 32 / 64, two-hop plan)
+ *   DSW_FWD_MIX_FIRST    channel mix first, recurrence on the Fout channels (dsw_cheb_mix_first) */
+#define DSW_FWD_PLAIN_HOPS 0
+#define DSW_FWD_FUSED_PAIRS 1
+#define DSW_FWD_STAGED_HOPS 2
+#define DSW_FWD_ONE_LAUNCH 3
+#define DSW_FWD_MIX_FIRST 4
+int dsw_cheb_fwd_path(const dsw_hop2_plan* plan, int64_t Fin, int64_t Fout, int64_t K, int dtype);
+
 /* Whole ConvCheb.forward (layers.py:365-376) = dsw_cheb_basis_fwd + dsw_cheb_mix_fwd.
  * T ([K-1,B,V,Fin], may be NULL iff K == 1) receives the basis and is what backward needs.
  * When dsw_cheb_mix_first(Fin, Fout, K): T is required as SCRATCH of the same size (its content afterwards is
