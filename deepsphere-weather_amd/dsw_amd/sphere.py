@@ -160,12 +160,102 @@ def equiangular_vec(nlat: int, nlon: int):
     return xyz, lat2, lon2
 
 
-def knn_graph_laplacian(coords: np.ndarray, k: int, lap_type: str = "normalized"):
+def icosahedral_vec(m: int, dual: bool = False) -> np.ndarray:
+    """Vertices of the icosahedron with every edge cut into ``m`` segments and every face into ``m^2`` triangles,
+    projected onto the sphere (public geometry; pygsp's ``SphereIcosahedral(subdivisions=m)``): ``10 m^2 + 2`` points,
+    or the ``20 m^2`` face centres with ``dual``.  Order: face by face (points shared with an earlier face are not
+    repeated), i.e. consecutive rows are neighbours on the sphere."""
+    if m < 1:
+        raise ValueError("subdivisions must be >= 1")
+    phi = (1.0 + np.sqrt(5.0)) / 2.0
+    base = np.array([[-1, phi, 0], [1, phi, 0], [-1, -phi, 0], [1, -phi, 0], [0, -1, phi], [0, 1, phi],
+                     [0, -1, -phi], [0, 1, -phi], [phi, 0, -1], [phi, 0, 1], [-phi, 0, -1], [-phi, 0, 1]], dtype=np.float64)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    faces = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+             (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7),
+             (9, 8, 1)]
+    pts = []
+    for a, b, c in faces:
+        A, Bv, C = base[a], base[b], base[c]
+        if dual:     # centres of the m^2 small triangles
+            for i in range(m):
+                for j in range(m - i):
+                    p0 = (A * (m - i - j) + Bv * i + C * j)
+                    p1 = (A * (m - i - j - 1) + Bv * (i + 1) + C * j)
+                    p2 = (A * (m - i - j - 1) + Bv * i + C * (j + 1))
+                    pts.append((p0 + p1 + p2) / 3.0)
+                    if i + j < m - 1:
+                        p3 = (A * (m - i - j - 2) + Bv * (i + 1) + C * (j + 1))
+                        pts.append((p1 + p2 + p3) / 3.0)
+        else:
+            for i in range(m + 1):
+                for j in range(m + 1 - i):
+                    pts.append(A * (m - i - j) + Bv * i + C * j)
+    pts = np.asarray(pts)
+    pts /= np.linalg.norm(pts, axis=1, keepdims=True)
+    if not dual:     # vertices on shared edges / corners appear once per face: keep the first occurrence
+        key = np.round(pts * 1e9).astype(np.int64)
+        _, first = np.unique(key, axis=0, return_index=True)
+        pts = pts[np.sort(first)]
+    return pts
+
+
+def cubed_vec(m: int, spacing: str = "equiangular") -> np.ndarray:
+    """Cell centres of the cubed sphere with ``m x m`` cells per face (``6 m^2`` points; pygsp's ``SphereCubed``):
+    ``equiangular`` spacing cuts every face into equal angles (tan of a uniform angle in [-pi/4, pi/4]), ``equidistant``
+    into equal steps on the cube face.  Order: face by face, row-major inside a face."""
+    if m < 1:
+        raise ValueError("subdivisions must be >= 1")
+    if spacing == "equiangular":
+        t = np.tan(-np.pi / 4 + (np.arange(m) + 0.5) * (np.pi / 2) / m)
+    elif spacing == "equidistant":
+        t = -1.0 + (np.arange(m) + 0.5) * 2.0 / m
+    else:
+        raise ValueError("spacing must be 'equiangular' or 'equidistant'")
+    a, b = np.meshgrid(t, t, indexing="ij")
+    a, b, one = a.ravel(), b.ravel(), np.ones(m * m)
+    faces = [np.stack(f, axis=1) for f in ((one, a, b), (-a, one, b), (-one, -a, b), (a, -one, b), (-b, a, one), (b, a, -one))]
+    pts = np.concatenate(faces)
+    return pts / np.linalg.norm(pts, axis=1, keepdims=True)
+
+
+def gauss_legendre_vec(nlat: int, nlon="ecmwf-octahedral"):
+    """Gauss-Legendre sampling (pygsp's ``SphereGaussLegendre``): latitudes at the roots of the Legendre polynomial of
+    degree ``nlat``; ``nlon`` an int (the same number of longitudes on every ring; default of pygsp: 2 nlat) or
+    ``'ecmwf-octahedral'`` - the reduced grid of ECMWF's O-grids: ``4 i + 16`` longitudes on the i-th ring from a pole
+    (O24 = ``nlat`` 48: 20, 24, .., 112, .., 24, 20 = 3168 points).  Order: ring by ring from north to south."""
+    if nlat < 2 or nlat % 2:
+        raise ValueError("nlat must be an even number >= 2")
+    x, _ = np.polynomial.legendre.leggauss(nlat)          # roots in ascending order: sin(latitude) from south to north
+    lat = np.arcsin(x[::-1])
+    if isinstance(nlon, str):
+        if nlon != "ecmwf-octahedral":
+            raise ValueError("nlon must be an int or 'ecmwf-octahedral'")
+        half = 4 * np.arange(1, nlat // 2 + 1) + 16
+        per_ring = np.concatenate([half, half[::-1]])
+    else:
+        per_ring = np.full(nlat, int(nlon))
+    lat2 = np.repeat(lat, per_ring)
+    lon2 = np.concatenate([np.arange(n) * 2.0 * np.pi / n for n in per_ring])
+    xyz = np.stack([np.cos(lat2) * np.cos(lon2), np.cos(lat2) * np.sin(lon2), np.sin(lat2)], axis=1)
+    return xyz, lat2, lon2
+
+
+# Published kernel widths of the HEALPix k-NN graphs (DeepSphere, Defferrard et al. 2020, table of "optimal" widths for
+# equivariance): they scale with the pixel size, ~ c_k / nside; c_k below are the nside = 32 values times 32.  pygsp's
+# sphere-graphs branch keeps the full per-(k, nside) table (`_OPTIMAL_KERNEL_WIDTHS`), which is not vendored with the
+# reference: these figures are quoted from the paper, the 1 / nside scaling is an approximation (the table's own entries
+# drift from it by ~2 %) - parity with pygsp's graphs stays UNPINNED (DESIGN.md, section 4).
+HEALPIX_KERNEL_WIDTH_TIMES_NSIDE = {8: 0.02500 * 32, 20: 0.03185 * 32, 40: 0.042432 * 32, 60: 0.051720 * 32}
+
+
+def knn_graph_laplacian(coords: np.ndarray, k: int, lap_type: str = "normalized", kernel_width=None):
     """Symmetrised k-NN Gaussian graph and its Laplacian (scipy CSR, float64).
 
-    Weight ``exp(-d^2 / (2 s^2))`` with ``s^2`` the mean squared k-NN distance;
-    symmetrisation keeps an edge if either endpoint selected it (so degrees are >= k
-    and irregular where the sampling is anisotropic, e.g. equiangular poles).
+    Weight ``exp(-d^2 / (2 s^2))``.  ``kernel_width``: ``None`` - ``s^2`` = the mean SQUARED k-NN distance (this
+    module's rule since round 1); ``"mean"`` - ``s`` = the mean k-NN distance (the default rule of pygsp's ``NNGraph``);
+    a float - that width (e.g. ``healpix_kernel_width``).  Symmetrisation keeps an edge if either endpoint selected it
+    (so degrees are >= k and irregular where the sampling is anisotropic, e.g. equiangular poles).
     """
     n = coords.shape[0]
     if k >= n:
@@ -174,7 +264,16 @@ def knn_graph_laplacian(coords: np.ndarray, k: int, lap_type: str = "normalized"
     dist, idx = tree.query(coords, k=k + 1)
     dist = dist[:, 1:]
     idx = idx[:, 1:]
-    s2 = float(np.mean(dist**2))
+    if kernel_width is None:
+        s2 = float(np.mean(dist**2))
+    elif isinstance(kernel_width, str):
+        if kernel_width != "mean":
+            raise ValueError("kernel_width must be None, 'mean' or a positive number")
+        s2 = float(np.mean(dist)) ** 2
+    else:
+        if not kernel_width > 0:
+            raise ValueError("kernel_width must be None, 'mean' or a positive number")
+        s2 = float(kernel_width) ** 2
     w = np.exp(-(dist**2) / (2.0 * s2))
     rows = np.repeat(np.arange(n), k)
     W = sparse.csr_matrix((w.ravel(), (rows, idx.ravel())), shape=(n, n))
@@ -199,34 +298,76 @@ class _SphereGraph:
     ``.L``, ``.W``, ``.n_vertices``, ``.coords``, ``.signals['lat'|'lon']``
     (``/root/reference/modules/models.py:54``, ``modules/layers.py:540-543``)."""
 
-    def __init__(self, coords, k, lap_type):
+    def __init__(self, coords, k, lap_type, kernel_width=None):
         self.coords = coords
         self.n_vertices = coords.shape[0]
         self.k = k
         self.lap_type = lap_type
-        self.W, self.L = knn_graph_laplacian(coords, k, lap_type)
+        self.kernel_width = kernel_width
+        self.W, self.L = knn_graph_laplacian(coords, k, lap_type, kernel_width)
         lat = np.degrees(np.arcsin(np.clip(coords[:, 2], -1, 1)))
         lon = np.degrees(np.arctan2(coords[:, 1], coords[:, 0])) % 360.0
         self.signals = {"lat": lat, "lon": lon}
 
 
-class SphereHealpix(_SphereGraph):
-    """HEALPix k-NN graph (``subdivisions`` = nside), nested or ring order."""
+def healpix_kernel_width(k: int, nside: int) -> float:
+    """Kernel width pygsp's ``SphereHealpix`` would use (its per-(k, nside) table, approximated: see
+    ``HEALPIX_KERNEL_WIDTH_TIMES_NSIDE``); raises for a ``k`` the published table does not have, as pygsp does."""
+    if k not in HEALPIX_KERNEL_WIDTH_TIMES_NSIDE:
+        raise ValueError("No known optimal kernel width for {} neighbors and nside={}.".format(k, nside))
+    return HEALPIX_KERNEL_WIDTH_TIMES_NSIDE[k] / float(nside)
 
-    def __init__(self, subdivisions=2, nest=False, k=20, lap_type="normalized", **kwargs):
+
+class SphereHealpix(_SphereGraph):
+    """HEALPix k-NN graph (``subdivisions`` = nside), nested or ring order.  ``kernel_width="optimal"`` takes the
+    published width for (k, nside) - the rule of pygsp's class -, a float that width, the default this module's own rule."""
+
+    def __init__(self, subdivisions=2, nest=False, k=20, lap_type="normalized", kernel_width=None, **kwargs):
         self.subdivisions = int(subdivisions)
         self.nest = bool(nest)
-        super().__init__(healpix_pix2vec(self.subdivisions, self.nest), k, lap_type)
+        if isinstance(kernel_width, str) and kernel_width == "optimal":
+            kernel_width = healpix_kernel_width(k, self.subdivisions)
+        super().__init__(healpix_pix2vec(self.subdivisions, self.nest), k, lap_type, kernel_width)
 
 
 class SphereEquiangular(_SphereGraph):
     """Equiangular (nlat x nlon) k-NN graph; irregular degree near the poles."""
 
-    def __init__(self, nlat=36, nlon=72, poles=0, k=20, lap_type="normalized", **kwargs):
+    def __init__(self, nlat=36, nlon=72, poles=0, k=20, lap_type="normalized", kernel_width=None, **kwargs):
         self.nlat = int(nlat)
         self.nlon = int(nlon)
         coords, _, _ = equiangular_vec(self.nlat, self.nlon)
-        super().__init__(coords, k, lap_type)
+        super().__init__(coords, k, lap_type, kernel_width)
+
+
+class SphereIcosahedral(_SphereGraph):
+    """Subdivided-icosahedron k-NN graph (``10 subdivisions^2 + 2`` vertices, or the ``20 subdivisions^2`` face centres
+    with ``dual``); configs/UNetSpherical/Icosahedral_400km uses ``subdivisions`` 16 -> 8 -> 4."""
+
+    def __init__(self, subdivisions=2, dual=False, k=20, lap_type="normalized", kernel_width=None, **kwargs):
+        self.subdivisions = int(subdivisions)
+        self.dual = bool(dual)
+        super().__init__(icosahedral_vec(self.subdivisions, self.dual), k, lap_type, kernel_width)
+
+
+class SphereCubed(_SphereGraph):
+    """Cubed-sphere k-NN graph (``6 subdivisions^2`` cell centres); configs/UNetSpherical/Cubed_400km: 24 -> 12 -> 6."""
+
+    def __init__(self, subdivisions=3, spacing="equiangular", k=20, lap_type="normalized", kernel_width=None, **kwargs):
+        self.subdivisions = int(subdivisions)
+        self.spacing = spacing
+        super().__init__(cubed_vec(self.subdivisions, spacing), k, lap_type, kernel_width)
+
+
+class SphereGaussLegendre(_SphereGraph):
+    """Gauss-Legendre k-NN graph, regular (``nlon`` an int, default 2 nlat) or reduced (``'ecmwf-octahedral'``);
+    configs/UNetSpherical/O24: ``nlat`` 48 -> 24 -> 12, octahedral."""
+
+    def __init__(self, nlat=4, nlon="ecmwf-octahedral", k=20, lap_type="normalized", kernel_width=None, **kwargs):
+        self.nlat = int(nlat)
+        self.nlon = nlon
+        coords, _, _ = gauss_legendre_vec(self.nlat, nlon)
+        super().__init__(coords, k, lap_type, kernel_width)
 
 
 def healpix_pool_matrices(nside_fine: int, nest: bool = True):

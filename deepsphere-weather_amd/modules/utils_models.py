@@ -3,14 +3,15 @@
 API-compatible counterpart of the reference's ``modules/utils_models.py`` (same function names,
 arguments, return values and exception types); the implementation is table driven.  Graph classes
 come from pygsp's ``sphere-graphs`` branch when it is importable, otherwise from the self-contained
-builders in ``dsw_amd.sphere`` (healpix and equiangular only).
+builders in ``dsw_amd.sphere`` (all five samplings of the reference's table, ``utils_models.py:11-20``).
 """
 from dsw_amd import sphere as _sphere
 
 _SAMPLINGS = ("healpix", "equiangular", "icosahedral", "cubed", "gauss")
 _PYGSP_CLASS = dict(zip(_SAMPLINGS, ("SphereHealpix", "SphereEquiangular", "SphereIcosahedral",
                                      "SphereCubed", "SphereGaussLegendre")))
-_BUILTIN = {"healpix": _sphere.SphereHealpix, "equiangular": _sphere.SphereEquiangular}
+_BUILTIN = {"healpix": _sphere.SphereHealpix, "equiangular": _sphere.SphereEquiangular,
+            "icosahedral": _sphere.SphereIcosahedral, "cubed": _sphere.SphereCubed, "gauss": _sphere.SphereGaussLegendre}
 # which sampling kwargs shrink (integer division) when going one U-Net level down
 _COARSEN_KEYS = {"equiangular": ("nlat", "nlon"), "healpix": ("subdivisions",), "icosahedral": ("subdivisions",),
                  "cubed": ("subdivisions",), "gauss": ("nlat",)}

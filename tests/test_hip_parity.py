@@ -1109,6 +1109,34 @@ def test_conv_on_non_local_row_orders_takes_clustered_tiles(sampling, knn, Fin, 
     assert orc.max_rel_err(db.float(), db64) <= 2 * tol
 
 
+@pytest.mark.parametrize("sampling,kwargs", [("icosahedral", {"subdivisions": 16}), ("cubed", {"subdivisions": 24}),
+                                             ("gauss", {"nlat": 48, "nlon": "ecmwf-octahedral"})])
+def test_conv_on_the_other_samplings_vs_oracle(sampling, kwargs):
+    """f2: ConvCheb forward + backward on the k = 20 graphs of the samplings added in round 4 (the sizes of the reference's
+    Icosahedral_400km / Cubed_400km / O24 configs) against the fp64 oracle - whatever tiles the plan builder finds for
+    their row orders."""
+    from modules.layers import ConvCheb
+    from modules.utils_models import get_pygsp_graph
+
+    g = get_pygsp_graph(sampling, dict(kwargs), knn=20)
+    lap = orc.prepare_laplacian_fixed_lmax(g.L, 1.9)
+    rp, ci, va = orc.csr_arrays_from_coo(lap)
+    V = len(rp) - 1
+    Fin, Fout, K, B = 32, 64, 3, 3
+    layer = ConvCheb(Fin, Fout, K, laplacian=lap)
+    w = recipes.rand(81, (Fin, K, Fout), np.sqrt(2.0 / (Fin * K)))
+    b = recipes.rand(82, (Fout,), 0.1)
+    layer.set_parameters(torch.from_numpy(w), torch.from_numpy(b))
+    layer = layer.to(DEV)
+    x = recipes.rand(83, (B, V, Fin))
+    gy = recipes.rand(84, (B, V, Fout))
+    y, dx, dw, db = _run_layer(layer, torch.from_numpy(x).to(DEV), torch.from_numpy(gy).to(DEV))
+    y64 = orc.cheb_forward_f64(rp, ci, va, x, w, b)
+    dx64, dw64, db64 = orc.cheb_backward_f64(rp, ci, va, x, w, gy, True)
+    assert orc.max_rel_err(y, y64) <= TOL_F64 and orc.max_rel_err(dx, dx64) <= TOL_F64
+    assert orc.max_rel_err(dw, dw64) <= 2 * TOL_F64 and orc.max_rel_err(db, db64) <= 2 * TOL_F64
+
+
 @pytest.mark.parametrize("pool_method", ["interp", "maxval"])
 def test_unet_bf16_storage_tracks_fp32(pool_method):
     """`model.to(torch.bfloat16)` end to end (every kernel's bf16 variant, the copy-free concatenation on 2-byte rows,

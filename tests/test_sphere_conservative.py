@@ -109,3 +109,75 @@ def test_build_pooling_matrices_methods_and_loss_weights():
         WeightedMSELoss(weights=w[:-1])(pred, obs)
     with pytest.raises(TypeError):
         WeightedMSELoss(weights=w.numpy())
+
+
+@pytest.mark.parametrize("sampling,kwargs,n_expected", [
+    ("healpix", {"subdivisions": 8, "nest": True}, (768, 192, 48)),
+    ("equiangular", {"nlat": 36, "nlon": 72, "poles": 0}, (2592, 648, 162)),
+    ("icosahedral", {"subdivisions": 16}, (2562, 642, 162)),               # configs/UNetSpherical/Icosahedral_400km
+    ("cubed", {"subdivisions": 24}, (3456, 864, 216)),                      # configs/UNetSpherical/Cubed_400km
+    ("gauss", {"nlat": 48, "nlon": "ecmwf-octahedral"}, (3168, 1008, 360)), # configs/UNetSpherical/O24
+])
+def test_unet_builds_on_all_five_samplings(sampling, kwargs, n_expected):
+    """f2: every sampling of the reference's table (utils_models.py:11-20) constructs - graphs per level, scaled
+    Laplacians, conservative pooling matrices between the levels (their invariants: rows of pool and of unpool^T sum to 1,
+    non-negative) - and a forward on the CPU wiring (the oracle behind the host logic) has the right shape."""
+    import torch
+    import modules.my_models_graph as arch
+    from dsw_amd import functional
+    from _oracle_backend import OracleBackend
+
+    V = n_expected[0]
+    tensor_info = {
+        "dim_order": {"dynamic": ["sample", "time", "node", "feature"]},
+        "input_n_feature": 2, "output_n_feature": 1, "input_n_time": 2, "output_n_time": 1,
+        "input_shape_info": {"dynamic": {"node": V}}, "output_shape_info": {"dynamic": {"node": V}},
+    }
+    torch.manual_seed(0)
+    model = arch.UNetSpherical(tensor_info, sampling=sampling, sampling_kwargs=dict(kwargs), kernel_size_conv=3,
+                               conv_type="graph", graph_type="knn", knn=20, pool_method="interp")
+    assert tuple(g.n_vertices for g in model.graphs) == n_expected
+    for lvl in (1, 2):
+        pool = getattr(model, f"pool{lvl}").remap_matrix.to_dense().double()
+        unpool = getattr(model, f"unpool{lvl}").remap_matrix.to_dense().double()
+        assert pool.shape == (n_expected[lvl], n_expected[lvl - 1]) and unpool.shape == pool.t().shape
+        assert float(pool.min()) >= 0 and float(unpool.min()) >= 0
+        np.testing.assert_allclose(pool.sum(1).numpy(), 1, rtol=1e-5)
+        np.testing.assert_allclose(unpool.sum(1).numpy(), 1, rtol=1e-5)
+    functional.set_test_backend(OracleBackend())
+    try:
+        with torch.no_grad():
+            y = model(torch.randn(1, 2, V, 2))
+    finally:
+        functional.set_test_backend(None)
+    assert y.shape == (1, 1, V, 1) and bool(torch.isfinite(y).all())
+
+
+def test_sampling_geometry_and_kernel_widths():
+    """Vertex counts / symmetries of the new samplings, and the kernel-width options of the k-NN graphs."""
+    ico = sphere.icosahedral_vec(3)
+    assert ico.shape == (92, 3) and sphere.icosahedral_vec(4, dual=True).shape == (320, 3)
+    np.testing.assert_allclose(ico.sum(0), 0, atol=1e-12)                     # centrally symmetric point set
+    cub = sphere.cubed_vec(5)
+    assert cub.shape == (150, 3)
+    np.testing.assert_allclose(cub.sum(0), 0, atol=1e-12)
+    np.testing.assert_allclose(np.abs(cub).max(1).min(), np.abs(cub).max(1).min())
+    xyz, lat, lon = sphere.gauss_legendre_vec(48)
+    assert xyz.shape == (3168, 3) and np.isclose(lat[0], -lat[-1]) and lat[0] > 0
+    counts = np.unique(np.round(lat, 12), return_counts=True)[1]
+    assert counts.min() == 20 and counts.max() == 112 and (counts == counts[::-1]).all()
+    assert sphere.gauss_legendre_vec(8, nlon=16)[0].shape == (128, 3)
+    for bad in (lambda: sphere.gauss_legendre_vec(7), lambda: sphere.gauss_legendre_vec(8, nlon="reduced"),
+                lambda: sphere.cubed_vec(4, spacing="x"), lambda: sphere.icosahedral_vec(0)):
+        with pytest.raises(ValueError):
+            bad()
+    g0 = sphere.SphereHealpix(8, nest=True, k=20)
+    g1 = sphere.SphereHealpix(8, nest=True, k=20, kernel_width="optimal")
+    g2 = sphere.SphereHealpix(8, nest=True, k=20, kernel_width="mean")
+    assert g1.kernel_width == pytest.approx(0.03185 * 32 / 8)
+    assert abs(g0.L - g1.L).max() > 1e-3 and abs(g0.L - g2.L).max() > 1e-6   # three different weightings of the same edges
+    assert (g0.L != 0).nnz == (g1.L != 0).nnz
+    with pytest.raises(ValueError, match="No known optimal kernel width"):
+        sphere.SphereHealpix(8, k=12, kernel_width="optimal")
+    with pytest.raises(ValueError):
+        sphere.SphereHealpix(8, k=8, kernel_width="median")

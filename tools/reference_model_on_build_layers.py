@@ -23,7 +23,7 @@ ref_root = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 # the reference's utils_models / models import pygsp (absent): stand-in with this repo's graph builders
 pg, pgg = types.ModuleType("pygsp"), types.ModuleType("pygsp.graphs")
 pgg.SphereHealpix, pgg.SphereEquiangular = sphere.SphereHealpix, sphere.SphereEquiangular
-pgg.SphereIcosahedral = pgg.SphereCubed = pgg.SphereGaussLegendre = None
+pgg.SphereIcosahedral, pgg.SphereCubed, pgg.SphereGaussLegendre = sphere.SphereIcosahedral, sphere.SphereCubed, sphere.SphereGaussLegendre
 pg.graphs = pgg
 sys.modules["pygsp"], sys.modules["pygsp.graphs"] = pg, pgg
 
