@@ -279,7 +279,9 @@ static int cheb_fwd_impl(const int32_t* rowptr, const int32_t* colind, const flo
         // the room - it does unless the batch is a handful of nodes): one epilogue operand less at the top of the recurrence
         const void* Wz = W;
         int folded = 0;
-        if (K >= 3) {
+        // (only where it saves a pass: the staged one-hop kernels read that plane from HBM; inside a fused pair it is the
+        // staged input of the first hop anyway, and the fold would only add a launch)
+        if (K >= 3 && plan != nullptr && plan->hops == 1) {
             const int64_t used = round_up((K - 1 + (K >= 4 ? 2 : 0)) * N * Fout * elem_size(dtype), 256);
             const int64_t have = (K - 1) * N * Fin * elem_size(dtype);
             if (have - used >= Fin * K * Fout * elem_size(dtype)) {
@@ -403,7 +405,9 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
     // dgrad weights with plane K-3 folded (G_{K-3} - G_{K-1} out of the GEMM): the adjoint recurrence then has one
     // epilogue operand less at its top - for K = 3 every step is a one-operand step
     const void* Wd = W;
-    const int folded = (K >= 3 && dX != nullptr && N > 0) ? 1 : 0;
+    // (staged one-hop plans only: inside a fused pair the subtracted plane is the staged input of the first hop - no pass
+    // is saved there and the fold would only add a launch)
+    const int folded = (K >= 3 && dX != nullptr && N > 0 && plan_t != nullptr && plan_t->hops == 1) ? 1 : 0;
     if (folded) {
         const int64_t S_ = dsw_wgrad_slabs(N, Fin, Fout, K);
         void* Wf = reinterpret_cast<char*>(partial) + round_up((S_ > 0 ? S_ : 1) * (K * Fin + 1) * Fout * 4, 256);

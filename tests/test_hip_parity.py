@@ -1203,6 +1203,14 @@ def test_bench_two_ranks_self_launched():
     assert "roofline" not in out and "cpu_baseline" not in out          # N = 1 legs only
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 @pytest.mark.parametrize("ranks,global_batch", [(4, 6), (8, 5)])
 def test_bench_many_ranks_ragged_and_empty_shards(ranks, global_batch):
     """the N > 1 path with 4 and 8 ranks before the driver's 8-GPU box sees it - one GPU here, so the
@@ -1241,7 +1249,7 @@ def test_bench_one_gpu_line_is_the_same_under_torchrun():
     plain = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=900)
     assert plain.returncode == 0, plain.stderr[-2000:]
     tr = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
-                         "127.0.0.1", "--master-port", "29731", os.path.join(root, "bench.py"), *args],
+                         "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), *args],
                         env=env, capture_output=True, text=True, timeout=900)
     assert tr.returncode == 0, tr.stderr[-2000:]
     a, b = (json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]) for r in (plain, tr))
@@ -1264,7 +1272,7 @@ def test_bench_one_rank_world_captures_the_exchange():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DSW_DIST_BACKEND")}
-    env.update(DSW_FORCE_GRAD_SYNC="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631")
+    env.update(DSW_FORCE_GRAD_SYNC="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "2", "--no-cpu-baseline",
                         "--no-roofline"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -1369,7 +1377,7 @@ def test_training_driver_one_rank_world_whole_step_graph(tmp_path):
             "--steps", "6", "--warmup", "0", "--batch_size", "2", "--ar_iterations", "1"]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DSW_DIST_BACKEND")}
     outs = []
-    for extra_env, extra_args in (({}, []), ({"DSW_FORCE_GRAD_SYNC": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29641"},
+    for extra_env, extra_args in (({}, []), ({"DSW_FORCE_GRAD_SYNC": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())},
                                              ["--graph"])):
         r = subprocess.run(base + extra_args, env=dict(env, **extra_env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
