@@ -10,7 +10,11 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("DSW_HIP_LIB") or os.path.join(_HERE, "libdsw_hip.so")  # env: A/B builds only
+# Environment read by the PACKAGE (csrc/ reads none in the product build), each announced on stderr when in effect:
+#   DSW_HIP_LIB            another build of the library (A/B runs of tools/build_variant*.sh)      [_native.py]
+#   DSW_DIST_BACKEND       process-group backend instead of nccl / gloo by device                    [parallel.py]
+#   DSW_FORCE_GRAD_SYNC=1  run the gradient exchange in a one-rank world (tests of the N > 1 path)   [parallel.py]
+LIB_PATH = os.environ.get("DSW_HIP_LIB") or os.path.join(_HERE, "libdsw_hip.so")
 
 DSW_F32 = 0
 DSW_BF16 = 1
@@ -104,6 +108,10 @@ def load():
             "(run `python -c 'import __graft_entry__ as g; g.build()'` at the repo root). "
             "There is no CPU/PyTorch fallback for the dsw hot path."
         )
+    if os.environ.get("DSW_HIP_LIB"):
+        import sys
+
+        print("dsw_amd: DSW_HIP_LIB is set - loading %s instead of the in-tree library" % LIB_PATH, file=sys.stderr, flush=True)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure

@@ -1,9 +1,12 @@
 """Host side of the hot path: operator caches and ``torch.autograd.Function`` wrappers that call the
 C ABI of ``libdsw_hip.so`` on the current HIP stream.
 
-PyTorch is plumbing here (device memory, streams, autograd graph); every FLOP and byte of the path
-runs in the hand-written gfx950 kernels under ``csrc/``.  CPU tensors are rejected: there is no
-fallback implementation in the product.  (Tests may inject a checker backend with
+PyTorch is plumbing here (device memory, streams, autograd graph); the convolutions, poolings, residual
+epilogues and their backward passes run in the hand-written gfx950 kernels under ``csrc/``.  What stock
+torch still launches inside a model step is glue, not the path: autograd's ``add`` where a tensor has two
+consumers and no fused route (a ResBlock's input: conv stack + residual map - the fused alternative,
+``dense_mix_fork`` / ``dX_add``, exists and measured slower), the zero-pad of an unaligned input width
+(``_padded_width``), the loss.  CPU tensors are rejected: there is no fallback implementation in the product.  (Tests may inject a checker backend with
 ``set_test_backend`` to exercise the host logic on CPU; nothing in the package does.)
 """
 from __future__ import annotations

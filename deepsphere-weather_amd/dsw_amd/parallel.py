@@ -28,6 +28,12 @@ def init_from_env(backend: str | None = None):
     if (world > 1 or force) and not dist.is_initialized():
         if backend is None:   # DSW_DIST_BACKEND=gloo: run the N>1 path of a GPU script on a single-GPU box (tests)
             backend = os.environ.get("DSW_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if rank == 0 and (force or os.environ.get("DSW_DIST_BACKEND")):     # never silently: these change what runs
+            import sys
+
+            print("dsw_amd.parallel: %s" % ", ".join(
+                ([("DSW_DIST_BACKEND=%s (process-group backend)" % os.environ["DSW_DIST_BACKEND"])] if os.environ.get("DSW_DIST_BACKEND") else [])
+                + (["DSW_FORCE_GRAD_SYNC=1 (gradient exchange in a one-rank world)"] if force else [])), file=sys.stderr, flush=True)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":

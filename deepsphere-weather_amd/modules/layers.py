@@ -356,15 +356,21 @@ class GeneralMaxValPool(RemapBlock):
     """Max-value pooling: per coarse cell, sample and channel the value of the overlapping fine cell whose
     area-WEIGHTED value is largest (reference ``layers.py:1040-1079``).
 
-    Returns ``(x_pooled [B, Vd, F], index)``.  ``index`` is the compact int32 ``[B, Vd, F]`` selection (the chosen fine
-    cell per output element) - the same information as the reference's ``[2, B*F*Vd]`` int64 tensor at a sixteenth of
-    the size; :meth:`reference_index` converts, and :class:`GeneralMaxValUnpool` accepts either form."""
+    Returns ``(x_pooled [B, Vd, F], index)``.  ``index_format = "reference"`` (the default: what code written against the
+    reference sees): the reference's ``[2, B*F*Vd]`` int64 tensor; ``"compact"`` (set by this package's own
+    ``UNetSpherical``, which only hands the index to the unpooling): the int32 ``[B, Vd, F]`` selection the kernel
+    produces (the chosen fine cell per output element) - the same information at a sixteenth of the size and without the
+    conversion pass.  :meth:`reference_index` converts; :class:`GeneralMaxValUnpool` accepts either form."""
 
     supports_out = False
     forward_fork = None    # the selection gradient is a scatter, not a product with an epilogue
+    index_format = "reference"
 
     def forward(self, x, *args, **kwargs):
-        return _F.maxval_pool(_F.get_operator(self.remap_matrix), x)
+        y, sel = _F.maxval_pool(_F.get_operator(self.remap_matrix), x)
+        if self.index_format == "compact":
+            return y, sel
+        return y, _F.maxval_reference_index(sel)
 
     @staticmethod
     def reference_index(index):

@@ -282,6 +282,8 @@ class UNetSpherical(UNet, torch.nn.Module):
             for lvl in (1, 2):
                 pool, unpool = PoolUnpoolBlock.getGeneralPoolUnpoolLayer(
                     src_graph=self.graphs[lvl - 1], dst_graph=self.graphs[lvl], pool_method=pool_method)
+                if hasattr(pool, "index_format"):
+                    pool.index_format = "compact"     # this model only passes the index on to the unpooling (decode())
                 setattr(self, f"pool{lvl}", pool)
                 setattr(self, f"unpool{lvl}", unpool)
         elif pool_method in ("max", "avg"):

@@ -424,6 +424,9 @@ def check_g8(tag, device="cpu", tol=1e-6):
     dev = lambda a: torch.from_numpy(a).to(device)
     pool, unpool = (m.to(device) for m in _g8_layers(g, tag, "maxval"))
     x = dev(g[f"{tag}_mv_x"]).requires_grad_(True)
+    yp, idx_ref = pool(x)                                 # default: the reference's [2, B*F*Vd] int64 index tensor
+    assert idx_ref.dtype == torch.int64 and torch.equal(idx_ref.cpu(), torch.from_numpy(g[f"{tag}_mv_index"]))
+    pool.index_format = "compact"
     yp, idx = pool(x)
     assert idx.dtype == torch.int32 and idx.shape == yp.shape
     assert torch.equal(pool.reference_index(idx).cpu(), torch.from_numpy(g[f"{tag}_mv_index"]))
