@@ -47,7 +47,7 @@ int dsw_wgrad_mixfirst_launch(const void* X, const void* dY, const void* D, void
                               int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int accumulate);
 int dsw_bwd_gemm_fused_try(const void* X, const void* T, const void* W, const void* dY, void* dW, void* db, void* G0,
                            void* Grest, float* partial, int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype,
-                           hipStream_t stream, int* rc, int accumulate);
+                           hipStream_t stream, int* rc, int accumulate, int fold);
 int dsw_zmix_launch(const void* X, const void* W, const void* bias, void* Z0, void* Zrest, int64_t N, int64_t Fin,
                     int64_t Fout, int64_t K, int dtype, hipStream_t stream, const DswEpiExtra* extra = nullptr);
 int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X, const void* W, const void* bias, void* Y,
@@ -404,28 +404,29 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
     int rc = DSW_OK;
     // dgrad weights with plane K-3 folded (G_{K-3} - G_{K-1} out of the GEMM): the adjoint recurrence then has one
     // epilogue operand less at its top - for K = 3 every step is a one-operand step
-    const void* Wd = W;
     // (staged one-hop plans only: inside a fused pair the subtracted plane is the staged input of the first hop - no pass
-    // is saved there and the fold would only add a launch)
+    // is saved there and the fold would only add work)
     const int folded = (K >= 3 && dX != nullptr && N > 0 && plan_t != nullptr && plan_t->hops == 1) ? 1 : 0;
-    if (folded) {
-        const int64_t S_ = dsw_wgrad_slabs(N, Fin, Fout, K);
-        void* Wf = reinterpret_cast<char*>(partial) + round_up((S_ > 0 ? S_ : 1) * (K * Fin + 1) * Fout * 4, 256);
-        rc = dsw_fold_w_launch(W, Wf, Fin, Fout, K, dtype, s);
-        if (rc != DSW_OK) return rc;
-        Wd = Wf;
-    }
     if (dX != nullptr && dW != nullptr && N > 0 && !extras) {
-        // small aligned fp32 layers: dgrad planes and dW partials from ONE pass over dY (dsw_wgrad_x3.hip, FUSE)
+        // small aligned fp32 layers: dgrad planes and dW partials from ONE pass over dY (dsw_wgrad_x3.hip, FUSE); the fold is
+        // applied while that kernel fills its W^T panel
         if (K > 1 && !rowptr_t) return DSW_ERR_BAD_ARG;
         int rcf = DSW_OK;
-        if (dsw_bwd_gemm_fused_try(X, T, Wd, dY, dW, db, dX, G, partial, N, Fin, Fout, K, dtype, s, &rcf, accumulate)) {
+        if (dsw_bwd_gemm_fused_try(X, T, W, dY, dW, db, dX, G, partial, N, Fin, Fout, K, dtype, s, &rcf, accumulate, folded)) {
             if (rcf != DSW_OK) return rcf;
             if (K > 1)
                 rcf = cheb_basis_adj_impl(rowptr_t, colind_t, vals_t, V, nnz, dX, G, B, Fin, K, dtype, stream, plan_t,
                                           K >= 4 ? spare : nullptr, folded);
             return rcf;
         }
+    }
+    const void* Wd = W;
+    if (folded) {     // the separate dgrad GEMMs take the folded copy of the weights
+        const int64_t S_ = dsw_wgrad_slabs(N, Fin, Fout, K);
+        void* Wf = reinterpret_cast<char*>(partial) + round_up((S_ > 0 ? S_ : 1) * (K * Fin + 1) * Fout * 4, 256);
+        rc = dsw_fold_w_launch(W, Wf, Fin, Fout, K, dtype, s);
+        if (rc != DSW_OK) return rc;
+        Wd = Wf;
     }
     if (dX != nullptr && N > 0) {
         if (K > 1 && !rowptr_t) return DSW_ERR_BAD_ARG;

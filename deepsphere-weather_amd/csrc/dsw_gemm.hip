@@ -903,13 +903,13 @@ int dsw_wgrad_dgrad_fused_try_launch(WgradParams& P, int bf16, int64_t max_slabs
 
 int dsw_bwd_gemm_fused_try(const void* X, const void* T, const void* W, const void* dY, void* dW, void* db, void* G0,
                            void* Grest, float* partial, int64_t N, int64_t Fin, int64_t Fout, int64_t K, int dtype,
-                           hipStream_t stream, int* rc, int accumulate) {
+                           hipStream_t stream, int* rc, int accumulate, int fold) {
     if ((dtype != DSW_F32 && dtype != DSW_BF16) || N <= 0 || !dW || !G0) return 0;
     WgradParams P{};
     P.X = X; P.T = T; P.plane_stride = (size_t)N * Fin; P.dY = dY; P.partial = partial;
     P.N = N; P.Fin = (int)Fin; P.Fout = (int)Fout; P.K = (int)K;
     P.tiles_per_plane = (int)((Fin + 31) / 32);
-    P.W = W; P.G0 = G0; P.Grest = Grest;
+    P.W = W; P.G0 = G0; P.Grest = Grest; P.fold = (fold && K >= 3) ? 1 : 0;
     const uintptr_t am = 15;
     P.t_vec = (Fin % 4 == 0) && (((uintptr_t)X & am) == 0) && (K == 1 || ((uintptr_t)T & am) == 0);
     P.dy_vec = (Fout % 4 == 0) && (((uintptr_t)dY & am) == 0);

@@ -156,6 +156,7 @@ struct WgradParams {
     const void* W;
     void* G0;
     void* Grest;
+    int fold;               // 1: dgrad plane K-3 with W[:, K-3, :] - W[:, K-1, :] (dsw_fold_w_launch done while the panel is filled)
     int dbg;                // reserved for ablation builds; 0
 };
 

@@ -151,6 +151,7 @@ __global__ __launch_bounds__(64 * NW, FUSE ? 2 : 1) void cheb_wgrad_x3_kernel(co
             if (t_ < ntiles) {
                 const int kk = t_ / P.tiles_per_plane, ff = (t_ - kk * P.tiles_per_plane) * 32 + (c & 31);
                 v = Wsrc[((size_t)ff * P.K + kk) * P.Fout + o];
+                if (P.fold && kk == P.K - 3) v -= Wsrc[((size_t)ff * P.K + (P.K - 1)) * P.Fout + o];
             }
             const float h = trunc_bf16(v), r1 = v - h, m = trunc_bf16(r1), l = r1 - m;
             Wp[c * WKS + o] = (unsigned short)(__float_as_uint(h) >> 16);
@@ -390,6 +391,8 @@ __global__ __launch_bounds__(64 * NW, FUSE ? 2 : 1) void cheb_wgrad_bf16_kernel(
             if (t_ < ntiles) {
                 const int kk = t_ / P.tiles_per_plane, ff = (t_ - kk * P.tiles_per_plane) * 32 + (c & 31);
                 v = Wsrc[((size_t)ff * P.K + kk) * P.Fout + o];
+                if (P.fold && kk == P.K - 3)
+                    v = f32_to_bf16(bf16_to_f32(v) - bf16_to_f32(Wsrc[((size_t)ff * P.K + (P.K - 1)) * P.Fout + o]));
             }
             Wp[c * WKS + o] = v;
         }
