@@ -14,12 +14,26 @@ int dsw_spmm_launch(const int* rowptr, const int* colind, const float* vals, int
 // hints: bit1 = the epilogue operands Z / Z2 are cold (not produced by the previous launch): stream them
 // with non-temporal loads so they do not evict the gathered rows from L2 / Infinity Cache
 #define DSW_SPMM_HINT_COLD_Z 2
-struct DswEpiExtra {   // optional epilogue operands of the channel-mix launchers (dsw_gemm.hip)
+struct DswEpiExtra {   // optional epilogue operands / scratch of the channel-mix launchers (dsw_gemm.hip)
     const void* scale;
     const void* R;
     int64_t ldr;
     int64_t ldc;
+    void* ws;            // scratch for an image of W (pre-split terms, or a folded copy)
+    int64_t ws_bytes;
+    int fold;            // 1: plane K-3 with W[:, K-3, :] - W[:, K-1, :]
 };
+// bytes of that scratch for a layer: the pre-split image of the streaming GEMM (1.5x the fp32 weights, columns padded to the
+// 128-column tile) or a copy of the weights, whichever is larger
+static inline int64_t w_image_bytes(int64_t Fin, int64_t Fout, int64_t K) {
+    const int64_t fwd = (K * Fin + 31) / 32 * 32 * ((Fout + 127) / 128 * 128) * 6;       // reduction K Fin, columns Fout
+    const int64_t bwd = (Fout + 31) / 32 * 32 * ((K * Fin + 127) / 128 * 128) * 6;       // reduction Fout, columns K Fin
+    const int64_t zmx = (Fin + 31) / 32 * 32 * ((K * Fout + 127) / 128 * 128) * 6;       // mix-first planes: columns K Fout
+    int64_t m = fwd > bwd ? fwd : bwd;
+    if (zmx > m) m = zmx;
+    const int64_t copy = Fin * K * Fout * 4;
+    return (m > copy ? m : copy) + 256;
+}
 int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* bias, void* Y, int64_t N,
                        int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int relu = 0,
                        const DswEpiExtra* extra = nullptr);
@@ -256,13 +270,20 @@ int dsw_cheb_fwd_path(const dsw_hop2_plan* plan, int64_t Fin, int64_t Fout, int6
 static int cheb_fwd_impl(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V, int64_t nnz,
                          const void* X, const void* W, const void* bias, void* Y, void* T, int64_t B, int64_t Fin,
                          int64_t Fout, int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan, int act,
-                         const void* scale, const void* R, int64_t ldr, int64_t ldy) {
+                         const void* scale, const void* R, int64_t ldr, int64_t ldy, void* workspace = nullptr,
+                         int64_t workspace_bytes = 0) {
     if (K <= 0 || (act != DSW_ACT_NONE && act != DSW_ACT_RELU)) return DSW_ERR_BAD_ARG;
+    if (workspace != nullptr && (Fin <= 0 || Fout <= 0 || workspace_bytes < w_image_bytes(Fin, Fout, K))) return DSW_ERR_WORKSPACE;
     if (R != nullptr && ldr < Fout) return DSW_ERR_BAD_ARG;
     if (ldy != 0 && ldy < Fout) return DSW_ERR_BAD_ARG;
     const int relu = act == DSW_ACT_RELU;
     const bool extras = scale != nullptr || R != nullptr || (ldy != 0 && ldy != Fout);
-    const DswEpiExtra ex = {scale, R, ldr, (ldy != 0 && ldy != Fout) ? ldy : 0};
+    // workspace (optional, dsw_cheb_fwd_workspace_bytes): scratch for a per-call image of the weights - the streaming-W GEMM
+    // of wide fp32 layers splits W once per call into it
+    char* wsa = workspace ? reinterpret_cast<char*>(round_up((int64_t)(uintptr_t)workspace, 256)) : nullptr;
+    const int64_t wsb = workspace ? workspace_bytes - (wsa - static_cast<char*>(workspace)) : 0;
+    DswEpiExtra ex = {scale, R, ldr, (ldy != 0 && ldy != Fout) ? ldy : 0, wsa, wsb, 0};
+    const bool use_ex = extras || wsa != nullptr;
     int rc = DSW_OK;
     if (mix_first(Fin, Fout, K)) {
         if (ldy != 0 && ldy != Fout) return DSW_ERR_BAD_ARG;   // the recurrence on the output planes runs on dense [N, Fout]
@@ -281,7 +302,10 @@ static int cheb_fwd_impl(const int32_t* rowptr, const int32_t* colind, const flo
         int folded = 0;
         // (only where it saves a pass: the staged one-hop kernels read that plane from HBM; inside a fused pair it is the
         // staged input of the first hop anyway, and the fold would only add a launch)
-        if (K >= 3 && plan != nullptr && plan->hops == 1) {
+        if (K >= 3 && plan != nullptr && plan->hops == 1 && wsa != nullptr) {
+            ex.fold = 1;        // the plane GEMM folds (while it splits W, or through a folded copy in the workspace)
+            folded = 1;
+        } else if (K >= 3 && plan != nullptr && plan->hops == 1) {
             const int64_t used = round_up((K - 1 + (K >= 4 ? 2 : 0)) * N * Fout * elem_size(dtype), 256);
             const int64_t have = (K - 1) * N * Fin * elem_size(dtype);
             if (have - used >= Fin * K * Fout * elem_size(dtype)) {
@@ -292,7 +316,7 @@ static int cheb_fwd_impl(const int32_t* rowptr, const int32_t* colind, const flo
                 folded = 1;
             }
         }
-        rc = dsw_zmix_launch(X, Wz, bias, Y, T, N, Fin, Fout, K, dtype, (hipStream_t)stream, extras ? &ex : nullptr);
+        rc = dsw_zmix_launch(X, Wz, bias, Y, T, N, Fin, Fout, K, dtype, (hipStream_t)stream, use_ex ? &ex : nullptr);
         if (rc != DSW_OK) return rc;
         // the Clenshaw recurrence has exactly the form of the adjoint recurrence (with L instead of L^T)
         rc = cheb_basis_adj_impl(rowptr, colind, vals, V, nnz, Y, T, B, Fout, K, dtype, stream, plan,
@@ -313,7 +337,21 @@ static int cheb_fwd_impl(const int32_t* rowptr, const int32_t* colind, const flo
     if (B * V < 0 || Fin <= 0 || Fout <= 0) return DSW_ERR_BAD_ARG;
     if (B * V == 0) return DSW_OK;
     if (!X || !W || !Y || (K > 1 && !T)) return DSW_ERR_BAD_ARG;
-    return dsw_mix_fwd_launch(X, T, W, bias, Y, B * V, Fin, Fout, K, dtype, (hipStream_t)stream, relu, extras ? &ex : nullptr);
+    return dsw_mix_fwd_launch(X, T, W, bias, Y, B * V, Fin, Fout, K, dtype, (hipStream_t)stream, relu, use_ex ? &ex : nullptr);
+}
+
+int64_t dsw_cheb_fwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t Fout, int64_t K, int dtype) {
+    if (B < 0 || V < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
+    if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
+    return w_image_bytes(Fin, Fout, K) + 256;
+}
+
+int dsw_cheb_fwd_ws(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V, int64_t nnz,
+                    const void* X, const void* W, const void* bias, void* Y, int64_t ldy, void* T, int64_t B, int64_t Fin,
+                    int64_t Fout, int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan, int act,
+                    const void* scale, const void* R, int64_t ldr, void* workspace, int64_t workspace_bytes) {
+    return cheb_fwd_impl(rowptr, colind, vals, V, nnz, X, W, bias, Y, T, B, Fin, Fout, K, dtype, stream, plan, act,
+                         scale, R, ldr, ldy, workspace, workspace_bytes);
 }
 
 int dsw_cheb_fwd_act(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V, int64_t nnz,
@@ -358,7 +396,7 @@ int64_t dsw_cheb_bwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t 
     const int64_t g = round_up((K - 1 + (K >= 4 ? 2 : 0)) * N * Fin * elem_size(dtype), 256);
     const int64_t S = dsw_wgrad_slabs(N, Fin, Fout, K);
     const int64_t p = round_up((S > 0 ? S : 1) * (K * Fin + 1) * Fout * 4, 256);
-    const int64_t wf = K >= 3 ? round_up(Fin * K * Fout * elem_size(dtype), 256) : 0;   // folded dgrad weights
+    const int64_t wf = round_up(w_image_bytes(Fin, Fout, K), 256);   // pre-split / folded image of the weights for the dgrad GEMM
     return g + p + wf + 256;
 }
 
@@ -369,7 +407,7 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
                  const void* dX_add, int64_t ld_add, int accumulate) {
     if (dX_add != nullptr && ld_add < Fin) return DSW_ERR_BAD_ARG;
     const bool extras = scale != nullptr || dX_add != nullptr;
-    const DswEpiExtra ex = {scale, dX_add, ld_add, 0};
+    const DswEpiExtra ex = {scale, dX_add, ld_add, 0, nullptr, 0, 0};
     if (B < 0 || V < 0 || Fin <= 0 || Fout <= 0 || K <= 0 || nnz < 0) return DSW_ERR_BAD_ARG;
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     const int64_t need = dsw_cheb_bwd_workspace_bytes(B, V, Fin, Fout, K, dtype);
@@ -420,19 +458,17 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
             return rcf;
         }
     }
-    const void* Wd = W;
-    if (folded) {     // the separate dgrad GEMMs take the folded copy of the weights
-        const int64_t S_ = dsw_wgrad_slabs(N, Fin, Fout, K);
-        void* Wf = reinterpret_cast<char*>(partial) + round_up((S_ > 0 ? S_ : 1) * (K * Fin + 1) * Fout * 4, 256);
-        rc = dsw_fold_w_launch(W, Wf, Fin, Fout, K, dtype, s);
-        if (rc != DSW_OK) return rc;
-        Wd = Wf;
-    }
     if (dX != nullptr && N > 0) {
         if (K > 1 && !rowptr_t) return DSW_ERR_BAD_ARG;
         // scale multiplies every dgrad plane (the recurrence is linear); dX_add joins plane 0 = the dX buffer, onto which
-        // the adjoint recurrence then accumulates
-        rc = dsw_mix_dgrad_launch(dY, Wd, dX, G, N, Fin, Fout, K, dtype, s, extras ? &ex : nullptr);
+        // the adjoint recurrence then accumulates.  The GEMM gets scratch for a per-call image of the weights (the streaming
+        // kernel splits W once per call into it, folding plane K-3 on the way; other kernels take a folded copy)
+        const int64_t S_ = dsw_wgrad_slabs(N, Fin, Fout, K);
+        DswEpiExtra exw = ex;
+        exw.ws = reinterpret_cast<char*>(partial) + round_up((S_ > 0 ? S_ : 1) * (K * Fin + 1) * Fout * 4, 256);
+        exw.ws_bytes = w_image_bytes(Fin, Fout, K);
+        exw.fold = folded;
+        rc = dsw_mix_dgrad_launch(dY, W, dX, G, N, Fin, Fout, K, dtype, s, &exw);
         if (rc == DSW_OK && K > 1)
             rc = cheb_basis_adj_impl(rowptr_t, colind_t, vals_t, V, nnz, dX, G, B, Fin, K, dtype, stream, plan_t,
                                      K >= 4 ? spare : nullptr, folded);

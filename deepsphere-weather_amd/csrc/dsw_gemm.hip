@@ -540,6 +540,8 @@ static int launch_ts_gemm_nt(const TsGemmParams& P, int col_tiles, hipStream_t s
     return dsw_check_launch();
 }
 
+constexpr int DSW_NEED_FOLD = 1;   // internal: launch_ts_gemm wants TsGemmParams::fold_q resolved by the caller (fold_then_launch)
+
 template <bool BF16>
 static int launch_ts_gemm(const TsGemmParams& P, hipStream_t stream) {
     const int n_total = P.n_planes_c * P.n_per_plane;
@@ -554,6 +556,7 @@ static int launch_ts_gemm(const TsGemmParams& P, hipStream_t stream) {
             int rc = DSW_OK;
             if (lds_nat > 160 * 1024 && dsw_ts_gemm_x3s_try_launch(P, stream, &rc)) return rc;
         }
+        if (P.fold_q >= 0) return DSW_NEED_FOLD;   // only the streaming kernel folds while it splits W: the caller folds and retries
         for (int nt = nat - 1; nt >= 1; --nt) {
             int rc = DSW_OK;
             // only when the natural width fails: probe it first through the normal path below
@@ -565,6 +568,7 @@ static int launch_ts_gemm(const TsGemmParams& P, hipStream_t stream) {
             if (dsw_ts_gemm_x3_try_launch(P, nt, tiles, BF16 ? 1 : 0, stream, &rc)) return rc;
         }
     }
+    if (P.fold_q >= 0) return DSW_NEED_FOLD;
     if (n_total <= 32) return launch_ts_gemm_nt<BF16, 1>(P, 1, stream);
     if (n_total <= 64) return launch_ts_gemm_nt<BF16, 2>(P, 1, stream);
     if (n_total <= 96) return launch_ts_gemm_nt<BF16, 3>(P, 1, stream);
@@ -582,12 +586,35 @@ struct DswEpiExtra {
     const void* R;
     int64_t ldr;
     int64_t ldc;
+    void* ws;            // scratch for an image of W (pre-split terms, or a folded copy), see TsGemmParams::pre_ws
+    int64_t ws_bytes;
+    int fold;            // 1: produce plane K-3 with W[:, K-3, :] - W[:, K-1, :] (launchers whose output planes are the orders k)
 };
 static inline bool epi_extra_set(const DswEpiExtra* e) { return e && (e->scale || e->R || e->ldc > 0); }
 static inline void epi_extra_apply(TsGemmParams& P, const DswEpiExtra* e) {
+    P.fold_q = -1;
     if (!e) return;
     P.scale = e->scale; P.R = e->R; P.ldr = (int)e->ldr;
     if (e->ldc > 0) P.ldc = (int)e->ldc;
+    P.pre_ws = e->ws; P.pre_bytes = (long)e->ws_bytes;
+}
+int dsw_fold_w_launch(const void* W, void* Wf, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t s);
+
+// launch_ts_gemm for the launchers whose output planes are the Chebyshev orders (dgrad planes G_k, mix-first planes Z_k):
+// with `fold` the streaming kernel folds while it splits W (pre_ws); every other kernel gets a folded COPY of W in pre_ws.
+static int fold_then_launch(TsGemmParams& P, const DswEpiExtra* e, const void* W, int64_t Fin, int64_t Fout, int64_t K,
+                            int dtype, hipStream_t stream) {
+    if (e && e->fold && K >= 3) {
+        if (!P.pre_ws) return DSW_ERR_WORKSPACE;
+        P.fold_q = (int)K - 3;
+    }
+    int rc = dtype == DSW_F32 ? launch_ts_gemm<false>(P, stream) : launch_ts_gemm<true>(P, stream);
+    if (rc != DSW_NEED_FOLD) return rc;
+    if (P.pre_bytes < Fin * K * Fout * (dtype == DSW_BF16 ? 2 : 4)) return DSW_ERR_WORKSPACE;
+    rc = dsw_fold_w_launch(W, P.pre_ws, Fin, Fout, K, dtype, stream);
+    if (rc != DSW_OK) return rc;
+    P.Bsrc = P.pre_ws; P.pre_ws = nullptr; P.pre_bytes = 0; P.fold_q = -1;
+    return dtype == DSW_F32 ? launch_ts_gemm<false>(P, stream) : launch_ts_gemm<true>(P, stream);
 }
 
 int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* bias, void* Y, int64_t N,
@@ -639,9 +666,8 @@ int dsw_mix_dgrad_launch(const void* dY, const void* W, void* G0, void* Grest, i
 #endif
     const uintptr_t am = (uintptr_t)(4 * es) - 1;
     P.a_vec = (Fout % 4 == 0) && (((uintptr_t)dY & am) == 0);
-    if (dtype == DSW_F32) return launch_ts_gemm<false>(P, stream);
-    if (dtype == DSW_BF16) return launch_ts_gemm<true>(P, stream);
-    return DSW_ERR_BAD_DTYPE;
+    if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
+    return fold_then_launch(P, extra, W, Fin, Fout, K, dtype, stream);
 }
 
 
@@ -651,7 +677,7 @@ int dsw_zmix_launch(const void* X, const void* W, const void* bias, void* Z0, vo
                     int64_t Fout, int64_t K, int dtype, hipStream_t stream, const DswEpiExtra* extra) {
     if (N == 0) return DSW_OK;
     if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
-    if (!epi_extra_set(extra)) {
+    if (!epi_extra_set(extra) && !(extra && extra->fold && K >= 3)) {   // (the vector-ALU kernel does not fold)
         int rcn = DSW_OK;
         if (dsw_narrow_fwd_try(X, W, bias, Z0, Zrest, N, Fin, Fout, K, dtype, stream, 0, &rcn)) return rcn;
     }
@@ -665,9 +691,8 @@ int dsw_zmix_launch(const void* X, const void* W, const void* bias, void* Z0, vo
     epi_extra_apply(P, extra);
     const uintptr_t am = (uintptr_t)(4 * es) - 1;
     P.a_vec = (Fin % 4 == 0) && (((uintptr_t)X & am) == 0);
-    if (dtype == DSW_F32) return launch_ts_gemm<false>(P, stream);
-    if (dtype == DSW_BF16) return launch_ts_gemm<true>(P, stream);
-    return DSW_ERR_BAD_DTYPE;
+    if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
+    return fold_then_launch(P, extra, W, Fin, Fout, K, dtype, stream);
 }
 
 // dX = sum_k D_k W_k^T with D_0 = dY and D_1.. = planes of [N, Fout] (the Chebyshev basis of dY under L^T)

@@ -70,6 +70,14 @@ struct TsGemmParams {
     const void* scale;      // ONE device scalar of the data dtype (the ReZero parameter) applied to every output plane, or null
     const void* R;          // [M, ldr] operand of the data dtype added to output PLANE 0 (later planes: nothing), or null
     int ldr;
+    // Scratch for a per-call image of the small operand (caller-owned device memory, may be null): the streaming-W kernel
+    // (dsw_gemm_x3s.hip) splits W into its three bf16 terms ONCE per call into it instead of once per workgroup and
+    // chunk; launchers without that path park a folded copy of W there.
+    void* pre_ws;
+    long pre_bytes;
+    // >= 0: output plane fold_q is produced with B(fold_q) - B(fold_q + 2) - the top of the adjoint / Clenshaw recurrence
+    // subtracts the raw plane K-1 from plane K-3, and both come out of this GEMM (dsw_api.hip, dsw_fold_w_launch).  -1: none.
+    int fold_q;
 };
 
 // epilogue activation; NaN stays NaN like torch.relu (fmaxf would turn it into 0)

@@ -37,8 +37,43 @@ static __device__ __forceinline__ float trunc_bf16(float f) {
     return __uint_as_float(__float_as_uint(f) & 0xffff0000u);
 }
 
+// Pre-split image of the small operand (TsGemmParams::pre_ws): for chunk c = a-plane * chunks + chunk, column tile t and
+// slot e = col * 16 + kp of the tile, three dwords {hi, mid, lo}, each the bf16 pair (k = 2 kp, 2 kp + 1) of one term -
+// exactly what a thread of the GEMM writes to LDS for that slot.  1.5x the fp32 bytes of W, built once per call
+// (a few microseconds), instead of ~5.5 vector instructions per element in every workgroup and chunk.
+template <int BNT>
+__global__ void x3s_presplit_kernel(const TsGemmParams P, unsigned* __restrict__ img, const int chunks, const int col_tiles) {
+    const long n_slots = (long)P.n_planes_a * chunks * col_tiles * (16 * BNT);
+    const int n_total = P.n_planes_c * P.n_per_plane;
+    const float* B = static_cast<const float*>(P.Bsrc);
+    for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < n_slots; s += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(s % (16 * BNT));
+        long r = s / (16 * BNT);
+        const int t = (int)(r % col_tiles);
+        r /= col_tiles;
+        const int kc = (int)(r % chunks), p = (int)(r / chunks);
+        const int col = e >> 4, kp = e & 15;
+        const int j = t * BNT + col;
+        float a = 0.f, b = 0.f;
+        if (j < n_total) {
+            const int q = j / P.n_per_plane, n = j - q * P.n_per_plane;
+            const long g = (long)p * P.b_sp + (long)q * P.b_sq + (long)n * P.b_sn + (long)(kc * BK + 2 * kp) * P.b_skd;
+            a = B[g]; b = B[g + P.b_skd];
+            if (q == P.fold_q) { a -= B[g + 2 * P.b_sq]; b -= B[g + 2 * P.b_sq + P.b_skd]; }
+        }
+        const float ah = trunc_bf16(a), bh = trunc_bf16(b);
+        const float a1 = a - ah, b1 = b - bh;
+        const float am = trunc_bf16(a1), bm = trunc_bf16(b1);
+        const float al = a1 - am, bl = b1 - bm;
+        img[3 * s] = __builtin_amdgcn_perm(__float_as_uint(bh), __float_as_uint(ah), 0x07060302u);
+        img[3 * s + 1] = __builtin_amdgcn_perm(__float_as_uint(bm), __float_as_uint(am), 0x07060302u);
+        img[3 * s + 2] = __builtin_amdgcn_perm(__float_as_uint(bl), __float_as_uint(al), 0x07060302u);
+    }
+}
+
 // KFAST: the B operand is contiguous along the reduction index (dgrad: W^T), else along the columns (forward).
-template <int NT, int NWV, bool KFAST, bool RES = false>
+// PRE: the W chunk comes pre-split from TsGemmParams::pre_ws (x3s_presplit_kernel) - three ready-made dwords per slot.
+template <int NT, int NWV, bool KFAST, bool RES = false, bool PRE = false>
 __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParams P) {
     constexpr int BMT = 32 * NWV;
     constexpr int NTH = 64 * NWV;
@@ -92,8 +127,8 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
         int e = tid + NTH * i;
         const bool slot_ok = !BTAIL || e < 16 * BNT;
         if (!slot_ok) e = 16 * BNT - 1;
-        const int col = KFAST ? e >> 4 : e % BNT;
-        const int kp = KFAST ? e & 15 : e / BNT;
+        const int col = (KFAST || PRE) ? e >> 4 : e % BNT;
+        const int kp = (KFAST || PRE) ? e & 15 : e / BNT;
         bslot_lds[i] = slot_ok ? col * KSB + 2 * kp : -1;
         const int j = col0 + col;
         if (j < n_total) {
@@ -104,19 +139,45 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
         }
     }
     const float* Bsrc = static_cast<const float*>(P.Bsrc);
-    float rb0[NPAIR][2], rb1[NPAIR][2], rb2[NPAIR][2];   // W ring: same depth / slot numbering as the A ring
+    constexpr int RBW = PRE ? 3 : 2;                     // dwords per slot in the W ring: three packed terms, or two fp32 values
+    float rb0[NPAIR][RBW], rb1[NPAIR][RBW], rb2[NPAIR][RBW];   // W ring: same depth / slot numbering as the A ring
     int bp = 0, bkc = 0;   // (plane, chunk) of the NEXT W chunk to fetch: cycles through the reduction, no clamp
-    auto fetch_b = [&](float (&rb)[NPAIR][2]) __attribute__((always_inline)) {
-        const long origin = (long)bp * P.b_sp + (long)(bkc * BK) * P.b_skd;
+    typedef float f32x3_t __attribute__((ext_vector_type(3)));
+    const float* Bimg = static_cast<const float*>(P.pre_ws);
+    auto fetch_b = [&](float (&rb)[NPAIR][RBW]) __attribute__((always_inline)) {
+        if constexpr (PRE) {
+            // image of (chunk, this column tile): 16 * BNT slots of 12 bytes, slot e = tid + NTH * i
+            const long origin = (((long)bp * chunks + bkc) * gridDim.y + blockIdx.y) * (16L * BNT) * 3;
 #pragma unroll
-        for (int i = 0; i < NPAIR; ++i) {
-            const long g = bslot_g[i] < 0 ? 0 : bslot_g[i];
-            rb[i][0] = Bsrc[origin + g];            // unconditional (clamped) loads: nothing may consume the value
-            rb[i][1] = Bsrc[origin + g + P.b_skd];  // here, or the compiler parks a vmcnt(0) right behind them
+            for (int i = 0; i < NPAIR; ++i) {
+                int e = tid + NTH * i;
+                if (BTAIL && e >= 16 * BNT) e = 16 * BNT - 1;
+                const f32x3_t v = *reinterpret_cast<const f32x3_t*>(Bimg + origin + 3L * e);
+                rb[i][0] = v[0]; rb[i][1] = v[1]; rb[i][2] = v[2];
+            }
+        } else {
+            const long origin = (long)bp * P.b_sp + (long)(bkc * BK) * P.b_skd;
+#pragma unroll
+            for (int i = 0; i < NPAIR; ++i) {
+                const long g = bslot_g[i] < 0 ? 0 : bslot_g[i];
+                rb[i][0] = Bsrc[origin + g];            // unconditional (clamped) loads: nothing may consume the value
+                rb[i][1] = Bsrc[origin + g + P.b_skd];  // here, or the compiler parks a vmcnt(0) right behind them
+            }
         }
         if (++bkc == chunks) { bkc = 0; if (++bp == P.n_planes_a) bp = 0; }
     };
-    auto store_b = [&](unsigned short* buf, const float (&rb)[NPAIR][2]) __attribute__((always_inline)) {
+    auto store_b = [&](unsigned short* buf, const float (&rb)[NPAIR][RBW]) __attribute__((always_inline)) {
+        if constexpr (PRE) {
+#pragma unroll
+            for (int i = 0; i < NPAIR; ++i) {
+                if (BTAIL && bslot_lds[i] < 0) continue;
+                uint32_t* dst = reinterpret_cast<uint32_t*>(buf + bslot_lds[i]);
+                dst[0] = __float_as_uint(rb[i][0]);
+                dst[BPLANE / 2] = __float_as_uint(rb[i][1]);
+                dst[BPLANE] = __float_as_uint(rb[i][2]);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NPAIR; ++i) {
             const float a = bslot_g[i] < 0 ? 0.f : rb[i][0], b = bslot_g[i] < 0 ? 0.f : rb[i][1];
@@ -179,7 +240,7 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
             else if constexpr (v == 1) return &ra1;
             else return &ra2;
         }();
-        float (&bslot)[NPAIR][2] = *[&]() -> float (*)[NPAIR][2] {
+        float (&bslot)[NPAIR][RBW] = *[&]() -> float (*)[NPAIR][RBW] {
             if constexpr (v == 0) return &rb0;
             else if constexpr (v == 1) return &rb1;
             else return &rb2;
@@ -254,12 +315,12 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
     }
 }
 
-template <int NT, int NWV, bool KFAST, bool RES = false>
+template <int NT, int NWV, bool KFAST, bool RES = false, bool PRE = false>
 int launch_x3s(const TsGemmParams& P, int col_tiles, hipStream_t stream) {
     constexpr int BMT = 32 * NWV;
     const size_t lds = (size_t)2 * BMT * LDA * 4 + (size_t)2 * 3 * (32 * NT) * KSB * 2;
     const long row_tiles = (P.M + BMT - 1) / BMT;
-    const void* kfn = (const void*)ts_gemm_x3s_kernel<NT, NWV, KFAST, RES>;
+    const void* kfn = (const void*)ts_gemm_x3s_kernel<NT, NWV, KFAST, RES, PRE>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DSW_ERR_LAUNCH;
@@ -270,7 +331,7 @@ int launch_x3s(const TsGemmParams& P, int col_tiles, hipStream_t stream) {
     if (gx > row_tiles) gx = row_tiles;
     if (col_tiles > 1 && gx >= 8) gx &= ~7L;   // column tiles of one row tile on one XCD (A re-reads hit its L2)
     dim3 grid((unsigned)gx, (unsigned)col_tiles);
-    hipLaunchKernelGGL((ts_gemm_x3s_kernel<NT, NWV, KFAST, RES>), grid, dim3(64 * NWV), lds, stream, P);
+    hipLaunchKernelGGL((ts_gemm_x3s_kernel<NT, NWV, KFAST, RES, PRE>), grid, dim3(64 * NWV), lds, stream, P);
     return dsw_check_launch();
 }
 
@@ -295,8 +356,24 @@ int dsw_ts_gemm_x3s_try_launch(const TsGemmParams& P, hipStream_t stream, int* r
     static const char* nwvenv = dsw_diag_env("DSW_X3S_NWV");
     const long tiles8 = ((P.M + 255) / 256) * col_tiles;
     const int nwv = nwvenv ? atoi(nwvenv) : (tiles8 < 128 ? 4 : 8);
+    // W split once per call into the caller's scratch (with the fold of output plane fold_q, if any) when there is room
+    static const char* preenv = dsw_diag_env("DSW_X3S_PRE");   // "0": split W per workgroup and chunk (diagnostics / A-B)
+    const int chunks_ = P.kd_per_plane / BK;
+    const long img_bytes = (long)P.n_planes_a * chunks_ * col_tiles * (16L * 32 * nt) * 12;
+    const bool pre = !(preenv && preenv[0] == '0') && P.pre_ws != nullptr && P.pre_bytes >= img_bytes &&
+                     (((uintptr_t)P.pre_ws) & 15u) == 0;
+    if (!pre && P.fold_q >= 0) return 0;       // the caller folds the weights itself and comes back without fold_q
+    if (pre) {
+        const long n_slots = img_bytes / 12;
+        const int blocks = (int)((n_slots + 255) / 256 < 2048 ? (n_slots + 255) / 256 : 2048);
+        if (nt == 4) hipLaunchKernelGGL((x3s_presplit_kernel<128>), dim3(blocks), dim3(256), 0, stream, P, static_cast<unsigned*>(P.pre_ws), chunks_, col_tiles);
+        else hipLaunchKernelGGL((x3s_presplit_kernel<64>), dim3(blocks), dim3(256), 0, stream, P, static_cast<unsigned*>(P.pre_ws), chunks_, col_tiles);
+        if ((*rc = dsw_check_launch()) != DSW_OK) return 1;
+    }
 #define DSW_X3S(NT_, NWV_)                                                                                          \
-    (*rc = res ? (kfast ? launch_x3s<NT_, NWV_, true, true>(P, col_tiles, stream)                                   \
+    (*rc = pre ? (res ? launch_x3s<NT_, NWV_, false, true, true>(P, col_tiles, stream)                              \
+                      : launch_x3s<NT_, NWV_, false, false, true>(P, col_tiles, stream))                            \
+         : res ? (kfast ? launch_x3s<NT_, NWV_, true, true>(P, col_tiles, stream)                                   \
                         : launch_x3s<NT_, NWV_, false, true>(P, col_tiles, stream))                                 \
                : (kfast ? launch_x3s<NT_, NWV_, true>(P, col_tiles, stream) : launch_x3s<NT_, NWV_, false>(P, col_tiles, stream)))
 #define DSW_X3S_NWV(NT_)                                                                     \

@@ -80,6 +80,12 @@ SIGNATURES = {
         [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
          _i64, _int, _vp, _vp, _vp, _vp, _i64, _int],
     ),
+    "dsw_cheb_fwd_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64, _i64, _int]),
+    "dsw_cheb_fwd_ws": (
+        _int,
+        [_i32p, _i32p, _f32p, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _int,
+         _vp, _vp, _i64, _vp, _i64],
+    ),
     "dsw_rezero_param_grads_workspace_bytes": (_i64, []),
     "dsw_rezero_param_grads": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _int, _vp]),
     "dsw_cheb_bwd_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64, _i64, _int]),

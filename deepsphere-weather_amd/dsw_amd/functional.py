@@ -351,14 +351,26 @@ class _HipBackend:
                      if (K > 1 and (_FWD_FUSED or mix_first)) else (None, None))
         csr = (None, None, None, V, 0) if op is None else (
             op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz)
+        ws, nws = self._fwd_workspace(lib, x, Fin, Fout, K)
         with torch.cuda.device(x.device):
-            rc = lib.dsw_cheb_fwd_act(
+            rc = lib.dsw_cheb_fwd_ws(
                 *csr,
-                x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(T), B, Fin, Fout, K,
-                _DTYPES[x.dtype], _stream(x), pp, 1 if relu else 0,
+                x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), Fout, _ptr(T), B, Fin, Fout, K,
+                _DTYPES[x.dtype], _stream(x), pp, 1 if relu else 0, None, None, 0, _ptr(ws), nws,
             )
-        _native.check(rc, "dsw_cheb_fwd_act")
+        _native.check(rc, "dsw_cheb_fwd_ws")
         return y, (None if mix_first else T)
+
+    @staticmethod
+    def _fwd_workspace(lib, x, Fin, Fout, K):
+        """Scratch for the per-call weight image of the forward (dsw_cheb_fwd_workspace_bytes): only wide fp32 layers (the
+        streaming-W GEMM) and mix-first layers use it; the 32-channel layers of the one-launch forward get none."""
+        if x.dtype != torch.float32 or K * Fin * Fout < 3 * 64 * 128:
+            return None, 0
+        n = int(lib.dsw_cheb_fwd_workspace_bytes(x.shape[0], x.shape[1], Fin, Fout, K, _DTYPES[x.dtype]))
+        if n < 0:
+            _native.check(n, "dsw_cheb_fwd_workspace_bytes")
+        return torch.empty((n,), dtype=torch.uint8, device=x.device), n
 
     def cheb_bwd(self, op, x, T, w, dy, need_dx, need_dw, need_db):
         lib = _native.load()
@@ -402,12 +414,14 @@ class _HipBackend:
                      if (K > 1 and (_FWD_FUSED or mix_first)) else (None, None))
         csr = (None, None, None, V, 0) if op is None else (
             op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz)
+        ws, nws = self._fwd_workspace(lib, x, Fin, Fout, K)
         with torch.cuda.device(x.device):
-            rc = lib.dsw_cheb_fwd_res(
+            rc = lib.dsw_cheb_fwd_ws(
                 *csr, x.data_ptr(), w.data_ptr(), _ptr(bias), y.data_ptr(), row_stride(y), _ptr(T), B, Fin, Fout, K,
                 _DTYPES[x.dtype], _stream(x), pp, 0, _ptr(scale), _ptr(res), 0 if res is None else row_stride(res),
+                _ptr(ws), nws,
             )
-        _native.check(rc, "dsw_cheb_fwd_res")
+        _native.check(rc, "dsw_cheb_fwd_ws")
         return y, (None if mix_first else T)
 
     def cheb_bwd_res(self, op, x, T, w, dy, need_dx, need_dw, scale=None, dx_add=None, acc_w=None, acc_b=None):

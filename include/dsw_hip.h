@@ -204,6 +204,18 @@ int dsw_cheb_fwd_res(const int32_t* rowptr, const int32_t* colind, const float* 
                      int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan, int act,
                      const void* scale, const void* R, int64_t ldr);
 
+/* dsw_cheb_fwd_res with caller-owned scratch (dsw_cheb_fwd_workspace_bytes; NULL / 0 = none): room for a per-call image of
+ * the weights.  The channel-mix GEMM of WIDE fp32 layers streams W chunk by chunk next to the activations and evaluates
+ * the fp32 product on the bf16 matrix pipe from three-term splits of both operands; with the scratch W is split ONCE per call
+ * (1.5x its fp32 bytes) instead of once per workgroup and chunk, and mix-first layers on dense stencils fold plane K-1 into
+ * the weights of plane K-3 there (one epilogue operand less in the recurrence).  Same results as without it. */
+int64_t dsw_cheb_fwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t Fout, int64_t K, int dtype);
+int dsw_cheb_fwd_ws(const int32_t* rowptr, const int32_t* colind, const float* vals,
+                    int64_t V, int64_t nnz, const void* X, const void* W, const void* bias,
+                    void* Y, int64_t ldy, void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K,
+                    int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan, int act,
+                    const void* scale, const void* R, int64_t ldr, void* workspace, int64_t workspace_bytes);
+
 /* Backward of that activation (autograd of F.relu, what the reference's ConvBlock records):
  *     dYm[i] = Y[i] > 0 ? dY[i] : 0          (Y = the layer's activated output; n elements; dYm may alias dY) */
 int dsw_relu_bwd(const void* dY, const void* Y, void* dYm, int64_t n, int dtype, dsw_stream_t stream);
