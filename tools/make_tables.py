@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Regenerate the measurement / parity tables of DESIGN.md from the committed profiles (prose and data must
-not drift).  usage: tools/make_tables.py <round tag, e.g. r03> [--write]
+"""Regenerate the measurement / parity tables of DESIGN.md from the committed profiles (prose and data must not drift).
+usage: tools/make_tables.py <round tag, e.g. r04> [--write]
 
-Reads profiles/<tag>_bench_*.json (bench.py lines), profiles/<tag>_*_kernel_stats.csv (rocprofv3 --kernel-trace --stats of
-the same commands), profiles/spmm_traffic.json (PMC passes: 2 x FETCH_SIZE + WRITE_SIZE) and
+Reads profiles/<tag>_bench_*.json (bench.py lines, each carrying the counter bytes of profiles/spmm_traffic.json),
+profiles/<tag>_*_kernel_stats.csv (rocprofv3 --kernel-trace --stats of the same commands) and
 profiles/<tag>_parity_fullsize.json (tests/test_hip_fullsize.py); prints markdown, and with --write replaces the text
 between the GENERATED markers of DESIGN.md."""
 import csv
@@ -14,33 +14,43 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
-HBM = 8000.0
+tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r04"
 
 
 def load(name):
     path = os.path.join(P, name)
-    return json.load(open(path)) if os.path.exists(path) else None
+    if not os.path.exists(path):
+        return None
+    txt = open(path).read().strip()
+    try:
+        return json.loads(txt)
+    except ValueError:
+        return json.loads(txt.splitlines()[-1])
 
 
 def stats(name):
     path = os.path.join(P, name)
-    rows = {}
+    rows = []
     if os.path.exists(path):
         for r in csv.DictReader(open(path)):
-            n = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+            n = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("dsw_gemm::", "")
             n = re.sub(r"\(.*", "", n)
-            rows[n] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["Percentage"]))
+            rows.append((n, int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
     return rows
+
+
+def f(v, fmt="%.3f"):
+    return "-" if v is None else fmt % v
 
 
 out = []
 w = out.append
-w("| workload (`profiles/%s_bench_*.json`) | ms / step | nodes·channels/s | SpMM recurrences / 8 TB/s | forward recurrence alone (gate 0.60) | per-step HIP events (median, p10-p90) | CPU baseline (oracle port, same box) |" % tag)
-w("|---|---|---|---|---|---|---|")
-names = {"ns_default": "**NS** (default command): nside 64, K 3, 32->64, B 16, fp32, k = 8", "ns_k20": "NS shape, k = 20 stencil (the reference's default graph)",
+names = {"ns_default": "**NS** (default command): nside 64, K 3, 32->64, B 16, fp32, k = 8",
+         "ns_k20": "NS shape, k = 20 stencil (the reference's default graph)",
          "c3": "C3: K 5, 64->128, bf16 (configs[2])", "unet": "C2: UNetSpherical nside 32, B 8, k = 20 (configs[1])",
          "c5": "C5: equiangular 200 x 400 + cross-sampling pooling (configs[4])"}
+w("| workload (`profiles/%s_bench_*.json`) | ms / step | nodes·channels/s | in-step SpMM launches: 8d bytes / 8 TB/s (counter bytes) | forward recurrence (gate 0.60; counter) | adjoint recurrence (counter) | pooling products | per-step HIP events (median, p10-p90) | CPU baseline (oracle port, same box) |" % tag)
+w("|---|---|---|---|---|---|---|---|---|")
 lines = {}
 for key, label in names.items():
     d = load("%s_bench_%s.json" % (tag, key))
@@ -48,42 +58,56 @@ for key, label in names.items():
         continue
     lines[key] = d
     r = d.get("roofline") or {}
+    fr, ar, po = r.get("forward_recurrence") or {}, r.get("adjoint_recurrence") or {}, r.get("pooling") or {}
     ps = d.get("per_step_us") or {}
     cb = d.get("cpu_baseline") or {}
-    w("| %s | **%.4f** | %.3g | %s | %s | %s | %s |" % (
-        label, d["ms_per_step"], d["value"], r.get("frac", "-"), r.get("fwd_recurrence_frac", "-"),
+    w("| %s | **%.4f** | %.3g | %s (%s)%s | %s (%s)%s | %s (%s) | %s | %s | %s |" % (
+        label, d["ms_per_step"], d["value"], f(r.get("frac")), f(r.get("frac_counter")), ", fused" if r.get("fused") else "",
+        f(fr.get("frac")), f(fr.get("frac_counter")), "" if fr.get("in_step") else ", leg only",
+        f(ar.get("frac")), f(ar.get("frac_counter")),
+        "%s (%s), %.0f us / step" % (f(po.get("frac")), f(po.get("frac_counter")), po["us_per_step"]) if po else "-",
         "%s us (%s-%s)" % (ps.get("median"), ps.get("p10"), ps.get("p90")) if ps else "-",
         "%.2g /s on %s threads of %s" % (cb["value"], cb.get("cores"), cb.get("host_cpus")) if cb else "-"))
 w("")
-w("In-step kernels of the default command (`roofline.in_step` of the bench line: HIP events on the launch stream; "
-  "algorithmic bytes = SURVEY 8d pass counts) next to rocprofv3 of the same command (`profiles/%s_default_kernel_stats.csv`) "
-  "and the PMC traffic (`profiles/spmm_traffic.json`, `%s_ns_pmc_summary.txt`):" % (tag, tag))
+w("`frac` = SURVEY 8(d) algorithmic bytes / HIP-event time / 8 TB/s; in brackets the same time against the HBM bytes the "
+  "counters saw for exactly these launches (`profiles/spmm_traffic.json`, `tools/pmc_traffic.sh`: 2 x FETCH_SIZE + WRITE_SIZE). "
+  "A fused pair keeps its intermediate plane on chip: its 8(d) fraction can exceed 1 while the counter fraction says what the "
+  "memory system delivered; staged one-hop launches move slightly MORE than the 8(d) count (halo rows that miss L2).")
 w("")
-w("| role | bench leg us | algorithmic MB -> fraction of 8 TB/s | rocprofv3 kernel (avg us, % of GPU time) | measured HBM MB (read + write) -> TB/s |")
-w("|---|---|---|---|---|")
 ns = lines.get("ns_default")
 st = stats("%s_default_kernel_stats.csv" % tag)
-tr = (load("spmm_traffic.json") or {}).get("ns", {}).get("kernels", {})
-match = {"forward": "cheb3_fwd_fused_kernel", "backward GEMM": "cheb_wgrad_x3_kernel", "adjoint": "spmm2_fused_kernel<false, 3, true, true"}
-if ns and ns.get("roofline", {}).get("in_step"):
+if ns and (ns.get("roofline") or {}).get("in_step"):
+    w("In-step kernels of the default command (`roofline.in_step`: HIP events on the launch stream, SURVEY 8d bytes) next to "
+      "rocprofv3 of the same command (`profiles/%s_default_kernel_stats.csv`):" % tag)
+    w("")
+    w("| role | bench leg us | algorithmic MB -> fraction of 8 TB/s | rocprofv3 kernel (avg us, % of GPU time) |")
+    w("|---|---|---|---|")
+    match = {"forward": "cheb3_fwd_fused_kernel", "backward GEMM": "cheb_wgrad_x3_kernel", "adjoint": "spmm2_fused_kernel<false, 3, true, true"}
     for e in ns["roofline"]["in_step"]:
         pat = next((v for k, v in match.items() if e["role"].startswith(k)), None)
-        kn = next((n for n in st if pat and n.startswith(pat)), None)
-        tk = next((n for n in tr if pat and n.startswith(pat)), None)
-        prof = "`%s` %.1f us, %.1f %%" % (kn[:48], st[kn][1], st[kn][2]) if kn else "-"
-        hbm = "-"
-        if tk and kn:
-            b = tr[tk]["read"] + tr[tk]["write"]
-            hbm = "%.0f + %.0f = %.0f -> %.2f" % (tr[tk]["read"] / 1e6, tr[tk]["write"] / 1e6, b / 1e6, b / st[kn][1] / 1e6)
-        w("| %s | %.1f | %.0f -> %.2f | %s | %s |" % (e["role"], e["avg_us"], e["algorithmic_bytes"] / 1e6, e["frac"], prof, hbm))
-w("")
-for key, fn in (("ns_k20", "k20"), ("c3", "c3"), ("unet", "unet"), ("c5", "c5")):
-    st = stats("%s_%s_kernel_stats.csv" % (tag, fn))
-    if not st:
+        kn = next((r_ for r_ in st if pat and r_[0].startswith(pat)), None)
+        prof = "`%s` %.1f us, %.1f %%" % (kn[0][:52], kn[2], kn[3]) if kn else "-"
+        w("| %s | %.1f | %.0f -> %.2f | %s |" % (e["role"], e["avg_us"], e["algorithmic_bytes"] / 1e6, e["frac"], prof))
+    w("")
+for key, fn in (("ns_default", "default"), ("ns_k20", "k20"), ("c3", "c3"), ("unet", "unet"), ("c5", "c5")):
+    rows = stats("%s_%s_kernel_stats.csv" % (tag, fn))
+    if not rows:
         continue
-    top = sorted(st.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:6]
-    w("%s (`profiles/%s_%s_kernel_stats.csv`), top kernels by total time: " % (key, tag, fn) + "; ".join(
-        "`%s` %d x %.1f us (%.1f %%)" % (n[:44], c, a, p) for n, (c, a, p) in top) + ".")
+    top = sorted(rows, key=lambda r_: -r_[1] * r_[2])[:7]
+    w("%s (`profiles/%s_%s_kernel_stats.csv`), top kernels by total time: %s." % (
+        key, tag, fn, "; ".join("`%s` %d x %.1f us (%.1f %%)" % (n[:46], c, us, pct) for n, c, us, pct in top)))
+    w("")
+for key in ("unet", "c5"):
+    po = ((lines.get(key) or {}).get("roofline") or {}).get("pooling")
+    if not po:
+        continue
+    w("Pooling products of %s (`roofline.pooling`; bytes = input rows + output rows + operator):" % key)
+    w("")
+    w("| layer | product | rows out x in | channels | entries / row | us | fraction of 8 TB/s |")
+    w("|---|---|---|---|---|---|---|")
+    for e in po["products"]:
+        w("| %s | %s | %d x %d | %d | %s | %.1f | %.2f |" % (e["layer"], e["product"], e["rows_out"], e["rows_in"], e["channels"],
+                                                            e["nnz_per_row"], e["us"], e["frac"]))
     w("")
 par = load("%s_parity_fullsize.json" % tag)
 if par:
@@ -91,8 +115,9 @@ if par:
     w("")
     w("| case | measured |")
     w("|---|---|")
-    for k, v in par.items():
-        w("| %s | %s |" % (k, ", ".join("%s %.2g" % (a, b) for a, b in v.items() if isinstance(b, (int, float)))))
+    for k in sorted(par):
+        v = par[k]
+        w("| %s | %s |" % (k, ", ".join("%s %.2g" % (kk, vv) for kk, vv in sorted(v.items()) if isinstance(vv, (int, float)))))
 text = "\n".join(out)
 print(text)
 if "--write" in sys.argv:
@@ -102,6 +127,6 @@ if "--write" in sys.argv:
     if a in s and b in s:
         s = s[:s.index(a) + len(a)] + "\n" + text + "\n" + s[s.index(b):]
         open(path, "w").write(s)
-        print("\n[make_tables] DESIGN.md updated", file=sys.stderr)
+        print("\n[DESIGN.md updated]", file=sys.stderr)
     else:
-        print("\n[make_tables] markers not found in DESIGN.md", file=sys.stderr)
+        print("\n[markers %s / %s not found in DESIGN.md]" % (a, b), file=sys.stderr)
