@@ -348,13 +348,18 @@ int dsw_ts_gemm_x3s_try_launch(const TsGemmParams& P, hipStream_t stream, int* r
     const int n_total = P.n_planes_c * P.n_per_plane;
     const bool kfast = P.b_skd == 1;
     const bool res = P.R != nullptr || P.scale != nullptr;     // epilogue operands: separate instantiations
-    const int nt = n_total > 64 ? 4 : 2;
-    const int col_tiles = (n_total + 32 * nt - 1) / (32 * nt);
-    // waves per workgroup (tile rows = 32 * waves).  Measured over the UNet shapes: a chunk step costs about the same
-    // for 4..8 waves (it is latency- not throughput-bound), so the 256-row tile wins whenever it still gives at
-    // least half of the CUs a workgroup; tiny grids (nside=8 levels) take 128-row tiles to spread over more CUs.
+    // Tile shape.  256 x 128 (8 waves) is the fastest shape per CU (a chunk step costs 3.6 us there against 2.7-3.0 us for
+    // the half-size shapes), but a launch that gives fewer than half of the CUs a workgroup is better served by more, smaller
+    // tiles: 64-column tiles double the workgroups (A is re-read out of L2), 128-row tiles double them again.  Measured
+    // (tools/bench_gemm.py, 6 144 rows): 512 -> 256 102 -> 66 us with 128 x 64 tiles, 256 -> 512 58 -> 47 us with 256 x 64.
+    static const char* ntenv = dsw_diag_env("DSW_X3S_NT");     // diagnostics: force 64-column tiles ("2")
     static const char* nwvenv = dsw_diag_env("DSW_X3S_NWV");
-    const long tiles8 = ((P.M + 255) / 256) * col_tiles;
+    const long row_tiles8 = (P.M + 255) / 256;
+    int nt = n_total > 64 ? 4 : 2;
+    if (nt == 4 && row_tiles8 * ((n_total + 127) / 128) < 128) nt = 2;
+    if (ntenv) nt = ntenv[0] == '2' ? 2 : (n_total > 64 ? 4 : 2);
+    const int col_tiles = (n_total + 32 * nt - 1) / (32 * nt);
+    const long tiles8 = row_tiles8 * col_tiles;
     const int nwv = nwvenv ? atoi(nwvenv) : (tiles8 < 128 ? 4 : 8);
     // W split once per call into the caller's scratch (with the fold of output plane fold_q, if any) when there is room
     static const char* preenv = dsw_diag_env("DSW_X3S_PRE");   // "0": split W per workgroup and chunk (diagnostics / A-B)
