@@ -64,6 +64,8 @@ static __device__ __forceinline__ void split_store(unsigned short* dst, const in
         const float m0 = trunc_bf16(r0), m1 = trunc_bf16(r1), m2 = trunc_bf16(r2), m3 = trunc_bf16(r3);
         *reinterpret_cast<u32x2*>(dst + plane_elems) = pack4(m0, m1, m2, m3);
         *reinterpret_cast<u32x2*>(dst + 2 * plane_elems) = pack4(r0 - m0, r1 - m1, r2 - m2, r3 - m3);
+        // (the residuals as register pairs - v_pk_add_f32, half the subtractions - measured +-0 on the NS step and the U-Net
+        // in round 4: the split is not what this loop waits for)
     }
 }
 
