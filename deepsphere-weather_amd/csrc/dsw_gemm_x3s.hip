@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
 
     // ---- W chunk: this thread's NPAIR (column, k-pair) slots; the global offset of a slot inside chunk 0
     int bslot_lds[NPAIR];     // element offset of the pair inside a plane of a B buffer
-    long bslot_g[NPAIR];      // element offset of W(k = 2*kp, col) relative to the chunk origin; < 0: column out of range
+    int bslot_g[NPAIR];       // BYTE offset of W(k = 2*kp, col) relative to the chunk origin; < 0: column out of range
 #pragma unroll
     for (int i = 0; i < NPAIR; ++i) {
         int e = tid + NTH * i;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
         const int j = col0 + col;
         if (j < n_total) {
             const int q = j / P.n_per_plane, n = j - q * P.n_per_plane;
-            bslot_g[i] = (long)q * P.b_sq + (long)n * P.b_sn + (long)(2 * kp) * P.b_skd;
+            bslot_g[i] = (int)(((long)q * P.b_sq + (long)n * P.b_sn + (long)(2 * kp) * P.b_skd) * 4);   // W is a few MB
         } else {
             bslot_g[i] = -1;
         }
@@ -147,21 +147,23 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
     auto fetch_b = [&](float (&rb)[NPAIR][RBW]) __attribute__((always_inline)) {
         if constexpr (PRE) {
             // image of (chunk, this column tile): 16 * BNT slots of 12 bytes, slot e = tid + NTH * i
-            const long origin = (((long)bp * chunks + bkc) * gridDim.y + blockIdx.y) * (16L * BNT) * 3;
+            const char* origin = reinterpret_cast<const char*>(Bimg + (((long)bp * chunks + bkc) * gridDim.y + blockIdx.y) * (16L * BNT) * 3);
 #pragma unroll
             for (int i = 0; i < NPAIR; ++i) {
                 int e = tid + NTH * i;
                 if (BTAIL && e >= 16 * BNT) e = 16 * BNT - 1;
-                const f32x3_t v = *reinterpret_cast<const f32x3_t*>(Bimg + origin + 3L * e);
+                const f32x3_t v = *reinterpret_cast<const f32x3_t*>(origin + 12u * (unsigned)e);
                 rb[i][0] = v[0]; rb[i][1] = v[1]; rb[i][2] = v[2];
             }
         } else {
-            const long origin = (long)bp * P.b_sp + (long)(bkc * BK) * P.b_skd;
+            // uniform chunk origin (and origin + one reduction step) + the slot's 32-bit byte offset
+            const char* o0 = reinterpret_cast<const char*>(Bsrc + (long)bp * P.b_sp + (long)(bkc * BK) * P.b_skd);
+            const char* o1 = o0 + P.b_skd * 4;
 #pragma unroll
             for (int i = 0; i < NPAIR; ++i) {
-                const long g = bslot_g[i] < 0 ? 0 : bslot_g[i];
-                rb[i][0] = Bsrc[origin + g];            // unconditional (clamped) loads: nothing may consume the value
-                rb[i][1] = Bsrc[origin + g + P.b_skd];  // here, or the compiler parks a vmcnt(0) right behind them
+                const unsigned g = bslot_g[i] < 0 ? 0u : (unsigned)bslot_g[i];
+                rb[i][0] = *reinterpret_cast<const float*>(o0 + g);   // unconditional (clamped) loads: nothing may consume the value
+                rb[i][1] = *reinterpret_cast<const float*>(o1 + g);   // here, or the compiler parks a vmcnt(0) right behind them
             }
         }
         if (++bkc == chunks) { bkc = 0; if (++bp == P.n_planes_a) bp = 0; }
@@ -203,16 +205,24 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
     TileChunkIter cur, pre;   // the chunk being multiplied / the chunk being prefetched (PF ahead, clamped)
     cur.init((long)blockIdx.x * BMT);
     pre.init((long)blockIdx.x * BMT);
+    // Addresses of the A loads = a UNIFORM pointer (plane, chunk: scalar registers, advanced by the scalar unit) + this lane's
+    // 32-bit byte offset inside the plane (row * lda + column, fixed for a row tile).  The first form recomputed
+    // (row * lda + plane * stride + k) in 64-bit vector arithmetic for every load: an in-kernel cycle timeline
+    // (tools/x3s_timeline.py) showed 750 of the 5 800 cycles of a chunk step in issuing its 12 loads.
+    unsigned arow_off[4];
     auto fetch = [&](f32x4 (&dra)[4]) __attribute__((always_inline)) {   // A rows of chunk `pre`, then advance it
-        const float* A = static_cast<const float*>((pre.p == 0) ? P.A0 : P.A1);
-        const size_t abase = (pre.p == 0) ? 0 : (size_t)(pre.p - 1) * P.a_plane_stride;
-        const int k0 = pre.kc * BK;
+        if (pre.c == 0) {                                               // uniform: first chunk of a row tile
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            long r = pre.row0 + ar + 8 * i;
-            r = r < P.M ? r : P.M - 1;
-            dra[i] = *reinterpret_cast<const f32x4*>(A + abase + (size_t)r * P.lda + k0 + ac4);
+            for (int i = 0; i < 4; ++i) {
+                long r = pre.row0 + ar + 8 * i;
+                r = r < P.M ? r : P.M - 1;
+                arow_off[i] = (unsigned)(((size_t)r * P.lda + ac4) * 4);    // < 4 GiB (checked by the launcher)
+            }
         }
+        const char* abase = reinterpret_cast<const char*>(static_cast<const float*>((pre.p == 0) ? P.A0 : P.A1) +
+                                                          ((pre.p == 0) ? 0 : (size_t)(pre.p - 1) * P.a_plane_stride) + pre.kc * BK);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dra[i] = *reinterpret_cast<const f32x4*>(abase + arow_off[i]);
         pre.next_clamped(n_iter, chunks, total, row_step);
     };
     if (n_iter <= 0) return;
@@ -345,7 +355,10 @@ int dsw_ts_gemm_x3s_try_launch(const TsGemmParams& P, hipStream_t stream, int* r
     static const char* senv = dsw_diag_env("DSW_GEMM_X3S");   // "0": disable only the streaming variant
     if (senv && senv[0] == '0') return 0;
     if (!P.a_vec || P.kd_per_plane % BK != 0 || P.M <= 0) return 0;
+    if ((unsigned long long)P.M * (unsigned long long)P.lda * 4ull >= (1ull << 32)) return 0;   // 32-bit row offsets inside a plane
     const int n_total = P.n_planes_c * P.n_per_plane;
+    if (((long)P.n_planes_c * (P.b_sq < 0 ? -P.b_sq : P.b_sq) + (long)P.n_per_plane * (P.b_sn < 0 ? -P.b_sn : P.b_sn) +
+         32L * (P.b_skd < 0 ? -P.b_skd : P.b_skd)) * 4 >= (1L << 31)) return 0;                 // 32-bit slot offsets inside a chunk
     const bool kfast = P.b_skd == 1;
     const bool res = P.R != nullptr || P.scale != nullptr;     // epilogue operands: separate instantiations
     // Tile shape.  256 x 128 (8 waves) is the fastest shape per CU (a chunk step costs 3.6 us there against 2.7-3.0 us for
