@@ -32,7 +32,9 @@ static inline int64_t w_image_bytes(int64_t Fin, int64_t Fout, int64_t K) {
     int64_t m = fwd > bwd ? fwd : bwd;
     if (zmx > m) m = zmx;
     const int64_t copy = Fin * K * Fout * 4;
-    return (m > copy ? m : copy) + 256;
+    // + the scratch of the streaming GEMM's balanced decomposition (dsw_gemm_x3s.hip: 4 KiB of flags, one partial 256 x 128
+    // fp32 tile per workgroup, 256 workgroups)
+    return (m > copy ? m : copy) + 512 + 4096 + 256 * (256 * 128 * 4);
 }
 int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* bias, void* Y, int64_t N,
                        int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int relu = 0,

@@ -78,6 +78,10 @@ struct TsGemmParams {
     // >= 0: output plane fold_q is produced with B(fold_q) - B(fold_q + 2) - the top of the adjoint / Clenshaw recurrence
     // subtracts the raw plane K-1 from plane K-3, and both come out of this GEMM (dsw_api.hip, dsw_fold_w_launch).  -1: none.
     int fold_q;
+    // Balanced decomposition of the streaming-W kernel (dsw_gemm_x3s.hip, set by its launcher only): one partial tile per
+    // workgroup + one ready flag per workgroup, carved out of pre_ws behind the image.  null: whole tiles per workgroup.
+    float* sk_part;
+    unsigned* sk_flags;
 };
 
 // epilogue activation; NaN stays NaN like torch.relu (fmaxf would turn it into 0)
@@ -129,6 +133,10 @@ struct TileChunkIter {
     long it;        // linear iteration index
     int p, kc, c;   // A plane, chunk inside the plane, c = p * chunks + kc
     __device__ __forceinline__ void init(const long first_row) { row0 = first_row; it = 0; p = 0; kc = 0; c = 0; }
+    // start in the middle of a tile: chunk c0 of the tile's `total` chunks
+    __device__ __forceinline__ void init_at(const long first_row, const int c0, const int chunks) {
+        row0 = first_row; it = 0; c = c0; p = c0 / chunks; kc = c0 - p * chunks;
+    }
     __device__ __forceinline__ void next(const int chunks, const int total, const long row_step) {
         ++it; ++c; ++kc;
         if (kc == chunks) { kc = 0; ++p; }

@@ -16,6 +16,7 @@
 // the tile is as large as registers allow: 8 waves x (32 x 128) -> 48 MFMAs per wave and chunk against 16 staged
 // W elements per lane.
 #include "dsw_gemm_common.h"
+#include <cstdio>
 
 using namespace dsw_gemm;
 
@@ -23,6 +24,7 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
+constexpr int SC1 = 16;   // cache-policy operand of the raw buffer builtins on gfx940+: bit 4 = sc1, device scope
 constexpr int KSB = 40;   // bf16 elements per B row in LDS: 32 k + 8 pad (80 B)
 
 static __device__ __forceinline__ bf16x8_t pack_trunc8(const float (&f)[8]) {
@@ -42,7 +44,10 @@ static __device__ __forceinline__ float trunc_bf16(float f) {
 // exactly what a thread of the GEMM writes to LDS for that slot.  1.5x the fp32 bytes of W, built once per call
 // (a few microseconds), instead of ~5.5 vector instructions per element in every workgroup and chunk.
 template <int BNT>
-__global__ void x3s_presplit_kernel(const TsGemmParams P, unsigned* __restrict__ img, const int chunks, const int col_tiles) {
+__global__ void x3s_presplit_kernel(const TsGemmParams P, unsigned* __restrict__ img, const int chunks, const int col_tiles,
+                                    unsigned* __restrict__ flags, const int n_flags) {
+    if (blockIdx.x == 0)   // ready flags of the balanced decomposition: cleared here, in the launch that precedes the GEMM
+        for (int i = threadIdx.x; i < n_flags; i += blockDim.x) flags[i] = 0u;
     const long n_slots = (long)P.n_planes_a * chunks * col_tiles * (16 * BNT);
     const int n_total = P.n_planes_c * P.n_per_plane;
     const float* B = static_cast<const float*>(P.Bsrc);
@@ -141,7 +146,26 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
     const float* Bsrc = static_cast<const float*>(P.Bsrc);
     constexpr int RBW = PRE ? 3 : 2;                     // dwords per slot in the W ring: three packed terms, or two fp32 values
     float rb0[NPAIR][RBW], rb1[NPAIR][RBW], rb2[NPAIR][RBW];   // W ring: same depth / slot numbering as the A ring
-    int bp = 0, bkc = 0;   // (plane, chunk) of the NEXT W chunk to fetch: cycles through the reduction, no clamp
+    // Work of this workgroup.  Whole tiles: row tiles blockIdx.x, + gridDim.x, ...  Balanced (P.sk_part): the column tile's
+    // row_tiles * total chunk steps are cut into gridDim.x equal contiguous ranges, wherever the cuts fall; a tile cut by a
+    // range boundary is finished by the workgroup that holds its FIRST chunk (it reaches it at the END of its own range, when
+    // the others - who met their piece first, or had nothing else - have parked theirs), see the segment logic in stage().
+    const bool sk = P.sk_part != nullptr;
+    const long S_sk = row_tiles * total;
+    long n_iter, row_first, row_step;
+    int c_first = 0;
+    if (sk) {
+        const long s0 = (long)blockIdx.x * S_sk / gridDim.x, s1 = (long)(blockIdx.x + 1) * S_sk / gridDim.x;
+        const long t0 = s0 / total;
+        n_iter = s1 - s0; c_first = (int)(s0 - t0 * total); row_first = t0 * BMT; row_step = BMT;
+    } else {
+        n_iter = (row_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x * total;
+        row_first = (long)blockIdx.x * BMT; row_step = (long)gridDim.x * BMT;
+    }
+    TileChunkIter cur, pre;   // the chunk being multiplied / the chunk being prefetched (PF ahead, clamped)
+    cur.init_at(row_first, c_first, chunks);
+    pre.init_at(row_first, c_first, chunks);
+    int bp = cur.p, bkc = cur.kc;   // (plane, chunk) of the NEXT W chunk to fetch: cycles through the reduction, no clamp
     typedef float f32x3_t __attribute__((ext_vector_type(3)));
     const float* Bimg = static_cast<const float*>(P.pre_ws);
     auto fetch_b = [&](float (&rb)[NPAIR][RBW]) __attribute__((always_inline)) {
@@ -199,19 +223,13 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
     const int ar = wave * 32 + (lane >> 3);
     const int ac4 = (lane & 7) * 4;
     f32x4 ra0[4], ra1[4], ra2[4];
-    const long my_tiles = (row_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
-    const long n_iter = my_tiles * total;
-    const long row_step = (long)gridDim.x * BMT;
-    TileChunkIter cur, pre;   // the chunk being multiplied / the chunk being prefetched (PF ahead, clamped)
-    cur.init((long)blockIdx.x * BMT);
-    pre.init((long)blockIdx.x * BMT);
     // Addresses of the A loads = a UNIFORM pointer (plane, chunk: scalar registers, advanced by the scalar unit) + this lane's
     // 32-bit byte offset inside the plane (row * lda + column, fixed for a row tile).  The first form recomputed
     // (row * lda + plane * stride + k) in 64-bit vector arithmetic for every load: an in-kernel cycle timeline
     // (tools/x3s_timeline.py) showed 750 of the 5 800 cycles of a chunk step in issuing its 12 loads.
     unsigned arow_off[4];
     auto fetch = [&](f32x4 (&dra)[4]) __attribute__((always_inline)) {   // A rows of chunk `pre`, then advance it
-        if (pre.c == 0) {                                               // uniform: first chunk of a row tile
+        if (pre.c == 0 || pre.it == 0) {                                // uniform: first chunk of a row tile / of the range
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 long r = pre.row0 + ar + 8 * i;
@@ -242,6 +260,7 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
     store_a(As, ra0);
     fetch_b(rb0); fetch(ra0);
     const long n_pad = (n_iter + PF - 1) / PF * PF;
+    bool seg_first = c_first == 0;   // the current segment holds chunk 0 of its tile
 
     auto stage = [&](auto U, const long it) __attribute__((always_inline)) {
         constexpr int v = (decltype(U)::value + 1) % 3;     // ring slot of chunk it+1
@@ -294,7 +313,63 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
         store_a(As + (size_t)(par ^ 1) * BMT * LDA, slot);
         fetch_b(bslot);
         fetch(slot);
-        if (cur.c == total - 1 && it < n_iter) {
+        const bool tile_end = cur.c == total - 1;
+        bool finish = tile_end && it < n_iter;
+        if (sk && it < n_iter && (tile_end || it == n_iter - 1) && !(seg_first && tile_end)) {
+            // a segment that is not a whole tile ends here
+            const long slot0 = (long)blockIdx.y * gridDim.x;
+            if (!seg_first) {
+                // A piece WITHOUT the tile's first chunk (always the first segment of a range): park it in this workgroup's
+                // slot and raise its flag.  Device-scope (sc1, write-through) stores - the reader sits on another XCD with its
+                // own L2.  Not a release FENCE: that writes back the whole L2, once per wave (measured: 65 -> 142 us on a
+                // 6 144-row layer); not atomic stores / loads either: the compiler waits for each before it issues the next.
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    P.sk_part + (slot0 + blockIdx.x) * (long)(BMT * BNT), 0, BMT * BNT * 4, 0x00020000);
+#ifdef DSW_ABLATION
+                if (!(P.dbg & 4))      // the flag is still raised
+#endif
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[nt][i]), rs, tid * 4, (nt * 16 + i) * NTH * 4, SC1);
+                        acc[nt][i] = 0.f;
+                    }
+                __syncthreads();   // every wave's stores have completed (s_waitcnt vmcnt(0) precedes the barrier)
+                if (tid == 0) __hip_atomic_store(P.sk_flags + slot0 + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                finish = false;
+            } else {
+                // The head of a tile at the end of the range: add the pieces of the later ranges in workgroup order, then the
+                // epilogue.  (Done after the loop, with all loads of a piece in flight, the kernel ran out of scalar
+                // registers and got 25 % slower.)
+                const long tile_stop = (cur.row0 / BMT + 1) * total;
+                for (long b = blockIdx.x + 1; b < gridDim.x && b * S_sk / gridDim.x < tile_stop; ++b) {
+#ifdef DSW_ABLATION
+                    if (P.dbg & 8) break;
+#endif
+                    if (tid == 0)
+                        while (__hip_atomic_load(P.sk_flags + slot0 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+                            __builtin_amdgcn_s_sleep(4);
+                    __syncthreads();
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                        P.sk_part + (slot0 + b) * (long)(BMT * BNT), 0, BMT * BNT * 4, 0x00020000);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {   // 16 loads in flight, not 64: the registers are full
+                        unsigned t[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)    // device-scope loads: never a stale line of this XCD's L2
+                            t[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, tid * 4, (nt * 16 + i) * NTH * 4, SC1);
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[nt][i] += __uint_as_float(t[i]);
+                        asm volatile("" ::: "memory");
+                    }
+                }
+                finish = true;
+            }
+        }
+        if (it < n_iter && (tile_end || it == n_iter - 1)) seg_first = true;   // the next segment starts a tile
+        if (finish) {
             const long rbase = cur.row0 + wave * 32 + 4 * half;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -325,8 +400,16 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
     }
 }
 
+// bytes of balanced-decomposition scratch behind the W image: flags (one per workgroup, 4 KiB) + one partial tile per workgroup
+constexpr long SK_FLAG_BYTES = 4096;
+constexpr long SK_MAX_WG = 1024;
+
 template <int NT, int NWV, bool KFAST, bool RES = false, bool PRE = false>
-int launch_x3s(const TsGemmParams& P, int col_tiles, hipStream_t stream) {
+int launch_x3s(const TsGemmParams& P0, int col_tiles, hipStream_t stream, char* sk_ws, long sk_bytes, bool flags_clear) {
+    TsGemmParams P = P0;
+#ifdef DSW_ABLATION   // -DDSW_ABLATION -DDSW_DIAG + DSW_DBG: 4 = pieces are not parked, 8 = not collected (wrong results by design)
+    { static const char* d = dsw_diag_env("DSW_DBG"); P.dbg = d ? atoi(d) : 0; }
+#endif
     constexpr int BMT = 32 * NWV;
     const size_t lds = (size_t)2 * BMT * LDA * 4 + (size_t)2 * 3 * (32 * NT) * KSB * 2;
     const long row_tiles = (P.M + BMT - 1) / BMT;
@@ -338,8 +421,40 @@ int launch_x3s(const TsGemmParams& P, int col_tiles, hipStream_t stream) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64 * NWV, lds) != hipSuccess || per_cu < 1) per_cu = 1;
     long gx = 256L * per_cu / col_tiles;
     if (gx < 1) gx = 1;
-    if (gx > row_tiles) gx = row_tiles;
     if (col_tiles > 1 && gx >= 8) gx &= ~7L;   // column tiles of one row tile on one XCD (A re-reads hit its L2)
+    // Whole tiles per workgroup leave CUs idle whenever the row tiles do not divide by the workgroups (384 tiles on 256 CUs:
+    // two rounds for 1.5 rounds of work; 96 x 2 tiles: a quarter of the chip idle).  With scratch for one partial tile per
+    // workgroup the chunk steps are divided evenly instead (kernel comment); at least SK_MIN_STEPS steps per workgroup keep
+    // the pipeline prologue and the parked pieces small against the work.  Measured (tools/bench_gemm.py --ws, same box, whole
+    // tiles -> balanced): 98 304 x 768 -> 128 199 -> 180 us, 24 576 x 1 536 -> 256 163 -> 150, 6 144 x 1 536 -> 256 62 -> 48;
+    // parking + collecting the pieces costs 4-7 us of that (ablation), and the chip gives part of the rest back as clock (all
+    // CUs busy: DVFS) - which is why 24 576 x 576 -> 256 (18 steps per tile, 4.5 saved) LOSES 4 us: short tiles stay whole.
+    static const char* skenv = dsw_diag_env("DSW_X3S_BALANCED");   // "0": whole tiles only (diagnostics / A-B)
+    constexpr long SK_MIN_STEPS = 6;
+    const long steps = row_tiles * (long)(P.n_planes_a * (P.kd_per_plane / BK));
+    long gsk = gx;
+    if (gsk > steps / SK_MIN_STEPS) gsk = steps / SK_MIN_STEPS;
+    if (col_tiles > 1 && gsk >= 8) gsk &= ~7L;
+    const long tile_bytes = (long)BMT * (32 * NT) * 4;
+    const long steps_tile = steps / row_tiles;
+    const long whole = (row_tiles + (gx < row_tiles ? gx : row_tiles) - 1) / (gx < row_tiles ? gx : row_tiles) * steps_tile;
+    const bool pays = steps_tile >= 24 && gsk >= 2 && (whole - steps / gsk) * 5 >= whole;   // saves >= 20 % of the steps
+    const bool balanced = !(skenv && skenv[0] == '0') && sk_ws != nullptr && pays && row_tiles % gsk != 0 &&
+                          gsk * col_tiles <= SK_MAX_WG && sk_bytes >= SK_FLAG_BYTES + gsk * col_tiles * tile_bytes;
+#ifdef DSW_DIAG
+    { static const char* tr = dsw_diag_env("DSW_X3S_TRACE");
+      if (tr) fprintf(stderr, "x3s M=%ld planes=%d kd=%d n=%d nt=%d nwv=%d col_tiles=%d row_tiles=%ld gx=%ld gsk=%ld steps_tile=%ld whole=%ld bal=%d kfast=%d pre=%d res=%d\n",
+                      (long)P.M, P.n_planes_a, P.kd_per_plane, P.n_planes_c * P.n_per_plane, NT, NWV, col_tiles, row_tiles, gx, gsk, steps_tile, whole, (int)balanced, (int)KFAST, (int)PRE, (int)RES); }
+#endif
+    if (balanced) {
+        gx = gsk;
+        P.sk_flags = reinterpret_cast<unsigned*>(sk_ws);
+        P.sk_part = reinterpret_cast<float*>(sk_ws + SK_FLAG_BYTES);
+        if (!flags_clear && hipMemsetAsync(sk_ws, 0, (size_t)(gsk * col_tiles * 4), stream) != hipSuccess) return DSW_ERR_LAUNCH;
+    } else if (gx > row_tiles) {
+        gx = row_tiles;
+        if (col_tiles > 1 && gx >= 8) gx &= ~7L;
+    }
     dim3 grid((unsigned)gx, (unsigned)col_tiles);
     hipLaunchKernelGGL((ts_gemm_x3s_kernel<NT, NWV, KFAST, RES, PRE>), grid, dim3(64 * NWV), lds, stream, P);
     return dsw_check_launch();
@@ -381,19 +496,30 @@ int dsw_ts_gemm_x3s_try_launch(const TsGemmParams& P, hipStream_t stream, int* r
     const bool pre = !(preenv && preenv[0] == '0') && P.pre_ws != nullptr && P.pre_bytes >= img_bytes &&
                      (((uintptr_t)P.pre_ws) & 15u) == 0;
     if (!pre && P.fold_q >= 0) return 0;       // the caller folds the weights itself and comes back without fold_q
+    // scratch of the balanced decomposition: behind the image (whether or not this call builds one)
+    const long img_room = (img_bytes + 255) / 256 * 256;
+    char* sk_ws = nullptr;
+    long sk_bytes = 0;
+    if (P.pre_ws != nullptr && (((uintptr_t)P.pre_ws) & 15u) == 0 && P.pre_bytes > img_room + SK_FLAG_BYTES) {
+        sk_ws = static_cast<char*>(P.pre_ws) + img_room;
+        sk_bytes = P.pre_bytes - img_room;
+    }
+    unsigned* flags = reinterpret_cast<unsigned*>(sk_ws);
+    const int n_flags = sk_ws ? (int)SK_MAX_WG : 0;
+    const bool fc = pre && sk_ws != nullptr;   // the split launch clears the flags on its way
     if (pre) {
         const long n_slots = img_bytes / 12;
         const int blocks = (int)((n_slots + 255) / 256 < 2048 ? (n_slots + 255) / 256 : 2048);
-        if (nt == 4) hipLaunchKernelGGL((x3s_presplit_kernel<128>), dim3(blocks), dim3(256), 0, stream, P, static_cast<unsigned*>(P.pre_ws), chunks_, col_tiles);
-        else hipLaunchKernelGGL((x3s_presplit_kernel<64>), dim3(blocks), dim3(256), 0, stream, P, static_cast<unsigned*>(P.pre_ws), chunks_, col_tiles);
+        if (nt == 4) hipLaunchKernelGGL((x3s_presplit_kernel<128>), dim3(blocks), dim3(256), 0, stream, P, static_cast<unsigned*>(P.pre_ws), chunks_, col_tiles, flags, n_flags);
+        else hipLaunchKernelGGL((x3s_presplit_kernel<64>), dim3(blocks), dim3(256), 0, stream, P, static_cast<unsigned*>(P.pre_ws), chunks_, col_tiles, flags, n_flags);
         if ((*rc = dsw_check_launch()) != DSW_OK) return 1;
     }
 #define DSW_X3S(NT_, NWV_)                                                                                          \
-    (*rc = pre ? (res ? launch_x3s<NT_, NWV_, false, true, true>(P, col_tiles, stream)                              \
-                      : launch_x3s<NT_, NWV_, false, false, true>(P, col_tiles, stream))                            \
-         : res ? (kfast ? launch_x3s<NT_, NWV_, true, true>(P, col_tiles, stream)                                   \
-                        : launch_x3s<NT_, NWV_, false, true>(P, col_tiles, stream))                                 \
-               : (kfast ? launch_x3s<NT_, NWV_, true>(P, col_tiles, stream) : launch_x3s<NT_, NWV_, false>(P, col_tiles, stream)))
+    (*rc = pre ? (res ? launch_x3s<NT_, NWV_, false, true, true>(P, col_tiles, stream, sk_ws, sk_bytes, fc)                              \
+                      : launch_x3s<NT_, NWV_, false, false, true>(P, col_tiles, stream, sk_ws, sk_bytes, fc))                            \
+         : res ? (kfast ? launch_x3s<NT_, NWV_, true, true>(P, col_tiles, stream, sk_ws, sk_bytes, fc)                                   \
+                        : launch_x3s<NT_, NWV_, false, true>(P, col_tiles, stream, sk_ws, sk_bytes, fc))                                 \
+               : (kfast ? launch_x3s<NT_, NWV_, true>(P, col_tiles, stream, sk_ws, sk_bytes, fc) : launch_x3s<NT_, NWV_, false>(P, col_tiles, stream, sk_ws, sk_bytes, fc)))
 #define DSW_X3S_NWV(NT_)                                                                     \
     if (nwv == 4) DSW_X3S(NT_, 4); else DSW_X3S(NT_, 8);
     if (nt == 4) { DSW_X3S_NWV(4) } else { DSW_X3S_NWV(2) }

@@ -606,6 +606,57 @@ def test_dense_mix_vs_f64(N, Fin, Fout):
     assert orc.max_rel_err(b.grad, g64.reshape(-1, Fout).sum(0).numpy()) <= TOL_F64
 
 
+@pytest.mark.parametrize("N,Kd,Fout,epi", [(5000, 768, 128, "relu"), (98304, 768, 128, "res"), (24576, 576, 256, "none"),
+                                            (6144, 1536, 256, "res"), (4999, 384, 200, "none"), (1300, 1536, 512, "relu")])
+def test_streaming_gemm_balanced_decomposition(N, Kd, Fout, epi):
+    """Wide fp32 channel mix through dsw_cheb_fwd_ws WITH caller scratch: the streaming-W GEMM cuts its chunk steps into equal
+    ranges per workgroup (tiles split between workgroups, pieces parked in the scratch, summed in workgroup order).  Against an
+    fp64 matmul, bitwise repeatable, and equal (to rounding) to the same call without scratch (whole tiles per workgroup)."""
+    from dsw_amd import _native
+
+    lib = _native.load()
+    torch.manual_seed(11)
+    x = torch.randn(N, Kd, device=DEV)
+    w = torch.randn(Kd, 1, Fout, device=DEV) / Kd ** 0.5
+    b = torch.randn(Fout, device=DEV)
+    r = torch.randn(N, Fout, device=DEV) if epi == "res" else None
+    sc = torch.tensor([0.37], device=DEV) if epi == "res" else None
+    st = torch.cuda.current_stream().cuda_stream
+    nws = int(lib.dsw_cheb_fwd_workspace_bytes(1, N, Kd, Fout, 1, 0))
+    assert nws > 0
+
+    def run(ws):
+        y = torch.full((N, Fout), float("nan"), device=DEV)
+        rc = lib.dsw_cheb_fwd_ws(None, None, None, N, 0, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), Fout, None, 1, Kd, Fout,
+                                 1, 0, st, None, 1 if epi == "relu" else 0, None if sc is None else sc.data_ptr(),
+                                 None if r is None else r.data_ptr(), 0 if r is None else Fout,
+                                 None if ws is None else ws.data_ptr(), 0 if ws is None else nws)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return y
+
+    ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+    ws.fill_(0xA5)                       # stale flags / pieces must not matter
+    y1 = run(ws)
+    x_keep = x.clone()
+    x.mul_(-1.7)                         # other pieces in the scratch (and in the L2s) between the two runs compared bitwise
+    run(ws)
+    x.copy_(x_keep)
+    y2 = run(ws)
+    ws.fill_(0x5A)
+    y3 = run(ws)
+    y0 = run(None)
+    assert torch.equal(y1, y3)
+    ref = x.double().cpu() @ w[:, 0].double().cpu() + b.double().cpu()
+    if epi == "res":
+        ref = 0.37 * ref + r.double().cpu()
+    if epi == "relu":
+        ref = ref.clamp_min(0)
+    assert torch.equal(y1, y2)
+    assert orc.max_rel_err(y1, ref.numpy()) <= TOL_F64
+    assert orc.max_rel_err(y0, ref.numpy()) <= TOL_F64
+
+
 def test_config_driven_training_driver(tmp_path):
     """scripts_training/train_synthetic_state.py: JSON config -> model -> AR steps with Adam; the loss of a
     fixed synthetic batch must go down and stay finite (whole-path smoke through fwd, bwd, optimizer)."""

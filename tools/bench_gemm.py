@@ -20,7 +20,8 @@ def timeit(fn, n=30, w=5):
 
 def main():
     lib = _native.load()
-    shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [
+    use_ws = "--ws" in sys.argv   # through dsw_cheb_fwd_ws (K = 1 layer of width K * Fin) with the caller scratch a layer call passes
+    shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:] if not a.startswith("-")] or [
         (98304, 256, 128, 3), (98304, 128, 256, 3), (98304, 64, 128, 3), (24576, 512, 256, 3), (24576, 192, 256, 3),
         (6144, 512, 256, 3), (6144, 256, 512, 3), (786432, 32, 64, 3)]
     st = torch.cuda.current_stream().cuda_stream
@@ -31,6 +32,13 @@ def main():
         b = torch.randn(Fout, device="cuda")
         y = torch.empty(N, Fout, device="cuda")
         f = lambda: lib.dsw_cheb_mix_fwd(x.data_ptr(), T.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, Fin, Fout, K, 0, st)
+        if use_ws:
+            xw = torch.cat([x] + [T[k] for k in range(K - 1)], 1).contiguous()
+            ww = w.permute(1, 0, 2).reshape(K * Fin, 1, Fout).contiguous()
+            nws = int(lib.dsw_cheb_fwd_workspace_bytes(1, N, K * Fin, Fout, 1, 0))
+            ws = torch.empty(nws, dtype=torch.uint8, device="cuda")
+            f = lambda: lib.dsw_cheb_fwd_ws(None, None, None, N, 0, xw.data_ptr(), ww.data_ptr(), b.data_ptr(), y.data_ptr(), Fout, None,
+                                            1, K * Fin, Fout, 1, 0, st, None, 0, None, None, 0, ws.data_ptr(), nws)
         assert f() == 0
         us = timeit(f)
         ref = (torch.cat([x] + [T[k] for k in range(K - 1)], 1).double() @ w.permute(1, 0, 2).reshape(K * Fin, Fout).double() + b.double())
