@@ -208,7 +208,11 @@ int dsw_cheb_fwd_res(const int32_t* rowptr, const int32_t* colind, const float* 
  * the weights.  The channel-mix GEMM of WIDE fp32 layers streams W chunk by chunk next to the activations and evaluates
  * the fp32 product on the bf16 matrix pipe from three-term splits of both operands; with the scratch W is split ONCE per call
  * (1.5x its fp32 bytes) instead of once per workgroup and chunk, and mix-first layers on dense stencils fold plane K-1 into
- * the weights of plane K-3 there (one epilogue operand less in the recurrence).  Same results as without it. */
+ * the weights of plane K-3 there (one epilogue operand less in the recurrence).  The scratch also holds one partial output
+ * tile per workgroup (+ 4 KiB of flags, cleared by the call): with it the streaming GEMM may divide its reduction steps
+ * evenly over the workgroups, tiles cut between two of them and summed in a fixed order (dsw_gemm_x3s.hip).  Results with
+ * and without scratch agree to fp32 rounding (the summation order of a cut tile differs), each bit-identical from run to run.
+ * Calls that share a scratch buffer must be stream-ordered. */
 int64_t dsw_cheb_fwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t Fout, int64_t K, int dtype);
 int dsw_cheb_fwd_ws(const int32_t* rowptr, const int32_t* colind, const float* vals,
                     int64_t V, int64_t nnz, const void* X, const void* W, const void* bias,
