@@ -22,8 +22,12 @@ def main():
     lib = _native.load()
     use_ws = "--ws" in sys.argv   # through dsw_cheb_fwd_ws (K = 1 layer of width K * Fin) with the caller scratch a layer call passes
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:] if not a.startswith("-")] or [
-        (98304, 256, 128, 3), (98304, 128, 256, 3), (98304, 64, 128, 3), (24576, 512, 256, 3), (24576, 192, 256, 3),
-        (6144, 512, 256, 3), (6144, 256, 512, 3), (786432, 32, 64, 3)]
+        # the streaming-GEMM launches of one U-Net step (nside 32, B 8; DSW_X3S_TRACE=1 in a diagnostics build lists them):
+        # basis-first forwards as (N, Fin, Fout, 3), mix-first plane GEMMs as (N, Fin, 3 * Fout, 1) ...
+        (98304, 64, 128, 3), (98304, 256, 384, 1), (24576, 128, 192, 3), (24576, 192, 256, 3), (24576, 512, 768, 1),
+        (24576, 256, 384, 1), (6144, 256, 512, 3), (6144, 512, 768, 1),
+        # ... and long reductions (>= 24 chunk steps per tile: what the balanced decomposition is for, with --ws)
+        (98304, 256, 128, 3), (24576, 512, 256, 3), (6144, 512, 256, 3)]
     st = torch.cuda.current_stream().cuda_stream
     for N, Fin, Fout, K in shapes:
         x = torch.randn(N, Fin, device="cuda")
