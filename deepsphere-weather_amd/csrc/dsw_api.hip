@@ -26,9 +26,9 @@ struct DswEpiExtra {   // optional epilogue operands / scratch of the channel-mi
 // bytes of that scratch for a layer: the pre-split image of the streaming GEMM (1.5x the fp32 weights, columns padded to the
 // 128-column tile) or a copy of the weights, whichever is larger
 static inline int64_t w_image_bytes(int64_t Fin, int64_t Fout, int64_t K) {
-    const int64_t fwd = (K * Fin + 31) / 32 * 32 * ((Fout + 127) / 128 * 128) * 6;       // reduction K Fin, columns Fout
-    const int64_t bwd = (Fout + 31) / 32 * 32 * ((K * Fin + 127) / 128 * 128) * 6;       // reduction Fout, columns K Fin
-    const int64_t zmx = (Fin + 31) / 32 * 32 * ((K * Fout + 127) / 128 * 128) * 6;       // mix-first planes: columns K Fout
+    const int64_t fwd = (K * Fin + 31) / 32 * 32 * ((Fout + 127) / 128 * 128) * 15 / 2;      // reduction K Fin, columns Fout
+    const int64_t bwd = (Fout + 31) / 32 * 32 * ((K * Fin + 127) / 128 * 128) * 15 / 2;      // reduction Fout, columns K Fin
+    const int64_t zmx = (Fin + 31) / 32 * 32 * ((K * Fout + 127) / 128 * 128) * 15 / 2;      // mix-first planes: columns K Fout
     int64_t m = fwd > bwd ? fwd : bwd;
     if (zmx > m) m = zmx;
     const int64_t copy = Fin * K * Fout * 4;

@@ -38,11 +38,18 @@ static __device__ __forceinline__ bf16x8_t pack_trunc8(const float (&f)[8]) {
 static __device__ __forceinline__ float trunc_bf16(float f) {
     return __uint_as_float(__float_as_uint(f) & 0xffff0000u);
 }
+// one LDS-DMA instruction: 16 bytes per lane from gsrc (per lane) to lds_dst (wave-uniform) + lane * 16.  M0 carries the LDS
+// destination; it is compiler-reserved: saved and restored in ONE statement (as in dsw_spmm1s.hip)
+static __device__ __forceinline__ void glds16(const char* gsrc, const unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 
 // Pre-split image of the small operand (TsGemmParams::pre_ws): for chunk c = a-plane * chunks + chunk, column tile t and
 // slot e = col * 16 + kp of the tile, three dwords {hi, mid, lo}, each the bf16 pair (k = 2 kp, 2 kp + 1) of one term -
-// exactly what a thread of the GEMM writes to LDS for that slot.  1.5x the fp32 bytes of W, built once per call
-// (a few microseconds), instead of ~5.5 vector instructions per element in every workgroup and chunk.
+// exactly what a thread of the GEMM writes to LDS for that slot.  1.9x the fp32 bytes of W (with the row pad of the LDS
+// image), built once per call (a few microseconds), instead of ~5.5 vector instructions per element in every workgroup and chunk.
 template <int BNT>
 __global__ void x3s_presplit_kernel(const TsGemmParams P, unsigned* __restrict__ img, const int chunks, const int col_tiles,
                                     unsigned* __restrict__ flags, const int n_flags) {
@@ -70,16 +77,19 @@ __global__ void x3s_presplit_kernel(const TsGemmParams P, unsigned* __restrict__
         const float a1 = a - ah, b1 = b - bh;
         const float am = trunc_bf16(a1), bm = trunc_bf16(b1);
         const float al = a1 - am, bl = b1 - bm;
-        img[3 * s] = __builtin_amdgcn_perm(__float_as_uint(bh), __float_as_uint(ah), 0x07060302u);
-        img[3 * s + 1] = __builtin_amdgcn_perm(__float_as_uint(bm), __float_as_uint(am), 0x07060302u);
-        img[3 * s + 2] = __builtin_amdgcn_perm(__float_as_uint(bl), __float_as_uint(al), 0x07060302u);
+        // the image of (chunk, column tile) IS the LDS image [3 planes][BNT cols][KSB] (pad included): the GEMM copies it with
+        // LDS-DMA, 1 KiB per wave instruction, no registers and no ds_write in between
+        unsigned* dst = img + (s / (16 * BNT)) * (long)(3 * BNT * KSB / 2) + col * (KSB / 2) + kp;
+        dst[0] = __builtin_amdgcn_perm(__float_as_uint(bh), __float_as_uint(ah), 0x07060302u);
+        dst[BNT * KSB / 2] = __builtin_amdgcn_perm(__float_as_uint(bm), __float_as_uint(am), 0x07060302u);
+        dst[BNT * KSB] = __builtin_amdgcn_perm(__float_as_uint(bl), __float_as_uint(al), 0x07060302u);
     }
 }
 
 // KFAST: the B operand is contiguous along the reduction index (dgrad: W^T), else along the columns (forward).
 // PRE: the W chunk comes pre-split from TsGemmParams::pre_ws (x3s_presplit_kernel) - three ready-made dwords per slot.
 template <int NT, int NWV, bool KFAST, bool RES = false, bool PRE = false>
-__global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParams P) {
+__global__ __launch_bounds__(64 * NWV, (PRE || NWV == 8) ? 2 : 1) void ts_gemm_x3s_kernel(const TsGemmParams P) {
     constexpr int BMT = 32 * NWV;
     constexpr int NTH = 64 * NWV;
     constexpr int BNT = 32 * NT;
@@ -89,7 +99,11 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
     constexpr int BPLANE = BNT * KSB;                  // one bf16 plane of one B buffer
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                                                               // [2][BMT][LDA]
-    unsigned short* Bt = reinterpret_cast<unsigned short*>(smem + 2 * BMT * LDA);   // [2][3][BNT][KSB]
+    // A rows are wave-private (a wave stages and reads only its own 32 rows, LDS operations of a wave complete in order): the
+    // 4-wave shape keeps ONE A buffer - chunk it+1 is stored behind the fragment reads of chunk it - and with 78 KB of LDS
+    // two of its workgroups share a CU, each with its own barrier: one's staging runs under the other's MFMAs.
+    constexpr int NABUF = NWV == 4 ? 1 : 2;
+    unsigned short* Bt = reinterpret_cast<unsigned short*>(smem + NABUF * BMT * LDA);   // [2][3][BNT][KSB]
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -144,8 +158,8 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
         }
     }
     const float* Bsrc = static_cast<const float*>(P.Bsrc);
-    constexpr int RBW = PRE ? 3 : 2;                     // dwords per slot in the W ring: three packed terms, or two fp32 values
-    float rb0[NPAIR][RBW], rb1[NPAIR][RBW], rb2[NPAIR][RBW];   // W ring: same depth / slot numbering as the A ring
+    constexpr int RBW = 2;                               // dwords per slot in the W ring: two fp32 values
+    float rb0[NPAIR][RBW], rb1[NPAIR][RBW], rb2[NPAIR][RBW];   // W ring (not PRE): same depth / slot numbering as the A ring
     // Work of this workgroup.  Whole tiles: row tiles blockIdx.x, + gridDim.x, ...  Balanced (P.sk_part): the column tile's
     // row_tiles * total chunk steps are cut into gridDim.x equal contiguous ranges, wherever the cuts fall; a tile cut by a
     // range boundary is finished by the workgroup that holds its FIRST chunk (it reaches it at the END of its own range, when
@@ -166,19 +180,29 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
     cur.init_at(row_first, c_first, chunks);
     pre.init_at(row_first, c_first, chunks);
     int bp = cur.p, bkc = cur.kc;   // (plane, chunk) of the NEXT W chunk to fetch: cycles through the reduction, no clamp
-    typedef float f32x3_t __attribute__((ext_vector_type(3)));
-    const float* Bimg = static_cast<const float*>(P.pre_ws);
+    // PRE: the pre-split image of (chunk, this column tile) is the LDS image itself - copied by LDS-DMA, 1 KiB pieces dealt
+    // round-robin to the waves; no ring registers, no ds_write.  The compiler does not see these operations: its own vmcnt
+    // waits (A ring) become stricter than needed, never laxer (the counter retires in order); the wait for the pieces is
+    // hand-counted in stage().
+    constexpr int IMG_BYTES = 3 * BPLANE * 2;
+    constexpr int NPIECE = IMG_BYTES / 1024;
+    static_assert(IMG_BYTES % 1024 == 0, "whole 1 KiB pieces");
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned bt_lds = (unsigned)reinterpret_cast<uintptr_t>(Bt);
+    auto dma_b = [&](const int buf) __attribute__((always_inline)) {
+        const char* src = static_cast<const char*>(P.pre_ws) + (((long)bp * chunks + bkc) * gridDim.y + blockIdx.y) * (long)IMG_BYTES + lane * 16;
+        const unsigned dst = bt_lds + (unsigned)buf * IMG_BYTES;
+#pragma unroll
+        for (int i = 0; i < (NPIECE + NWV - 1) / NWV; ++i) {
+            const int j = wave_u + NWV * i;
+            if (j < NPIECE) glds16(src + j * 1024, dst + (unsigned)j * 1024u);
+        }
+        if (++bkc == chunks) { bkc = 0; if (++bp == P.n_planes_a) bp = 0; }
+    };
     auto fetch_b = [&](float (&rb)[NPAIR][RBW]) __attribute__((always_inline)) {
         if constexpr (PRE) {
-            // image of (chunk, this column tile): 16 * BNT slots of 12 bytes, slot e = tid + NTH * i
-            const char* origin = reinterpret_cast<const char*>(Bimg + (((long)bp * chunks + bkc) * gridDim.y + blockIdx.y) * (16L * BNT) * 3);
-#pragma unroll
-            for (int i = 0; i < NPAIR; ++i) {
-                int e = tid + NTH * i;
-                if (BTAIL && e >= 16 * BNT) e = 16 * BNT - 1;
-                const f32x3_t v = *reinterpret_cast<const f32x3_t*>(origin + 12u * (unsigned)e);
-                rb[i][0] = v[0]; rb[i][1] = v[1]; rb[i][2] = v[2];
-            }
+            (void)rb;
+            return;
         } else {
             // uniform chunk origin (and origin + one reduction step) + the slot's 32-bit byte offset
             const char* o0 = reinterpret_cast<const char*>(Bsrc + (long)bp * P.b_sp + (long)(bkc * BK) * P.b_skd);
@@ -189,21 +213,11 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
                 rb[i][0] = *reinterpret_cast<const float*>(o0 + g);   // unconditional (clamped) loads: nothing may consume the value
                 rb[i][1] = *reinterpret_cast<const float*>(o1 + g);   // here, or the compiler parks a vmcnt(0) right behind them
             }
+            if (++bkc == chunks) { bkc = 0; if (++bp == P.n_planes_a) bp = 0; }
         }
-        if (++bkc == chunks) { bkc = 0; if (++bp == P.n_planes_a) bp = 0; }
     };
     auto store_b = [&](unsigned short* buf, const float (&rb)[NPAIR][RBW]) __attribute__((always_inline)) {
-        if constexpr (PRE) {
-#pragma unroll
-            for (int i = 0; i < NPAIR; ++i) {
-                if (BTAIL && bslot_lds[i] < 0) continue;
-                uint32_t* dst = reinterpret_cast<uint32_t*>(buf + bslot_lds[i]);
-                dst[0] = __float_as_uint(rb[i][0]);
-                dst[BPLANE / 2] = __float_as_uint(rb[i][1]);
-                dst[BPLANE] = __float_as_uint(rb[i][2]);
-            }
-            return;
-        }
+        if constexpr (PRE) return;
 #pragma unroll
         for (int i = 0; i < NPAIR; ++i) {
             const float a = bslot_g[i] < 0 ? 0.f : rb[i][0], b = bslot_g[i] < 0 ? 0.f : rb[i][1];
@@ -253,12 +267,19 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&abuf[(ar + 8 * i) * LDA + ac4]) = slot[i];
     };
-    fetch_b(rb0); fetch(ra0);
-    fetch_b(rb1); fetch(ra1);
-    fetch_b(rb2); fetch(ra2);
-    store_b(Bt, rb0);
-    store_a(As, ra0);
-    fetch_b(rb0); fetch(ra0);
+    if constexpr (PRE) {
+        dma_b(0);                      // chunk 0 -> pair 0; chunk it+1 follows at the top of stage it
+        fetch(ra0); fetch(ra1); fetch(ra2);
+        store_a(As, ra0);
+        fetch(ra0);
+    } else {
+        fetch_b(rb0); fetch(ra0);
+        fetch_b(rb1); fetch(ra1);
+        fetch_b(rb2); fetch(ra2);
+        store_b(Bt, rb0);
+        store_a(As, ra0);
+        fetch_b(rb0); fetch(ra0);
+    }
     const long n_pad = (n_iter + PF - 1) / PF * PF;
     bool seg_first = c_first == 0;   // the current segment holds chunk 0 of its tile
 
@@ -275,9 +296,13 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
             else return &rb2;
         }();
         const int par = (int)(it & 1);
-        const float* abuf = As + (size_t)par * BMT * LDA;
+        const float* abuf = As + (size_t)(NABUF == 2 ? par : 0) * BMT * LDA;
         const unsigned short* bbuf = Bt + (size_t)par * 3 * BPLANE;
+        // PRE: this wave's pieces of chunk `it` have landed - younger than them, still in flight: the 4 A loads issued behind
+        // them (more at the end of a tile, where the count only errs on the safe side)
+        if constexpr (PRE) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __syncthreads();   // pair `par` complete; every wave is done reading the other pair (stage it-1)
+        if constexpr (PRE) dma_b(par ^ 1);     // chunk it+1 -> the other pair, under the MFMAs of this one
         const float* arow = &abuf[(wave * 32 + l31) * LDA + 8 * half];
         const unsigned short* brow = bbuf + (size_t)l31 * KSB + 8 * half;
 #pragma unroll
@@ -310,7 +335,7 @@ __global__ __launch_bounds__(64 * NWV) void ts_gemm_x3s_kernel(const TsGemmParam
         }
         // chunk it+1 -> the other pair, then refill its ring slot with chunk it+4
         store_b(Bt + (size_t)(par ^ 1) * 3 * BPLANE, bslot);
-        store_a(As + (size_t)(par ^ 1) * BMT * LDA, slot);
+        store_a(As + (size_t)(NABUF == 2 ? (par ^ 1) : 0) * BMT * LDA, slot);
         fetch_b(bslot);
         fetch(slot);
         const bool tile_end = cur.c == total - 1;
@@ -411,7 +436,7 @@ int launch_x3s(const TsGemmParams& P0, int col_tiles, hipStream_t stream, char* 
     { static const char* d = dsw_diag_env("DSW_DBG"); P.dbg = d ? atoi(d) : 0; }
 #endif
     constexpr int BMT = 32 * NWV;
-    const size_t lds = (size_t)2 * BMT * LDA * 4 + (size_t)2 * 3 * (32 * NT) * KSB * 2;
+    const size_t lds = (size_t)(NWV == 4 ? 1 : 2) * BMT * LDA * 4 + (size_t)2 * 3 * (32 * NT) * KSB * 2;
     const long row_tiles = (P.M + BMT - 1) / BMT;
     const void* kfn = (const void*)ts_gemm_x3s_kernel<NT, NWV, KFAST, RES, PRE>;
     if (lds > 64 * 1024 &&
@@ -492,7 +517,7 @@ int dsw_ts_gemm_x3s_try_launch(const TsGemmParams& P, hipStream_t stream, int* r
     // W split once per call into the caller's scratch (with the fold of output plane fold_q, if any) when there is room
     static const char* preenv = dsw_diag_env("DSW_X3S_PRE");   // "0": split W per workgroup and chunk (diagnostics / A-B)
     const int chunks_ = P.kd_per_plane / BK;
-    const long img_bytes = (long)P.n_planes_a * chunks_ * col_tiles * (16L * 32 * nt) * 12;
+    const long img_bytes = (long)P.n_planes_a * chunks_ * col_tiles * (3L * 32 * nt * KSB * 2);   // LDS-shaped: 3 planes x cols x (32 k + pad)
     const bool pre = !(preenv && preenv[0] == '0') && P.pre_ws != nullptr && P.pre_bytes >= img_bytes &&
                      (((uintptr_t)P.pre_ws) & 15u) == 0;
     if (!pre && P.fold_q >= 0) return 0;       // the caller folds the weights itself and comes back without fold_q
@@ -508,7 +533,7 @@ int dsw_ts_gemm_x3s_try_launch(const TsGemmParams& P, hipStream_t stream, int* r
     const int n_flags = sk_ws ? (int)SK_MAX_WG : 0;
     const bool fc = pre && sk_ws != nullptr;   // the split launch clears the flags on its way
     if (pre) {
-        const long n_slots = img_bytes / 12;
+        const long n_slots = (long)P.n_planes_a * chunks_ * col_tiles * (16L * 32 * nt);
         const int blocks = (int)((n_slots + 255) / 256 < 2048 ? (n_slots + 255) / 256 : 2048);
         if (nt == 4) hipLaunchKernelGGL((x3s_presplit_kernel<128>), dim3(blocks), dim3(256), 0, stream, P, static_cast<unsigned*>(P.pre_ws), chunks_, col_tiles, flags, n_flags);
         else hipLaunchKernelGGL((x3s_presplit_kernel<64>), dim3(blocks), dim3(256), 0, stream, P, static_cast<unsigned*>(P.pre_ws), chunks_, col_tiles, flags, n_flags);
