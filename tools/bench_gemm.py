@@ -20,6 +20,7 @@ def timeit(fn, n=30, w=5):
 
 def main():
     lib = _native.load()
+    zeros = "--zeros" in sys.argv   # zero-filled operands: same instructions, least switching power (is the launch clock-limited?)
     use_ws = "--ws" in sys.argv   # through dsw_cheb_fwd_ws (K = 1 layer of width K * Fin) with the caller scratch a layer call passes
     shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:] if not a.startswith("-")] or [
         # the streaming-GEMM launches of one U-Net step (nside 32, B 8; DSW_X3S_TRACE=1 in a diagnostics build lists them):
@@ -35,6 +36,8 @@ def main():
         w = torch.randn(Fin, K, Fout, device="cuda") * 0.05
         b = torch.randn(Fout, device="cuda")
         y = torch.empty(N, Fout, device="cuda")
+        if zeros:
+            x.zero_(); T.zero_(); w.zero_(); b.zero_()
         f = lambda: lib.dsw_cheb_mix_fwd(x.data_ptr(), T.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, Fin, Fout, K, 0, st)
         if use_ws:
             xw = torch.cat([x] + [T[k] for k in range(K - 1)], 1).contiguous()
@@ -46,7 +49,7 @@ def main():
         assert f() == 0
         us = timeit(f)
         ref = (torch.cat([x] + [T[k] for k in range(K - 1)], 1).double() @ w.permute(1, 0, 2).reshape(K * Fin, Fout).double() + b.double())
-        err = ((y.double() - ref).abs().max() / ref.abs().max()).item()
+        err = ((y.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
         fl = 2.0 * N * Fin * K * Fout
         by = (N * Fin * K + N * Fout) * 4
         print("N=%7d %4d->%4d K=%d  %8.1f us  %6.1f TF/s fp32  bf16-pipe %.3f  HBM %6.0f GB/s  err %.1e" % (
