@@ -72,6 +72,9 @@ def parse():
                          "dispatch of the run then belongs to the leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--zero-inputs", action="store_true",
+                    help="diagnostics: zero-filled activations / gradients (same launches, least switching power) - how much of the "
+                         "step time is the clock the chip sustains under real data; the line says data = zeros")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--plain-resblock", action="store_true",
                     help="unet: residual-block tails as separate passes instead of GEMM epilogues (A/B)")
@@ -766,6 +769,9 @@ def main():
             model, lap = make_layer(wl, args.knn, device, dtype)
         x = torch.randn(B, V, wl["fin"], device=device, dtype=dtype).requires_grad_(True)
         gy = torch.randn(B, V, wl["fout"], device=device, dtype=dtype)
+        if args.zero_inputs:
+            with torch.no_grad():
+                x.zero_(); gy.zero_()
 
         def step():
             zero_grads()
@@ -941,7 +947,7 @@ def main():
         "value": units / (elapsed / args.steps), "unit": "nodes*channels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "weak" if args.global_batch is None else "strong", "vs_baseline": None,
-        "dtype": wl["dtype"], "data": "synthetic",
+        "dtype": wl["dtype"], "data": "zeros (diagnostics)" if args.zero_inputs else "synthetic",
         "timing": "median of %d back-to-back timed regions of exactly %d steps each (barrier + synchronize around every region, max over ranks)" % (n_regions, args.steps),
         "region_ms": {"n": n_regions, "min": round(regions[0] * 1e3, 4), "median": round(elapsed * 1e3, 4),
                       "max": round(regions[-1] * 1e3, 4)},
