@@ -29,8 +29,10 @@ static inline int64_t w_image_bytes(int64_t Fin, int64_t Fout, int64_t K) {
     const int64_t fwd = (K * Fin + 31) / 32 * 32 * ((Fout + 127) / 128 * 128) * 15 / 2;      // reduction K Fin, columns Fout
     const int64_t bwd = (Fout + 31) / 32 * 32 * ((K * Fin + 127) / 128 * 128) * 15 / 2;      // reduction Fout, columns K Fin
     const int64_t zmx = (Fin + 31) / 32 * 32 * ((K * Fout + 127) / 128 * 128) * 15 / 2;      // mix-first planes: columns K Fout
+    const int64_t zdg = (K * Fout + 31) / 32 * 32 * ((Fin + 127) / 128 * 128) * 15 / 2;      // mix-first dX: reduction K Fout, columns Fin
     int64_t m = fwd > bwd ? fwd : bwd;
     if (zmx > m) m = zmx;
+    if (zdg > m) m = zdg;
     const int64_t copy = Fin * K * Fout * 4;
     // + the scratch of the streaming GEMM's balanced decomposition (dsw_gemm_x3s.hip: 4 KiB of flags, one partial 256 x 128
     // fp32 tile per workgroup, 256 workgroups)
@@ -392,7 +394,7 @@ int64_t dsw_cheb_bwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t 
             const int64_t pn = (Sn > 0 ? Sn : 1) * (Fin + 1) * K * Fout * 4;
             if (pn > pm) pm = pn;
         }
-        return d + round_up(pm, 256) + 256;
+        return d + round_up(pm, 256) + round_up(w_image_bytes(Fin, Fout, K), 256) + 256;   // + the weight image / scratch of the dX GEMM
     }
     // G_1..G_{K-1} planes, plus two spare planes for the pairwise fused adjoint when K >= 4
     const int64_t g = round_up((K - 1 + (K >= 4 ? 2 : 0)) * N * Fin * elem_size(dtype), 256);
@@ -431,8 +433,12 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
         const int64_t dplane = N * Fout * elem_size(dtype);
         char* D = ws;                                                     // D_1 .. D_{K-1}
         float* part = reinterpret_cast<float*>(ws + round_up((K - 1) * dplane, 256));
+        // scratch of the dX GEMM (per-call weight image, balanced decomposition) behind everything else: need - wf from the base
+        DswEpiExtra exw = ex;
+        exw.ws = ws + (need - 256 - round_up(w_image_bytes(Fin, Fout, K), 256));
+        exw.ws_bytes = w_image_bytes(Fin, Fout, K);
         int rcm = dsw_cheb_basis_fwd(rowptr_t, colind_t, vals_t, V, nnz, dY, D, B, Fout, K, dtype, stream, plan_t);
-        if (rcm == DSW_OK && dX != nullptr) rcm = dsw_zdgrad_launch(dY, D, W, dX, N, Fin, Fout, K, dtype, s, extras ? &ex : nullptr);
+        if (rcm == DSW_OK && dX != nullptr) rcm = dsw_zdgrad_launch(dY, D, W, dX, N, Fin, Fout, K, dtype, s, &exw);
         if (rcm == DSW_OK && dW != nullptr)
             rcm = dsw_wgrad_mixfirst_launch(X, dY, D, dW, db, part, N, Fin, Fout, K, dtype, s, accumulate);
         return rcm;
