@@ -513,7 +513,11 @@ int dsw_ts_gemm_x3s_try_launch(const TsGemmParams& P, hipStream_t stream, int* r
     if (ntenv) nt = ntenv[0] == '2' ? 2 : (n_total > 64 ? 4 : 2);
     const int col_tiles = (n_total + 32 * nt - 1) / (32 * nt);
     const long tiles8 = row_tiles8 * col_tiles;
-    const int nwv = nwvenv ? atoi(nwvenv) : (tiles8 < 128 ? 4 : 8);
+    // one column tile + the pre-split image: two 4-wave workgroups per CU (one A buffer: 78 KB of LDS each) beat one 8-wave
+    // workgroup on short reductions (98 304 x 192 -> 128: 51.9 -> 47.2 us same box); with more column tiles, or on long
+    // reductions (98 304 x 768 -> 128: 156 -> 162 us), they do not
+    const bool two_wg = col_tiles == 1 && nt == 4 && P.pre_ws != nullptr && P.n_planes_a * (P.kd_per_plane / BK) < 24;
+    const int nwv = nwvenv ? atoi(nwvenv) : ((tiles8 < 128 || two_wg) ? 4 : 8);
     // W split once per call into the caller's scratch (with the fold of output plane fold_q, if any) when there is room
     static const char* preenv = dsw_diag_env("DSW_X3S_PRE");   // "0": split W per workgroup and chunk (diagnostics / A-B)
     const int chunks_ = P.kd_per_plane / BK;
