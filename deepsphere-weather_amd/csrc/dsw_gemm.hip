@@ -554,7 +554,11 @@ static int launch_ts_gemm(const TsGemmParams& P, hipStream_t stream) {
             const size_t ks = (size_t)P.n_planes_a * P.kd_per_plane + 8;
             const size_t lds_nat = (size_t)BM * LDA * 4 + (size_t)3 * (size_t)(32 * nat) * ks * 2;
             int rc = DSW_OK;
-            if (lds_nat > 160 * 1024 && dsw_ts_gemm_x3s_try_launch(P, stream, &rc)) return rc;
+            // ... and, with caller scratch (pre-split image by LDS-DMA), also the shapes whose panel would fit when the output
+            // has two or more 128-column tiles: 24 576 x 128 -> 256 32.6 -> 28.3 us, x 128 -> 512 43.5 -> 40.4, 98 304 x 64 -> 256
+            // 43.8 -> 40.1 (narrower outputs: the resident panel wins or ties)
+            const bool stream_w = lds_nat > 160 * 1024 || (P.pre_ws != nullptr && n_total >= 256);
+            if (stream_w && dsw_ts_gemm_x3s_try_launch(P, stream, &rc)) return rc;
         }
         if (P.fold_q >= 0) return DSW_NEED_FOLD;   // only the streaming kernel folds while it splits W: the caller folds and retries
         for (int nt = nat - 1; nt >= 1; --nt) {
