@@ -70,6 +70,11 @@ def parse():
                     help="profiling aid (tools/pmc_traffic.sh): run ONLY that leg of the roofline measurement - the forward "
                          "recurrence, the adjoint recurrence or the pooling products of the workload - and exit; every "
                          "dispatch of the run then belongs to the leg")
+    ap.add_argument("--grad-handling", default="auto", choices=["auto", "autograd", "bucket"],
+                    help="where the parameter gradients live: 'bucket' = one flat buffer (one memset per step) the weight-gradient "
+                         "kernels add into - what every N > 1 run does; 'autograd' = zero_grad(set_to_none) + autograd's tensors; "
+                         "'auto' = bucket when N > 1, autograd when N = 1.  `--gpus 1 --grad-handling bucket` runs the N > 1 step "
+                         "without the exchange, so that a scaling curve compares like with like")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--zero-inputs", action="store_true",
@@ -170,8 +175,37 @@ def _traffic(traffic_key, leg):
         return None
 
 
-def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None):
-    """Time exactly the SpMM launches of one fwd+bwd (K-1 basis hops + K-1 adjoint hops)."""
+def trace_steps(step_fn, n_steps, warm=5, capacity=1 << 16):
+    """Per-role durations INSIDE running steps: HIP events recorded by the library on the launch stream at the role
+    boundaries of its entry points (include/dsw_hip.h: dsw_trace_begin / dsw_trace_end) while `step_fn` - the very step the
+    timed region replays - runs eagerly, back to back.  Every kernel is timed in the cache state the step leaves it, which
+    isolated back-to-back calls of one kernel are not.  Returns {(role, aux0, aux1, aux2): {calls_per_step, avg_us,
+    median_us, us_per_step}}."""
+    from dsw_amd import _native
+
+    for _ in range(warm):
+        step_fn()
+    torch.cuda.synchronize()
+    with _native.LaunchTrace(capacity) as tr:
+        for _ in range(n_steps):
+            step_fn()
+        torch.cuda.synchronize()
+    agg = {}
+    for role, a0, a1, a2, us in tr.intervals:
+        agg.setdefault((role, a0, a1, a2), []).append(us)
+    out = {}
+    for k, v in agg.items():
+        v.sort()
+        out[k] = {"calls_per_step": len(v) / n_steps, "avg_us": sum(v) / len(v), "median_us": v[len(v) // 2],
+                  "us_per_step": sum(v) / n_steps}
+    return out
+
+
+def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced=None, ms_per_step=None):
+    """The SpMM recurrence launches of the workload's dominant ConvCheb layer against the HBM roofline.  Durations of
+    everything a timed step launches come from `traced` (trace_steps: in-step HIP events); launches the step does NOT make
+    (the forward recurrence alone at the north-star shape, the stand-alone channel mix) are timed as isolated legs and
+    say so."""
     from dsw_amd import functional as F_
 
     op = F_.get_operator(layer.laplacian)
@@ -201,10 +235,6 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None):
                                     G0.data_ptr(), Gr.data_ptr(), B, C, K, dcode, st, ppt, spare.data_ptr())
         assert rc == 0
 
-    def launches():
-        fwd()
-        adj()
-
     if pmc_leg in ("fwd", "adj"):     # profiling aid: this leg only
         fn = fwd if pmc_leg == "fwd" else adj
         for _ in range(steps):
@@ -212,12 +242,13 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None):
         torch.cuda.synchronize()
         return {"pmc_leg": pmc_leg, "calls": steps}
     for _ in range(warmup):
-        launches()
+        fwd()
+        adj()
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream()
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    def timed(fn):   # median of three HIP-event regions of `steps` calls each (seconds per call)
+    def timed(fn):   # ISOLATED leg: median of three HIP-event regions of `steps` back-to-back calls (seconds per call)
         reps = []
         for _ in range(3):
             t0.record(stream)
@@ -235,126 +266,137 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None):
 
     n_fwd, n_adj = n_launches(_k1), n_launches(_k2)
     fwd_b, bwd_b = spmm_algorithmic_bytes(E, Lb, K)
-    # the two recurrences, each alone: the forward one is the north-star gate, the adjoint one runs in every step
-    fwd_s = timed(fwd)
-    adj_s_leg = timed(adj)
-    out_mfma = mfma_leg(layer, x, T, steps)
-    # whole forward through the C ABI (dsw_cheb_fwd): at the north-star shape ONE launch (two hops + channel mix,
-    # dsw_fwd3.hip); its algorithmic bytes = the forward recurrence (5E + 2Lb for K = 3) + the mix (K E in, N Fout s out)
     Fout = layer.out_channels
-    yb = torch.empty((B, V, Fout), dtype=x.dtype, device=x.device)
-    bias = layer.bias
+    N = B * V
     mf = bool(lib.dsw_cheb_mix_first(C, Fout, K))
     ppf, _k3 = F_._plan_ptr(op, x, Fout if mf else C) if K > 2 else (None, None)
-
-    def whole_fwd():
-        rc = lib.dsw_cheb_fwd(op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz, x.data_ptr(),
-                              layer.weight.data_ptr(), None if bias is None else bias.data_ptr(), yb.data_ptr(),
-                              T.data_ptr(), B, C, Fout, K, dcode, st, ppf)
-        assert rc == 0
-
-    for _ in range(3):
-        whole_fwd()
-    torch.cuda.synchronize()
-    t0.record(stream)
-    for _ in range(steps):
-        whole_fwd()
-    t1.record(stream)
-    torch.cuda.synchronize()
-    wf_s = t0.elapsed_time(t1) * 1e-3 / steps
-    wf_bytes = fwd_b + (K * E + B * V * Fout * es)
-    out_fwd = {"what": "dsw_cheb_fwd (recurrence + channel mix + bias), HIP events", "avg_us": round(wf_s * 1e6, 2),
-               "algorithmic_bytes": int(wf_bytes), "achieved_GBs": round(wf_bytes / wf_s / 1e9, 1),
-               "frac": round(wf_bytes / wf_s / 1e9 / HBM_PEAK_GBS, 4),
-               "compulsory_bytes": int(E + (K - 1) * E + B * V * Fout * es),
-               "note": "algorithmic = unfused pass count (SURVEY 8d); compulsory = X in, T_1.. out (kept for backward), Y out"}
-    # ---- the kernels that actually run inside a timed step, each against ITS OWN algorithmic bytes -------------------
-    # forward = dsw_cheb_fwd (above); backward = dsw_cheb_bwd = GEMM pass (dW partials + db, dgrad planes G_k; one fused
-    # launch where the shape allows, + the partial reduce) followed by the adjoint recurrence.  The adjoint launches are
-    # timed alone (dsw_cheb_basis_adj); the GEMM pass is the whole backward minus them.
-    in_step = None
-    if not mf:
-        dy = torch.randn((B, V, Fout), dtype=x.dtype, device=x.device)
-        dxb = torch.empty_like(x)
-        dwb = torch.empty_like(layer.weight)
-        dbb = torch.empty((Fout,), dtype=x.dtype, device=x.device)
-        nws = int(lib.dsw_cheb_bwd_workspace_bytes(B, V, C, Fout, K, dcode))
-        ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=x.device)
-
-        def whole_bwd():
-            rc = lib.dsw_cheb_bwd(opt.rowptr.data_ptr(), opt.colind.data_ptr(), opt.values.data_ptr(), V, opt.nnz,
-                                  x.data_ptr(), T.data_ptr(), layer.weight.data_ptr(), dy.data_ptr(), dxb.data_ptr(),
-                                  dwb.data_ptr(), dbb.data_ptr(), ws.data_ptr(), nws, B, C, Fout, K, dcode, st, ppt)
-            assert rc == 0
-
-        fwd()            # T = the basis of x (what the backward of a real step reads)
-        for _ in range(3):
-            whole_bwd()
-        torch.cuda.synchronize()
-        bwd_s = timed(whole_bwd)
-        adj_s = timed(adj)
-        gemm_s = max(bwd_s - adj_s, 1e-9)
-        yb_bytes = B * V * Fout * es
-        gemm_bytes = K * E + yb_bytes + K * E          # basis planes + dY read ONCE, K dgrad planes written
-        gemm_flops = 4.0 * B * V * C * K * Fout         # dW and dgrad
-
-        def entry(role, kernels, sec, nbytes, extra=None):
-            d = {"role": role, "kernels": kernels, "avg_us": round(sec * 1e6, 2), "algorithmic_bytes": int(nbytes),
-                 "achieved_GBs": round(nbytes / sec / 1e9, 1), "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4)}
-            d.update(extra or {})
-            return d
-
-        in_step = [
-            entry("forward (dsw_cheb_fwd)", "cheb3_fwd_fused: hops + channel mix + bias in ONE launch where the shape has "
-                  "it (fp32, K=3, 32-channel chunks), else spmm2_fused / spmm1_dma / spmm_csr hops + ts_gemm* mix", wf_s, wf_bytes,
-                  {"compulsory_bytes": out_fwd["compulsory_bytes"]}),
-            entry("backward GEMM pass (dsw_cheb_bwd minus its adjoint launches)",
-                  "cheb_wgrad_x3<FUSE> (dW partials + db + dgrad planes in one pass) or cheb_wgrad* + ts_gemm* dgrad, "
-                  "+ cheb_wgrad_reduce", gemm_s, gemm_bytes,
-                  {"flops": gemm_flops, "TFLOPs": round(gemm_flops / gemm_s / 1e12, 1),
-                   "bytes_note": "K basis planes + dY read once, K dgrad planes written (separate launches re-read dY)"}),
-            entry("adjoint recurrence (dsw_cheb_basis_adj)", "spmm_csr x%d" % (K - 1) if ppt is None else
-                  "spmm1_dma / spmm1_staged x%d" % (K - 1) if _k2.hops == 1 else "spmm2_fused adjoint pair(s)", adj_s, bwd_b),
-        ]
-        tot = wf_s + bwd_s
-        for d in in_step:
-            d["share_of_fwd_bwd"] = round(d["avg_us"] * 1e-6 / tot, 3)
-    # ---- the headline entry: the SpMM recurrence launches that a timed step really makes --------------------------------
-    # the adjoint recurrence always; the forward recurrence only where the step launches it (not at the north-star shape,
-    # whose forward is ONE launch with the hops inside - that kernel is in_step[0] and whole_forward)
     fwd_path = int(lib.dsw_cheb_fwd_path(ppf, C, Fout, K, dcode))
     path_names = {0: "plain hops + GEMM", 1: "fused hop pairs + GEMM", 2: "staged hops + GEMM", 3: "one launch (hops + channel mix)",
                   4: "mix-first (recurrence on the output channels)"}
     fwd_rec_in_step = fwd_path in (0, 1, 2)
-    legs = [("adj", n_adj, adj_s_leg, bwd_b)] + ([("fwd", n_fwd, fwd_s, fwd_b)] if fwd_rec_in_step else [])
+    traced = traced or {}
+
+    def tr(role, a0, a1, a2):
+        return traced.get((role, a0, a1, a2))
+
+    # ---- in-step durations of this layer's roles (None where the step does not run the role / nothing was traced) -------
+    t_one = tr("fwd_one_launch", V, C, Fout)
+    t_bfwd = tr("basis_fwd", V, C, K)
+    t_mix = tr("mix_fwd", N, K * C, Fout)
+    t_zmix, t_clen = tr("zmix", V, C, Fout), tr("clenshaw_fwd", V, Fout, K)
+    t_gemm = tr("bwd_gemm_fused", V, C, Fout)
+    t_dgrad, t_wgrad = tr("bwd_dgrad", V, C, Fout), tr("bwd_wgrad", V, C, Fout)
+    t_adj = tr("basis_adj", V, C, K)
+    t_bwdf = tr("bwd_fused", V, C, Fout)
+    have_trace = t_adj is not None or t_bwdf is not None or mf
+
+    # forward recurrence alone: in the step where the step launches it, otherwise an isolated leg (north-star gate)
+    fwd_s_iso = timed(fwd)
+    fwd_s = t_bfwd["avg_us"] * 1e-6 if (fwd_rec_in_step and t_bfwd is not None) else fwd_s_iso
+    adj_s_iso = None
+    if t_adj is not None:
+        adj_s = t_adj["avg_us"] * 1e-6
+    else:
+        adj_s = adj_s_iso = timed(adj)
+    out_mfma = mfma_leg(layer, x, T, steps, in_step=t_mix)
+
+    yb_bytes = N * Fout * es
+    wf_bytes = fwd_b + (K * E + yb_bytes)
+    compulsory_fwd = int(E + (K - 1) * E + yb_bytes)
+
+    def entry(role, kernels, sec, nbytes, calls, extra=None):
+        d = {"role": role, "kernels": kernels, "avg_us": round(sec * 1e6, 2), "calls_per_step": calls,
+             "algorithmic_bytes": int(nbytes), "achieved_GBs": round(nbytes / sec / 1e9, 1),
+             "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4), "timing": "in-step HIP events (dsw_trace)"}
+        d.update(extra or {})
+        return d
+
+    in_step = []
+    if t_one is not None:
+        in_step.append(entry("forward (dsw_cheb_fwd)", "cheb3_fwd_fused: hops + channel mix + bias in ONE launch",
+                             t_one["avg_us"] * 1e-6, wf_bytes, t_one["calls_per_step"], {"compulsory_bytes": compulsory_fwd}))
+    else:
+        if t_bfwd is not None:
+            in_step.append(entry("forward recurrence (dsw_cheb_fwd: basis launches)", "spmm2_fused / spmm1_dma / spmm_csr hops",
+                                 t_bfwd["avg_us"] * 1e-6, fwd_b, t_bfwd["calls_per_step"]))
+        if t_mix is not None:
+            in_step.append(entry("forward channel mix (dsw_cheb_fwd: GEMM + bias)", "ts_gemm_x3 / ts_gemm_x3s / ts_gemm",
+                                 t_mix["avg_us"] * 1e-6, K * E + yb_bytes, t_mix["calls_per_step"],
+                                 {"flops": 2.0 * N * C * K * Fout}))
+        if t_zmix is not None:
+            in_step.append(entry("forward plane GEMM of a mix-first layer", "ts_gemm* / narrow_*", t_zmix["avg_us"] * 1e-6,
+                                 E + K * yb_bytes, t_zmix["calls_per_step"]))
+        if t_clen is not None:
+            in_step.append(entry("forward Clenshaw recurrence on the output channels", "spmm* hops", t_clen["avg_us"] * 1e-6,
+                                 spmm_algorithmic_bytes(yb_bytes, Lb, K)[1], t_clen["calls_per_step"]))
+    gemm_flops = 4.0 * N * C * K * Fout         # dW and dgrad
+    if t_gemm is not None:
+        in_step.append(entry("backward GEMM pass (dW partials + db + dgrad planes in one pass, + reduce)",
+                             "cheb_wgrad_x3<FUSE> + cheb_wgrad_reduce", t_gemm["avg_us"] * 1e-6, K * E + yb_bytes + K * E,
+                             t_gemm["calls_per_step"],
+                             {"flops": gemm_flops, "TFLOPs": round(gemm_flops / (t_gemm["avg_us"] * 1e-6) / 1e12, 1),
+                              "bytes_note": "K basis planes + dY read once, K dgrad planes written"}))
+    if t_dgrad is not None:
+        in_step.append(entry("backward dgrad GEMM (planes G_k = dY W_k^T)", "ts_gemm_x3 / ts_gemm_x3s", t_dgrad["avg_us"] * 1e-6,
+                             yb_bytes + K * E, t_dgrad["calls_per_step"], {"flops": gemm_flops / 2}))
+    if t_wgrad is not None:
+        in_step.append(entry("backward wgrad (dW, db)", "cheb_wgrad_x3 / cheb_wgrad_bf16 + reduce", t_wgrad["avg_us"] * 1e-6,
+                             K * E + yb_bytes, t_wgrad["calls_per_step"], {"flops": gemm_flops / 2}))
+    if t_bwdf is not None:
+        in_step.append(entry("backward dgrad + adjoint recurrence in ONE launch (dY -> dX)", "cheb3_bwd_fused",
+                             t_bwdf["avg_us"] * 1e-6, yb_bytes + K * E + bwd_b, t_bwdf["calls_per_step"],
+                             {"compulsory_bytes": int(yb_bytes + E),
+                              "bytes_note": "algorithmic = the dgrad GEMM (dY in, K planes out) + the adjoint recurrence it replaces"}))
+    if t_adj is not None:
+        in_step.append(entry("adjoint recurrence (dsw_cheb_bwd: basis_adj launches)", "spmm_csr x%d" % (K - 1) if ppt is None else
+                             "spmm1_dma / spmm1_staged x%d" % (K - 1) if _k2.hops == 1 else "spmm2_fused adjoint pair(s)",
+                             t_adj["avg_us"] * 1e-6, bwd_b, t_adj["calls_per_step"]))
+    step_sum_us = sum(d["avg_us"] * d["calls_per_step"] for d in in_step)
+    for d in in_step:
+        d["share_of_layer"] = round(d["avg_us"] * d["calls_per_step"] / max(step_sum_us, 1e-9), 3)
+
+    # ---- the headline entry: the SpMM recurrence launches that a timed step really makes --------------------------------
+    # the adjoint recurrence always (inside cheb3_bwd_fused where the step takes that launch); the forward recurrence only
+    # where the step launches it (not at the north-star shape, whose forward is ONE launch with the hops inside)
+    legs = []
+    if t_bwdf is None:
+        legs.append(("adj", n_adj, adj_s, bwd_b))
+    if fwd_rec_in_step:
+        legs.append(("fwd", n_fwd, fwd_s, fwd_b))
+    fused_bwd = t_bwdf is not None
+    if fused_bwd:      # the adjoint recurrence lives inside the fused backward launch: that launch against the bytes it replaces
+        legs.append(("bwdf", 1, t_bwdf["avg_us"] * 1e-6, yb_bytes + K * E + bwd_b))
     n_in = sum(l[1] for l in legs)
     t_in = sum(l[2] for l in legs)
     b_in = sum(l[3] for l in legs)
     achieved = b_in / t_in / 1e9
     moved = [_traffic(traffic_key, l[0]) for l in legs]
     traffic = None if any(m is None for m in moved) else sum(m["hbm_bytes_per_call"] for m in moved) / n_in
-    kname = lambda plan, tr: ("spmm_csr_rowsplit x%d" % (K - 1) if plan is None else
-                              "spmm1_dma / spmm1_staged x%d (one staged launch per hop)" % (K - 1) if plan.hops == 1 else
-                              "spmm2_fused x%d (hops pairwise in one launch)" % pairs) + (" on L^T" if tr else "")
+    kname = lambda plan, trn: ("spmm_csr_rowsplit x%d" % (K - 1) if plan is None else
+                               "spmm1_dma / spmm1_staged x%d (one staged launch per hop)" % (K - 1) if plan.hops == 1 else
+                               "spmm2_fused x%d (hops pairwise in one launch)" % pairs) + (" on L^T" if trn else "")
 
-    def rec_entry(leg, plan, tr, n, sec, nbytes):
+    def rec_entry(leg, plan, trn, n, sec, nbytes, how):
         m = _traffic(traffic_key, leg)
-        d = {"kernels": kname(plan, tr), "launches": n, "us": round(sec * 1e6, 2), "algorithmic_bytes": int(nbytes),
-             "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4),
-             # a launch that keeps an intermediate plane on chip moves fewer bytes than SURVEY 8d's unfused pass count: the
-             # fraction by algorithmic bytes may then exceed what the memory system delivered - bytes_moved says what it did
-             "fused": bool(plan is not None and plan.hops != 1),
-             "bytes_moved": None if m is None else int(m["hbm_bytes_per_call"]),
-             "frac_counter": None if m is None else round(m["hbm_bytes_per_call"] / sec / 1e9 / HBM_PEAK_GBS, 4)}
-        return d
+        return {"kernels": kname(plan, trn), "launches": n, "us": round(sec * 1e6, 2), "algorithmic_bytes": int(nbytes),
+                "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4), "timing": how,
+                # a launch that keeps an intermediate plane on chip moves fewer bytes than SURVEY 8d's unfused pass count: the
+                # fraction by algorithmic bytes may then exceed what the memory system delivered - bytes_moved says what it did
+                "fused": bool(plan is not None and plan.hops != 1),
+                "bytes_moved": None if m is None else int(m["hbm_bytes_per_call"]),
+                "frac_counter": None if m is None else round(m["hbm_bytes_per_call"] / sec / 1e9 / HBM_PEAK_GBS, 4)}
 
-    return {
+    IN, ISO = "in-step HIP events (dsw_trace)", "ISOLATED leg: median of 3 regions of %d back-to-back calls" % steps
+    out = {
         "bound": "hbm",
-        "kernel": "SpMM recurrence launches of a timed step: adjoint recurrence (%s)%s; forward path of this layer: %s" % (
-            kname(_k2, True), (" + forward recurrence (%s)" % kname(_k1, False)) if fwd_rec_in_step else "", path_names.get(fwd_path)),
+        "kernel": ("SpMM recurrence launches of a timed step: " +
+                   ("cheb3_bwd_fused (dgrad GEMM + adjoint recurrence in one launch)" if fused_bwd else
+                    "adjoint recurrence (%s)" % kname(_k2, True)) +
+                   ((" + forward recurrence (%s)" % kname(_k1, False)) if fwd_rec_in_step else "") +
+                   "; forward path of this layer: %s" % path_names.get(fwd_path)),
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4),
-        "fused": any(p is not None and p.hops != 1 for p in ((_k2, _k1) if fwd_rec_in_step else (_k2,))),
+        "fused": fused_bwd or any(p is not None and p.hops != 1 for p in ((_k2, _k1) if fwd_rec_in_step else (_k2,))),
         "traffic": None if traffic is None else int(traffic),
         "frac_counter": None if traffic is None else round(traffic * n_in / t_in / 1e9 / HBM_PEAK_GBS, 4),
         "traffic_source": (None if traffic is None else
@@ -362,21 +404,28 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None):
                            "these launches (2 x FETCH_SIZE + WRITE_SIZE, tools/pmc_traffic.sh); a committed measurement, not "
                            "read in this run"),
         "bytes_per_launch": int(b_in / n_in), "avg_launch_us": round(t_in / n_in * 1e6, 2), "launches": n_in,
-        "launch_timing": "HIP events on the launch stream; median of 3 regions of %d back-to-back calls" % steps,
-        "definition": "achieved = SURVEY 8d algorithmic bytes of these launches / their time; frac_counter = measured HBM bytes / "
-                      "the same time / 8 TB/s",
-        "forward_recurrence": dict(rec_entry("fwd", _k1, False, n_fwd, fwd_s, fwd_b), in_step=fwd_rec_in_step,
+        "launch_timing": (IN + ": the step the timed region replays, run eagerly back to back with the library's role "
+                          "markers on the launch stream" if have_trace and adj_s_iso is None else ISO),
+        "definition": "achieved = SURVEY 8d algorithmic bytes of these launches / their in-step time; frac_counter = measured "
+                      "HBM bytes / the same time / 8 TB/s",
+        "forward_recurrence": dict(rec_entry("fwd", _k1, False, n_fwd, fwd_s, fwd_b,
+                                             IN if (fwd_rec_in_step and t_bfwd is not None) else ISO),
+                                   in_step=fwd_rec_in_step,
                                    note="north-star gate: >= 0.60 of 8 TB/s on the K = 3 forward recurrence"),
-        "adjoint_recurrence": dict(rec_entry("adj", _k2, True, n_adj, adj_s_leg, bwd_b), in_step=True),
+        "adjoint_recurrence": (None if fused_bwd else
+                               dict(rec_entry("adj", _k2, True, n_adj, adj_s, bwd_b, IN if adj_s_iso is None else ISO), in_step=True)),
         "fwd_recurrence_us": round(fwd_s * 1e6, 2),
         "fwd_recurrence_frac": round(fwd_b / fwd_s / 1e9 / HBM_PEAK_GBS, 4),
         "in_step": in_step,
+        "in_step_sum_us": round(step_sum_us, 2),
         "mfma": out_mfma,
-        "whole_forward": out_fwd,
     }
+    if ms_per_step is not None and in_step:
+        out["in_step_sum_vs_ms_per_step"] = round(step_sum_us / (ms_per_step * 1e3), 4)
+    return out
 
 
-def pooling_leg(model, run_forward, steps, traffic_key=None, pmc_leg=None):
+def pooling_leg(model, run_forward, steps, traffic_key=None, pmc_leg=None, traced=None):
     """The interpolation-pooling products of the workload (RemapBlock: pool / unpool and their transposed backward), each
     with its own shape: bytes = input rows + output rows + operator (int32 column + fp32 value per entry + row pointers),
     time = HIP events around `steps` back-to-back calls.  north_star names this kernel; the U-Net has 4 distinct products
@@ -416,23 +465,33 @@ def pooling_leg(model, run_forward, steps, traffic_key=None, pmc_leg=None):
         torch.cuda.synchronize()
         return {"pmc_leg": "pool", "calls": steps}
     tot_s = tot_b = 0.0
+    traced = traced or {}
     for e, (_n, _w, o, t) in zip(entries, calls):
-        for _ in range(3):
-            F_.sparse_remap(o, t)
-        torch.cuda.synchronize()
-        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0.record(stream)
-        for _ in range(steps):
-            F_.sparse_remap(o, t)
-        t1.record(stream)
-        torch.cuda.synchronize()
-        sec = t0.elapsed_time(t1) * 1e-3 / steps
+        hit = traced.get(("spmm", o.shape[0], o.shape[1], t.shape[2]))
+        if hit is not None:
+            # in-step: the product timed inside the running step (products of equal shape - a pooling and the transposed
+            # unpooling of the same level - share one entry of the trace: their mean)
+            sec = hit["avg_us"] * 1e-6
+            e["timing"] = "in-step HIP events (dsw_trace), mean over the step's products of this shape"
+        else:
+            for _ in range(3):
+                F_.sparse_remap(o, t)
+            torch.cuda.synchronize()
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record(stream)
+            for _ in range(steps):
+                F_.sparse_remap(o, t)
+            t1.record(stream)
+            torch.cuda.synchronize()
+            sec = t0.elapsed_time(t1) * 1e-3 / steps
+            e["timing"] = "ISOLATED leg: %d back-to-back calls" % steps
         e["us"] = round(sec * 1e6, 2)
         e["frac"] = round(e["algorithmic_bytes"] / sec / 1e9 / HBM_PEAK_GBS, 4)
         tot_s += sec
         tot_b += e["algorithmic_bytes"]
     m = _traffic(traffic_key, "pool")
-    return {"kernel": "spmm_csr_rowsplit (+ the whole-wave path for rows beyond 64 entries): RemapBlock products",
+    return {"kernel": "RemapBlock products (dsw_spmm_csr: remap_* kernels for hierarchical / staged cross-sampling matrices, "
+                      "spmm_csr_rowsplit otherwise)",
             "bound": "hbm", "products": entries, "us_per_step": round(tot_s * 1e6, 2), "algorithmic_bytes": int(tot_b),
             "frac": round(tot_b / max(tot_s, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
             "bytes_moved": None if m is None else int(m["hbm_bytes_per_call"]),
@@ -444,7 +503,7 @@ def pooling_leg(model, run_forward, steps, traffic_key=None, pmc_leg=None):
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # dense matrix peaks of MI355X (MI355X_MICROARCH.md)
 
 
-def mfma_leg(layer, x, T, steps):
+def mfma_leg(layer, x, T, steps, in_step=None):
     """The channel-mix GEMM of the forward pass (layers.py:171-178): algorithmic flops 2 N Fin K Fout over the mean
     launch time (HIP events on the launch stream) against the dense MFMA peak of the storage dtype.  fp32 layers run
     on the bf16 matrix pipe with 3-way split operands (6 MFMA terms per product): the utilisation of that pipe is the
@@ -476,13 +535,17 @@ def mfma_leg(layer, x, T, steps):
     t1.record(stream)
     torch.cuda.synchronize()
     avg_s = t0.elapsed_time(t1) * 1e-3 / steps
+    how = "ISOLATED leg (the step does not launch the stand-alone channel mix for this layer): %d back-to-back calls" % steps
+    if in_step is not None:      # the step launches this GEMM: its in-step duration
+        avg_s = in_step["avg_us"] * 1e-6
+        how = "in-step HIP events (dsw_trace)"
     flops = 2.0 * N * Fin * K * Fout
     peak = MFMA_PEAK_TFLOPS["bf16" if bf16 else "f32"]
     ach = flops / avg_s / 1e12
     hbm = (K * N * Fin + N * Fout) * x.element_size()
     out = {"kernel": "channel mix forward (ts_gemm%s)" % ("" if bf16 else "_x3"), "flops": flops,
            "avg_launch_us": round(avg_s * 1e6, 2), "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-           "frac": round(ach / peak, 4), "hbm_GBs": round(hbm / avg_s / 1e9, 1)}
+           "frac": round(ach / peak, 4), "hbm_GBs": round(hbm / avg_s / 1e9, 1), "timing": how}
     if not bf16:
         out["bf16_pipe_frac"] = round(6 * ach / MFMA_PEAK_TFLOPS["bf16"], 4)
         out["note"] = ("fp32 product evaluated as 6 bf16 MFMA terms (3-way operand split); frac is against the fp32 "
@@ -790,7 +853,10 @@ def main():
     # it in place.  The exchange is part of the step: captured INTO the step graph when RCCL is the backend, issued
     # right after the replay otherwise (gloo, or DSW_BENCH_COLLECTIVES=eager).
     bucket = GradBucket(model.parameters(), overlap=False, attach=False)
-    if bucket.active():
+    if args.grad_handling == "autograd" and bucket.active():
+        sys.exit("bench.py: --grad-handling autograd has no N > 1 form (the exchange runs on the bucket)")
+    use_bucket = bucket.active() or args.grad_handling == "bucket"
+    if use_bucket:
         bucket.attach()
         bucket.direct_accumulation()     # the weight-gradient kernels add into the bucket: no autograd `add` per parameter
         zero_grads = bucket.zero
@@ -965,6 +1031,8 @@ def main():
             # N = 1 and N > 1 do not run byte-identical steps: say which one this line timed
             "grad_handling": ("parameter gradients live in one flat bucket (one memset per step), the weight-gradient kernels "
                               "add into it, all-reduced in place" if bucket.active() else
+                              "parameter gradients live in one flat bucket (one memset per step), the weight-gradient kernels "
+                              "add into it (the N > 1 step; no exchange in a one-rank world)" if use_bucket else
                               "zero_grad(set_to_none=True) + autograd's gradient tensors (no exchange in a one-rank world)"),
             "launch": (("hip graph replay, %d steps per graph" % GRAPH_STEPS if graph_multi is not None
                         else "hip graph replay of one fwd+bwd" if graph is not None else "eager")
@@ -1022,11 +1090,29 @@ def main():
         # restatement of the SAME workload
         rl_layer, rl_what, rl_x, tkey = roofline_target(args, model, x, B, V, device)
         if not args.no_roofline:
-            out["roofline"] = roofline_leg(rl_layer, rl_x, max(10, args.steps), 5, traffic_key=tkey)
+            # per-role durations inside running steps: the step of the timed region, launched eagerly back to back with the
+            # library's role markers on the launch stream (a graph replay cannot carry them)
+            traced = None
+            try:
+                traced = trace_steps(lambda: (step(), sync_grads()), 10 if args.workload == "unet" else 40)
+            except Exception as exc:  # noqa: BLE001 - the line then says its legs are isolated
+                print("bench: launch trace unavailable (%s: %s); roofline legs are isolated timings" % (type(exc).__name__, exc),
+                      file=sys.stderr)
+            out["roofline"] = roofline_leg(rl_layer, rl_x, max(10, args.steps), 5, traffic_key=tkey, traced=traced,
+                                           ms_per_step=ms if args.workload in ("ns", "c3") else None)
             if rl_what is not None:
                 out["roofline"]["kernel"] += "; layer " + rl_what
+            if traced is not None:
+                tot = sum(v["us_per_step"] for v in traced.values())
+                out["roofline"]["traced_step"] = {
+                    "what": "every role the library's entry points ran in one step (eager, back to back), us per step",
+                    "sum_us": round(tot, 1), "vs_ms_per_step": round(tot / (ms * 1e3), 4),
+                    "roles": sorted(({"role": k[0], "aux": list(k[1:]), "calls_per_step": round(v["calls_per_step"], 2),
+                                      "avg_us": round(v["avg_us"], 2), "us_per_step": round(v["us_per_step"], 2)}
+                                     for k, v in traced.items()), key=lambda d: -d["us_per_step"])[:24]}
             if args.workload in ("unet", "c5"):
-                out["roofline"]["pooling"] = pooling_leg(model, lambda: model(x.detach()), max(10, args.steps), traffic_key=tkey)
+                out["roofline"]["pooling"] = pooling_leg(model, lambda: model(x.detach()), max(10, args.steps), traffic_key=tkey,
+                                                         traced=traced)
         if not args.no_cpu_baseline:
             if args.workload == "unet":
                 out["cpu_baseline"] = cpu_baseline_unet(model, wl, V)

@@ -2,6 +2,52 @@
 #include "dsw_common.h"
 #include "../../include/dsw_hip.h"
 #include <cstdlib>
+#include <atomic>
+#include <mutex>
+#include <vector>
+
+// ---- launch tracing (dsw_trace_begin / dsw_trace_end): HIP events on the launch stream at the ROLE boundaries of the entry
+// points - forward launch, backward GEMM pass, adjoint recurrence, a pooling product ... - so that a benchmark can time each
+// role INSIDE a running step (the caches in the state the step leaves them) instead of in isolated back-to-back calls.
+// Off (one relaxed atomic load per entry point) unless a trace is open.
+namespace {
+struct DswTrace {
+    std::mutex mu;
+    std::atomic<bool> on{false};
+    std::vector<hipEvent_t> ev;
+    std::vector<int> role, a0, a1, a2;
+    int n = 0;
+    bool overflow = false;
+};
+DswTrace g_trace;
+std::atomic<int> g_build_flags{0};
+
+static void trace_event(hipStream_t s, int role, int64_t a0, int64_t a1, int64_t a2) {
+    if (!g_trace.on.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> lk(g_trace.mu);
+    if (!g_trace.on.load(std::memory_order_relaxed)) return;
+    if (g_trace.n >= (int)g_trace.ev.size()) { g_trace.overflow = true; return; }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return;      // never inside a graph capture
+    }
+    if (hipEventRecord(g_trace.ev[g_trace.n], s) != hipSuccess) { (void)hipGetLastError(); return; }
+    g_trace.role[g_trace.n] = role; g_trace.a0[g_trace.n] = (int)a0; g_trace.a1[g_trace.n] = (int)a1; g_trace.a2[g_trace.n] = (int)a2;
+    ++g_trace.n;
+}
+// start marker of an entry point (role 0: closes nothing) / end of a role (closes the interval since the previous event)
+static inline void trace_start(dsw_stream_t s) { trace_event((hipStream_t)s, 0, 0, 0, 0); }
+static inline void trace_mark(dsw_stream_t s, int role, int64_t a0 = 0, int64_t a1 = 0, int64_t a2 = 0) { trace_event((hipStream_t)s, role, a0, a1, a2); }
+}  // namespace
+
+void dsw_trace_point(hipStream_t s, int role, int64_t a0, int64_t a1, int64_t a2) { trace_event(s, role, a0, a1, a2); }
+
+// every translation unit reports the diagnostics switches it was compiled with (dsw_common.h: DSW_TU_BUILD_FLAGS)
+int dsw_register_build_flags(int flags) {
+    g_build_flags.fetch_or(flags, std::memory_order_relaxed);
+    return flags;
+}
 
 // internal launchers (dsw_spmm.hip / dsw_gemm.hip)
 int dsw_spmm_launch_ld(const int* rowptr, const int* colind, const float* vals, int64_t v_out, int64_t v_in,
@@ -25,7 +71,14 @@ struct DswEpiExtra {   // optional epilogue operands / scratch of the channel-mi
 };
 // bytes of that scratch for a layer: the pre-split image of the streaming GEMM (1.5x the fp32 weights, columns padded to the
 // 128-column tile) or a copy of the weights, whichever is larger
-static inline int64_t w_image_bytes(int64_t Fin, int64_t Fout, int64_t K) {
+// Can one of the layer's four channel-mix forms take the streaming-W GEMM (dsw_gemm.hip: launch_ts_gemm, fp32 only:
+// outputs of >= 256 columns, or a split W panel beyond LDS)?  Only then is the scratch of its balanced decomposition needed.
+static inline bool w_may_stream(int64_t red, int64_t cols) {
+    if (cols <= 32) return false;
+    const int64_t nat = cols <= 128 ? (cols + 31) / 32 * 32 : 128;
+    return cols >= 256 || 3 * nat * (red + 8) * 2 > 100 * 1024;    // (the launcher's own bound is ~140 KB of panel: conservative)
+}
+static inline int64_t w_image_bytes(int64_t Fin, int64_t Fout, int64_t K, int dtype = DSW_F32) {
     const int64_t fwd = (K * Fin + 31) / 32 * 32 * ((Fout + 127) / 128 * 128) * 15 / 2;      // reduction K Fin, columns Fout
     const int64_t bwd = (Fout + 31) / 32 * 32 * ((K * Fin + 127) / 128 * 128) * 15 / 2;      // reduction Fout, columns K Fin
     const int64_t zmx = (Fin + 31) / 32 * 32 * ((K * Fout + 127) / 128 * 128) * 15 / 2;      // mix-first planes: columns K Fout
@@ -35,8 +88,11 @@ static inline int64_t w_image_bytes(int64_t Fin, int64_t Fout, int64_t K) {
     if (zdg > m) m = zdg;
     const int64_t copy = Fin * K * Fout * 4;
     // + the scratch of the streaming GEMM's balanced decomposition (dsw_gemm_x3s.hip: 4 KiB of flags, one partial 256 x 128
-    // fp32 tile per workgroup, 256 workgroups)
-    return (m > copy ? m : copy) + 512 + 4096 + 256 * (256 * 128 * 4);
+    // fp32 tile per workgroup, 256 workgroups) - only for layers one of whose GEMMs can take that kernel (the
+    // 32-channel layers paid 32 MiB of scratch per backward call for a kernel they never launch)
+    const bool streams = dtype == DSW_F32 && (w_may_stream(K * Fin, Fout) || w_may_stream(Fout, K * Fin) ||
+                                               w_may_stream(Fin, K * Fout) || w_may_stream(K * Fout, Fin));
+    return (m > copy ? m : copy) + 512 + (streams ? 4096 + 256 * (256 * 128 * 4) : 0);
 }
 int dsw_mix_fwd_launch(const void* X, const void* T, const void* W, const void* bias, void* Y, int64_t N,
                        int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int relu = 0,
@@ -95,6 +151,53 @@ extern "C" {
 
 int dsw_version(void) { return DSW_VERSION; }
 
+int dsw_build_flags(void) { return g_build_flags.load(std::memory_order_relaxed); }
+
+int dsw_trace_begin(int capacity) {
+    if (capacity <= 0 || capacity > (1 << 20)) return DSW_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(g_trace.mu);
+    if (g_trace.on.load()) return DSW_ERR_BAD_ARG;          // one trace at a time
+    g_trace.ev.assign((size_t)capacity, nullptr);
+    for (int i = 0; i < capacity; ++i)
+        if (hipEventCreate(&g_trace.ev[i]) != hipSuccess) {
+            for (int j = 0; j < i; ++j) (void)hipEventDestroy(g_trace.ev[j]);
+            g_trace.ev.clear();
+            return DSW_ERR_LAUNCH;
+        }
+    g_trace.role.assign((size_t)capacity, 0); g_trace.a0.assign((size_t)capacity, 0); g_trace.a1.assign((size_t)capacity, 0);
+    g_trace.a2.assign((size_t)capacity, 0);
+    g_trace.n = 0; g_trace.overflow = false;
+    g_trace.on.store(true);
+    return DSW_OK;
+}
+
+int dsw_trace_end(int32_t* roles, int32_t* aux0, int32_t* aux1, int32_t* aux2, float* us, int cap) {
+    std::lock_guard<std::mutex> lk(g_trace.mu);
+    if (!g_trace.on.load()) return DSW_ERR_BAD_ARG;
+    g_trace.on.store(false);
+    int out = 0, rc = DSW_OK;
+    for (int i = 0; i < g_trace.n; ++i) {
+        if (hipEventSynchronize(g_trace.ev[i]) != hipSuccess) { rc = DSW_ERR_LAUNCH; break; }
+        if (g_trace.role[i] == 0 || i == 0) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_trace.ev[i - 1], g_trace.ev[i]) != hipSuccess) { rc = DSW_ERR_LAUNCH; break; }
+        if (out < cap && roles && us) {
+            roles[out] = g_trace.role[i];
+            if (aux0) aux0[out] = g_trace.a0[i];
+            if (aux1) aux1[out] = g_trace.a1[i];
+            if (aux2) aux2[out] = g_trace.a2[i];
+            us[out] = ms * 1000.f;
+        }
+        ++out;
+    }
+    for (hipEvent_t e : g_trace.ev) (void)hipEventDestroy(e);
+    g_trace.ev.clear(); g_trace.role.clear(); g_trace.a0.clear(); g_trace.a1.clear(); g_trace.a2.clear();
+    const bool ovf = g_trace.overflow;
+    g_trace.n = 0;
+    if (rc != DSW_OK) { (void)hipGetLastError(); return rc; }
+    return ovf ? DSW_ERR_WORKSPACE : out;
+}
+
 const char* dsw_strerror(int code) {
     switch (code) {
         case DSW_OK: return "ok";
@@ -114,8 +217,11 @@ int dsw_spmm_csr(const int32_t* rowptr, const int32_t* colind, const float* vals
     if (v_out == 0 || B == 0 || C == 0) return DSW_OK;
     if (!rowptr || !X || !Y || (nnz > 0 && (!colind || !vals))) return DSW_ERR_BAD_ARG;
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
-    return dsw_spmm_launch(rowptr, colind, vals, v_out, v_in, X, Y, B, C, alpha, Z, beta, Z2, gamma, dtype,
-                           (hipStream_t)stream);
+    trace_start(stream);
+    const int rc = dsw_spmm_launch(rowptr, colind, vals, v_out, v_in, X, Y, B, C, alpha, Z, beta, Z2, gamma, dtype,
+                                   (hipStream_t)stream);
+    trace_mark(stream, DSW_ROLE_SPMM, v_out, v_in, C);
+    return rc;
 }
 
 int dsw_spmm_csr_ld(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t v_out, int64_t v_in,
@@ -125,8 +231,11 @@ int dsw_spmm_csr_ld(const int32_t* rowptr, const int32_t* colind, const float* v
     if (v_out == 0 || B == 0 || C == 0) return DSW_OK;
     if (!rowptr || !X || !Y || (nnz > 0 && (!colind || !vals))) return DSW_ERR_BAD_ARG;
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
-    return dsw_spmm_launch_ld(rowptr, colind, vals, v_out, v_in, X, ldx, Y, ldy, B, C, alpha, Z, beta, Z2, gamma, dtype,
-                              (hipStream_t)stream, 0, Z ? ldz : C);
+    trace_start(stream);
+    const int rc = dsw_spmm_launch_ld(rowptr, colind, vals, v_out, v_in, X, ldx, Y, ldy, B, C, alpha, Z, beta, Z2, gamma, dtype,
+                                      (hipStream_t)stream, 0, Z ? ldz : C);
+    trace_mark(stream, DSW_ROLE_SPMM, v_out, v_in, C);
+    return rc;
 }
 
 int dsw_spmm2_fused(const dsw_hop2_plan* plan, int64_t V, const void* U, const void* Z1, const void* Z1b,
@@ -134,22 +243,28 @@ int dsw_spmm2_fused(const dsw_hop2_plan* plan, int64_t V, const void* U, const v
                     float a2, float b2, float c2, int dtype, dsw_stream_t stream) {
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     if (V < 0 || B < 0 || C < 0) return DSW_ERR_BAD_ARG;
-    return dsw_spmm2_launch(plan, V, U, Z1, Z1b, Z2, Y1, Y2, B, C, a1, b1, d1, a2, b2, c2, dtype,
-                            (hipStream_t)stream);
+    trace_start(stream);
+    const int rc = dsw_spmm2_launch(plan, V, U, Z1, Z1b, Z2, Y1, Y2, B, C, a1, b1, d1, a2, b2, c2, dtype,
+                                    (hipStream_t)stream);
+    trace_mark(stream, DSW_ROLE_SPMM2, V, V, C);
+    return rc;
 }
 
 int dsw_spmm_staged(const dsw_hop2_plan* plan, int64_t V, const void* U, const void* Z, const void* Z2, void* Y,
                     int64_t B, int64_t C, float a, float b, float c, int dtype, dsw_stream_t stream, int stream_out) {
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     if (V < 0 || B < 0 || C < 0) return DSW_ERR_BAD_ARG;
-    return dsw_spmm1s_launch(plan, V, U, Z, Z2, Y, B, C, a, b, c, dtype, (hipStream_t)stream, stream_out);
+    trace_start(stream);
+    const int rc = dsw_spmm1s_launch(plan, V, U, Z, Z2, Y, B, C, a, b, c, dtype, (hipStream_t)stream, stream_out);
+    trace_mark(stream, DSW_ROLE_SPMM_STAGED, V, V, C);
+    return rc;
 }
 
 int dsw_spmm_staged_supported(const dsw_hop2_plan* plan, int64_t C, int dtype) { return dsw_spmm1s_supported(plan, C, dtype); }
 
-int dsw_cheb_basis_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V,
-                       int64_t nnz, const void* X, void* T, int64_t B, int64_t C, int64_t K, int dtype,
-                       dsw_stream_t stream, const dsw_hop2_plan* plan) {
+static int cheb_basis_fwd_impl(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V,
+                               int64_t nnz, const void* X, void* T, int64_t B, int64_t C, int64_t K, int dtype,
+                               dsw_stream_t stream, const dsw_hop2_plan* plan) {
     if (K <= 1) return K == 1 ? DSW_OK : DSW_ERR_BAD_ARG;
     if (V < 0 || B < 0 || C < 0 || nnz < 0) return DSW_ERR_BAD_ARG;
     if (V == 0 || B == 0 || C == 0) return DSW_OK;
@@ -245,10 +360,22 @@ static int cheb_basis_adj_impl(const int32_t* rowptr_t, const int32_t* colind_t,
     return rc;
 }
 
+int dsw_cheb_basis_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V,
+                       int64_t nnz, const void* X, void* T, int64_t B, int64_t C, int64_t K, int dtype,
+                       dsw_stream_t stream, const dsw_hop2_plan* plan) {
+    trace_start(stream);
+    const int rc = cheb_basis_fwd_impl(rowptr, colind, vals, V, nnz, X, T, B, C, K, dtype, stream, plan);
+    trace_mark(stream, DSW_ROLE_BASIS_FWD, V, C, K);
+    return rc;
+}
+
 int dsw_cheb_basis_adj(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t, int64_t V,
                        int64_t nnz, void* G0, void* Grest, int64_t B, int64_t C, int64_t K, int dtype,
                        dsw_stream_t stream, const dsw_hop2_plan* plan_t, void* spare) {
-    return cheb_basis_adj_impl(rowptr_t, colind_t, vals_t, V, nnz, G0, Grest, B, C, K, dtype, stream, plan_t, spare, 0);
+    trace_start(stream);
+    const int rc = cheb_basis_adj_impl(rowptr_t, colind_t, vals_t, V, nnz, G0, Grest, B, C, K, dtype, stream, plan_t, spare, 0);
+    trace_mark(stream, DSW_ROLE_BASIS_ADJ, V, C, K);
+    return rc;
 }
 
 int dsw_cheb_mix_fwd(const void* X, const void* T, const void* W, const void* bias, void* Y, int64_t N,
@@ -256,7 +383,10 @@ int dsw_cheb_mix_fwd(const void* X, const void* T, const void* W, const void* bi
     if (N < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
     if (N == 0) return DSW_OK;
     if (!X || !W || !Y || (K > 1 && !T)) return DSW_ERR_BAD_ARG;
-    return dsw_mix_fwd_launch(X, T, W, bias, Y, N, Fin, Fout, K, dtype, (hipStream_t)stream);
+    trace_start(stream);
+    const int rc = dsw_mix_fwd_launch(X, T, W, bias, Y, N, Fin, Fout, K, dtype, (hipStream_t)stream);
+    trace_mark(stream, DSW_ROLE_MIX_FWD, N, Fin, Fout);
+    return rc;
 }
 
 int dsw_cheb_mix_first(int64_t Fin, int64_t Fout, int64_t K) { return mix_first(Fin, Fout, K) ? 1 : 0; }
@@ -277,7 +407,7 @@ static int cheb_fwd_impl(const int32_t* rowptr, const int32_t* colind, const flo
                          const void* scale, const void* R, int64_t ldr, int64_t ldy, void* workspace = nullptr,
                          int64_t workspace_bytes = 0) {
     if (K <= 0 || (act != DSW_ACT_NONE && act != DSW_ACT_RELU)) return DSW_ERR_BAD_ARG;
-    if (workspace != nullptr && (Fin <= 0 || Fout <= 0 || workspace_bytes < w_image_bytes(Fin, Fout, K))) return DSW_ERR_WORKSPACE;
+    if (workspace != nullptr && (Fin <= 0 || Fout <= 0 || workspace_bytes < w_image_bytes(Fin, Fout, K, dtype))) return DSW_ERR_WORKSPACE;
     if (R != nullptr && ldr < Fout) return DSW_ERR_BAD_ARG;
     if (ldy != 0 && ldy < Fout) return DSW_ERR_BAD_ARG;
     const int relu = act == DSW_ACT_RELU;
@@ -289,6 +419,7 @@ static int cheb_fwd_impl(const int32_t* rowptr, const int32_t* colind, const flo
     DswEpiExtra ex = {scale, R, ldr, (ldy != 0 && ldy != Fout) ? ldy : 0, wsa, wsb, 0};
     const bool use_ex = extras || wsa != nullptr;
     int rc = DSW_OK;
+    trace_start(stream);
     if (mix_first(Fin, Fout, K)) {
         if (ldy != 0 && ldy != Fout) return DSW_ERR_BAD_ARG;   // the recurrence on the output planes runs on dense [N, Fout]
         // T is scratch here: (K-1) planes of [N, Fin] hold the K-1 (+2 spare for K >= 4) planes of [N, Fout]
@@ -321,33 +452,44 @@ static int cheb_fwd_impl(const int32_t* rowptr, const int32_t* colind, const flo
             }
         }
         rc = dsw_zmix_launch(X, Wz, bias, Y, T, N, Fin, Fout, K, dtype, (hipStream_t)stream, use_ex ? &ex : nullptr);
+        trace_mark(stream, DSW_ROLE_ZMIX, V, Fin, Fout);
         if (rc != DSW_OK) return rc;
         // the Clenshaw recurrence has exactly the form of the adjoint recurrence (with L instead of L^T)
         rc = cheb_basis_adj_impl(rowptr, colind, vals, V, nnz, Y, T, B, Fout, K, dtype, stream, plan,
                                  K >= 4 ? spare : nullptr, folded);
+        trace_mark(stream, DSW_ROLE_CLENSHAW_FWD, V, Fout, K);
         // the mix-first order ends in an SpMM: the activation is one in-place pass over the (Fout-channel) output
-        if (rc == DSW_OK && relu) rc = dsw_relu_inplace_launch(Y, N * Fout, dtype, (hipStream_t)stream);
+        if (rc == DSW_OK && relu) {
+            rc = dsw_relu_inplace_launch(Y, N * Fout, dtype, (hipStream_t)stream);
+            trace_mark(stream, DSW_ROLE_ELEMENTWISE, V, Fout, 0);
+        }
         return rc;
     }
     if (K == 3 && !extras && X && W && Y && rowptr && B >= 0 && V >= 0) {
         // K = 3, 32 input channels, fp32: both hops AND the channel mix in one launch (dsw_fwd3.hip)
         int rcf = DSW_OK;
-        if (dsw_cheb3_fwd_fused_try(plan, V, X, W, bias, Y, T, B, Fin, Fout, K, dtype, (hipStream_t)stream, &rcf, relu)) return rcf;
+        if (dsw_cheb3_fwd_fused_try(plan, V, X, W, bias, Y, T, B, Fin, Fout, K, dtype, (hipStream_t)stream, &rcf, relu)) {
+            trace_mark(stream, DSW_ROLE_FWD_ONE_LAUNCH, V, Fin, Fout);
+            return rcf;
+        }
     }
     if (K > 1) {
-        rc = dsw_cheb_basis_fwd(rowptr, colind, vals, V, nnz, X, T, B, Fin, K, dtype, stream, plan);
+        rc = cheb_basis_fwd_impl(rowptr, colind, vals, V, nnz, X, T, B, Fin, K, dtype, stream, plan);
+        trace_mark(stream, DSW_ROLE_BASIS_FWD, V, Fin, K);
         if (rc != DSW_OK) return rc;
     }
     if (B * V < 0 || Fin <= 0 || Fout <= 0) return DSW_ERR_BAD_ARG;
     if (B * V == 0) return DSW_OK;
     if (!X || !W || !Y || (K > 1 && !T)) return DSW_ERR_BAD_ARG;
-    return dsw_mix_fwd_launch(X, T, W, bias, Y, B * V, Fin, Fout, K, dtype, (hipStream_t)stream, relu, use_ex ? &ex : nullptr);
+    rc = dsw_mix_fwd_launch(X, T, W, bias, Y, B * V, Fin, Fout, K, dtype, (hipStream_t)stream, relu, use_ex ? &ex : nullptr);
+    trace_mark(stream, DSW_ROLE_MIX_FWD, B * V, K * Fin, Fout);
+    return rc;
 }
 
 int64_t dsw_cheb_fwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t Fout, int64_t K, int dtype) {
     if (B < 0 || V < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
-    return w_image_bytes(Fin, Fout, K) + 256;
+    return w_image_bytes(Fin, Fout, K, dtype) + 256;
 }
 
 int dsw_cheb_fwd_ws(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V, int64_t nnz,
@@ -394,13 +536,13 @@ int64_t dsw_cheb_bwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t 
             const int64_t pn = (Sn > 0 ? Sn : 1) * (Fin + 1) * K * Fout * 4;
             if (pn > pm) pm = pn;
         }
-        return d + round_up(pm, 256) + round_up(w_image_bytes(Fin, Fout, K), 256) + 256;   // + the weight image / scratch of the dX GEMM
+        return d + round_up(pm, 256) + round_up(w_image_bytes(Fin, Fout, K, dtype), 256) + 256;   // + the weight image / scratch of the dX GEMM
     }
     // G_1..G_{K-1} planes, plus two spare planes for the pairwise fused adjoint when K >= 4
     const int64_t g = round_up((K - 1 + (K >= 4 ? 2 : 0)) * N * Fin * elem_size(dtype), 256);
     const int64_t S = dsw_wgrad_slabs(N, Fin, Fout, K);
     const int64_t p = round_up((S > 0 ? S : 1) * (K * Fin + 1) * Fout * 4, 256);
-    const int64_t wf = round_up(w_image_bytes(Fin, Fout, K), 256);   // pre-split / folded image of the weights for the dgrad GEMM
+    const int64_t wf = round_up(w_image_bytes(Fin, Fout, K, dtype), 256);   // pre-split / folded image of the weights for the dgrad GEMM
     return g + p + wf + 256;
 }
 
@@ -427,6 +569,7 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
     }
     // carve the workspace (256-byte aligned base)
     char* ws = reinterpret_cast<char*>(round_up((int64_t)(uintptr_t)workspace, 256));
+    trace_start(stream);
     if (mf) {
         if (N == 0 || (!dX && !dW)) return DSW_OK;
         if (!rowptr_t) return DSW_ERR_BAD_ARG;
@@ -435,12 +578,18 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
         float* part = reinterpret_cast<float*>(ws + round_up((K - 1) * dplane, 256));
         // scratch of the dX GEMM (per-call weight image, balanced decomposition) behind everything else: need - wf from the base
         DswEpiExtra exw = ex;
-        exw.ws = ws + (need - 256 - round_up(w_image_bytes(Fin, Fout, K), 256));
-        exw.ws_bytes = w_image_bytes(Fin, Fout, K);
-        int rcm = dsw_cheb_basis_fwd(rowptr_t, colind_t, vals_t, V, nnz, dY, D, B, Fout, K, dtype, stream, plan_t);
-        if (rcm == DSW_OK && dX != nullptr) rcm = dsw_zdgrad_launch(dY, D, W, dX, N, Fin, Fout, K, dtype, s, &exw);
-        if (rcm == DSW_OK && dW != nullptr)
+        exw.ws = ws + (need - 256 - round_up(w_image_bytes(Fin, Fout, K, dtype), 256));
+        exw.ws_bytes = w_image_bytes(Fin, Fout, K, dtype);
+        int rcm = cheb_basis_fwd_impl(rowptr_t, colind_t, vals_t, V, nnz, dY, D, B, Fout, K, dtype, stream, plan_t);
+        trace_mark(stream, DSW_ROLE_BASIS_DUAL, V, Fout, K);     // the dual: Chebyshev basis of dY under L^T
+        if (rcm == DSW_OK && dX != nullptr) {
+            rcm = dsw_zdgrad_launch(dY, D, W, dX, N, Fin, Fout, K, dtype, s, &exw);
+            trace_mark(stream, DSW_ROLE_BWD_DGRAD, V, Fin, Fout);
+        }
+        if (rcm == DSW_OK && dW != nullptr) {
             rcm = dsw_wgrad_mixfirst_launch(X, dY, D, dW, db, part, N, Fin, Fout, K, dtype, s, accumulate);
+            trace_mark(stream, DSW_ROLE_BWD_WGRAD, V, Fin, Fout);
+        }
         return rcm;
     }
     const int64_t plane = N * Fin * elem_size(dtype);
@@ -459,10 +608,13 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
         if (K > 1 && !rowptr_t) return DSW_ERR_BAD_ARG;
         int rcf = DSW_OK;
         if (dsw_bwd_gemm_fused_try(X, T, W, dY, dW, db, dX, G, partial, N, Fin, Fout, K, dtype, s, &rcf, accumulate, folded)) {
+            trace_mark(stream, DSW_ROLE_BWD_GEMM_FUSED, V, Fin, Fout);
             if (rcf != DSW_OK) return rcf;
-            if (K > 1)
+            if (K > 1) {
                 rcf = cheb_basis_adj_impl(rowptr_t, colind_t, vals_t, V, nnz, dX, G, B, Fin, K, dtype, stream, plan_t,
                                           K >= 4 ? spare : nullptr, folded);
+                trace_mark(stream, DSW_ROLE_BASIS_ADJ, V, Fin, K);
+            }
             return rcf;
         }
     }
@@ -474,16 +626,20 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
         const int64_t S_ = dsw_wgrad_slabs(N, Fin, Fout, K);
         DswEpiExtra exw = ex;
         exw.ws = reinterpret_cast<char*>(partial) + round_up((S_ > 0 ? S_ : 1) * (K * Fin + 1) * Fout * 4, 256);
-        exw.ws_bytes = w_image_bytes(Fin, Fout, K);
+        exw.ws_bytes = w_image_bytes(Fin, Fout, K, dtype);
         exw.fold = folded;
         rc = dsw_mix_dgrad_launch(dY, W, dX, G, N, Fin, Fout, K, dtype, s, &exw);
-        if (rc == DSW_OK && K > 1)
+        trace_mark(stream, DSW_ROLE_BWD_DGRAD, V, Fin, Fout);
+        if (rc == DSW_OK && K > 1) {
             rc = cheb_basis_adj_impl(rowptr_t, colind_t, vals_t, V, nnz, dX, G, B, Fin, K, dtype, stream, plan_t,
                                      K >= 4 ? spare : nullptr, folded);
+            trace_mark(stream, DSW_ROLE_BASIS_ADJ, V, Fin, K);
+        }
         if (rc != DSW_OK) return rc;
     }
     if (dW != nullptr) {
         rc = dsw_wgrad_launch(X, T, dY, dW, db, partial, N, Fin, Fout, K, dtype, s, accumulate);
+        trace_mark(stream, DSW_ROLE_BWD_WGRAD, V, Fin, Fout);
     }
     return rc;
 }
@@ -515,6 +671,7 @@ int dsw_rezero_param_grads(const void* W, const void* bias, const void* dW_raw, 
     if (n_w < 0 || n_b < 0 || !W || !dW_raw || !scale || !dW || !dscale || (n_b > 0 && (!bias || !db_raw || !db)))
         return DSW_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < dsw_rezero_param_grads_ws_bytes_impl()) return DSW_ERR_WORKSPACE;
+    DswTraceScope trace_((hipStream_t)stream, DSW_ROLE_ELEMENTWISE, n_w + n_b, 4, 0);
     return dsw_rezero_param_grads_launch(W, bias, dW_raw, db_raw, scale, dW, db, dscale, n_w, n_b, workspace, dtype,
                                          (hipStream_t)stream);
 }

@@ -40,9 +40,49 @@ static inline const char* dsw_diag_env(const char* name) { return getenv(name); 
 static inline const char* dsw_diag_env(const char*) { return nullptr; }
 #endif
 
+// Build flags of this translation unit, collected at load time (dsw_build_flags()): a library any of whose objects was
+// compiled with a diagnostics / ablation switch is refused by dsw_amd._native.load() unless it was asked for by path
+// (DSW_HIP_LIB) - a variant build is one -D away from a wrong-by-design product library.
+#define DSW_FLAG_DIAG 1
+#define DSW_FLAG_ABLATION 2
+#if defined(DSW_DIAG)
+#define DSW_TU_F_DIAG DSW_FLAG_DIAG
+#else
+#define DSW_TU_F_DIAG 0
+#endif
+#if defined(DSW_ABLATION) || defined(DSW_ABL_NODMA) || defined(DSW_ABL_NOGATHER)
+#define DSW_TU_F_ABL DSW_FLAG_ABLATION
+#else
+#define DSW_TU_F_ABL 0
+#endif
+int dsw_register_build_flags(int flags);                                            // dsw_api.hip
+namespace { const int dsw_tu_build_flags_registered = dsw_register_build_flags(DSW_TU_F_DIAG | DSW_TU_F_ABL); }
+
+// launch tracing (dsw_trace_begin / dsw_trace_end, dsw_api.hip): role 0 = start marker of an entry point
+void dsw_trace_point(hipStream_t s, int role, int64_t a0, int64_t a1, int64_t a2);
+struct DswTraceScope {   // start marker now, the role's end marker when the entry point returns
+    hipStream_t s; int role; int64_t a0, a1, a2;
+    DswTraceScope(hipStream_t s_, int role_, int64_t a0_ = 0, int64_t a1_ = 0, int64_t a2_ = 0)
+        : s(s_), role(role_), a0(a0_), a1(a1_), a2(a2_) { dsw_trace_point(s, 0, 0, 0, 0); }
+    ~DswTraceScope() { dsw_trace_point(s, role, a0, a1, a2); }
+};
+
 static inline int dsw_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? DSW_OK : DSW_ERR_LAUNCH;
+}
+
+// compute units of the current device (cached per device ordinal; 256 on a whole MI355X, fewer in partition modes)
+static inline long dsw_device_cus() {
+    static int cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        __atomic_store_n(&cached[dev], n, __ATOMIC_RELAXED);
+    }
+    return n;
 }
 
 static inline bool dsw_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

@@ -258,6 +258,7 @@ int dsw_relu_bwd(const void* dY, const void* Y, void* dYm, int64_t n, int dtype,
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     const int vec = (dsw_aligned16(dY) && dsw_aligned16(Y) && dsw_aligned16(dYm)) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
+    DswTraceScope trace_(s, DSW_ROLE_ELEMENTWISE, n, 1, 0);
     if (dtype == DSW_F32)
         hipLaunchKernelGGL((relu_kernel<false, true>), dim3(ew_blocks(n, vec ? 4 : 1)), dim3(EW_THREADS), 0, s, dY, Y, dYm, (long)n, vec);
     else
@@ -277,6 +278,7 @@ int dsw_rezero_residual_fwd(const void* c, const void* r, const void* w, void* y
     // aligned: they take the scalar path of the same kernel (the reference simply works there)
     const int vec = (dsw_aligned16(c) && dsw_aligned16(r) && dsw_aligned16(y)) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
+    DswTraceScope trace_(s, DSW_ROLE_ELEMENTWISE, n, 2, 0);
     if (dtype == DSW_F32)
         hipLaunchKernelGGL(rezero_fwd_kernel<false>, dim3(ew_blocks(n, vec ? 4 : 1)), dim3(EW_THREADS), 0, s, c, r, w, y,
                            (long)n, vec);
@@ -297,6 +299,7 @@ int dsw_rezero_residual_fwd_ld(const void* c, const void* r, const void* w, void
     const int V = dtype == DSW_BF16 ? 8 : 4;
     if (C % V != 0 || ldy % V != 0 || !dsw_aligned16(c) || !dsw_aligned16(r) || !dsw_aligned16(y)) return DSW_ERR_ALIGN;
     hipStream_t s = (hipStream_t)stream;
+    DswTraceScope trace_(s, DSW_ROLE_ELEMENTWISE, rows * C, 2, 0);
     const int cpr = (int)(C / V);
     if (dtype == DSW_F32)
         hipLaunchKernelGGL(rezero_fwd_ld_kernel<false>, dim3(ew_blocks(rows * C, V)), dim3(EW_THREADS), 0, s, c, r, w, y,
@@ -336,6 +339,7 @@ int dsw_rezero_residual_bwd(const void* g, const void* c, const void* w, void* g
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     const int vec = (dsw_aligned16(g) && dsw_aligned16(c) && (!grad_c || dsw_aligned16(grad_c))) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
+    DswTraceScope trace_(s, DSW_ROLE_ELEMENTWISE, n, 3, 0);
     float* partial = static_cast<float*>(workspace);
     const int nb = ew_blocks(n, !vec ? 1 : dtype == DSW_BF16 ? 8 : 4);
     if (dtype == DSW_F32) {

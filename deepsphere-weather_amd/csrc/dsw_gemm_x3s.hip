@@ -360,7 +360,11 @@ __global__ __launch_bounds__(64 * NWV, (PRE || NWV == 8) ? 2 : 1) void ts_gemm_x
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[nt][i]), rs, tid * 4, (nt * 16 + i) * NTH * 4, SC1);
                         acc[nt][i] = 0.f;
                     }
-                __syncthreads();   // every wave's stores have completed (s_waitcnt vmcnt(0) precedes the barrier)
+                // RELEASE: every wave drains ITS OWN stores before the barrier (the compiler emits only vmcnt(63) here - the
+                // stores are fire-and-forget for it - and a gfx950 workgroup barrier does not wait for memory operations), so
+                // the flag below cannot become visible before any byte of the piece
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
                 if (tid == 0) __hip_atomic_store(P.sk_flags + slot0 + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 finish = false;
             } else {
@@ -444,7 +448,8 @@ int launch_x3s(const TsGemmParams& P0, int col_tiles, hipStream_t stream, char* 
         return DSW_ERR_LAUNCH;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64 * NWV, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    long gx = 256L * per_cu / col_tiles;
+    const long n_cu = dsw_device_cus();      // the device the launch goes to (a partitioned / masked device has fewer than 256)
+    long gx = n_cu * per_cu / col_tiles;
     if (gx < 1) gx = 1;
     if (col_tiles > 1 && gx >= 8) gx &= ~7L;   // column tiles of one row tile on one XCD (A re-reads hit its L2)
     // Whole tiles per workgroup leave CUs idle whenever the row tiles do not divide by the workgroups (384 tiles on 256 CUs:
@@ -464,7 +469,15 @@ int launch_x3s(const TsGemmParams& P0, int col_tiles, hipStream_t stream, char* 
     const long steps_tile = steps / row_tiles;
     const long whole = (row_tiles + (gx < row_tiles ? gx : row_tiles) - 1) / (gx < row_tiles ? gx : row_tiles) * steps_tile;
     const bool pays = steps_tile >= 24 && gsk >= 2 && (whole - steps / gsk) * 5 >= whole;   // saves >= 20 % of the steps
-    const bool balanced = !(skenv && skenv[0] == '0') && sk_ws != nullptr && pays && row_tiles % gsk != 0 &&
+    // Forward progress of the balanced form: a workgroup parks the piece at the START of its range without waiting for
+    // anybody and waits, at the END of its range, only for the first pieces of the FOLLOWING workgroups that share its last
+    // tile (at most ceil(steps_tile / (steps / gsk)) of them).  Workgroups are dispatched in index order, so with other work
+    // resident on the chip (RCCL kernels, side streams) the resident set is a prefix of the grid: every member whose
+    // followers are resident finishes and frees its slot for the next index.  That argument needs room for one tile's
+    // span of workgroups; a device with very few CUs (partition modes) takes whole tiles.
+    const long span = (steps_tile + (steps / (gsk > 0 ? gsk : 1)) - 1) / ((steps / (gsk > 0 ? gsk : 1)) > 0 ? (steps / (gsk > 0 ? gsk : 1)) : 1) + 1;
+    const bool progress_ok = n_cu >= 32 && span * 4 <= n_cu * per_cu;
+    const bool balanced = !(skenv && skenv[0] == '0') && sk_ws != nullptr && pays && progress_ok && row_tiles % gsk != 0 &&
                           gsk * col_tiles <= SK_MAX_WG && sk_bytes >= SK_FLAG_BYTES + gsk * col_tiles * tile_bytes;
 #ifdef DSW_DIAG
     { static const char* tr = dsw_diag_env("DSW_X3S_TRACE");

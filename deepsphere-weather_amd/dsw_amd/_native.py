@@ -30,6 +30,9 @@ _int = ctypes.c_int
 SIGNATURES = {
     "dsw_version": (_int, []),
     "dsw_strerror": (ctypes.c_char_p, [_int]),
+    "dsw_build_flags": (_int, []),
+    "dsw_trace_begin": (_int, [_int]),
+    "dsw_trace_end": (_int, [_vp, _vp, _vp, _vp, _vp, _int]),
     "dsw_spmm_csr": (
         _int,
         [_i32p, _i32p, _f32p, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _f32, _vp, _f32, _vp, _f32, _int, _vp],
@@ -123,8 +126,50 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure
         fn.restype = res
         fn.argtypes = args
+    flags = int(lib.dsw_build_flags())
+    if flags and not os.environ.get("DSW_HIP_LIB"):
+        # a diagnostics build (environment overrides of the kernel selection) or an ablation build (kernels with phases cut
+        # out: wrong results by design) must never stand in for the product library by accident
+        raise DswNativeError(
+            f"{LIB_PATH} is a diagnostics build (dsw_build_flags() = {flags}: bit 0 DSW_DIAG, bit 1 ablation switches); "
+            "rebuild the product library (`python -m dsw_amd.build --force`) or name the variant explicitly with DSW_HIP_LIB")
     _lib = lib
     return lib
+
+
+ROLE_NAMES = {1: "spmm", 2: "spmm2", 3: "spmm_staged", 4: "basis_fwd", 5: "basis_adj", 6: "mix_fwd", 7: "fwd_one_launch",
+              8: "bwd_gemm_fused", 9: "bwd_dgrad", 10: "bwd_wgrad", 11: "zmix", 12: "clenshaw_fwd", 13: "elementwise",
+              14: "bwd_fused", 15: "basis_dual"}
+
+
+class LaunchTrace:
+    """``with LaunchTrace(capacity) as tr: ...steps...`` then ``tr.intervals``: list of (role name, aux0, aux1, aux2, us) for
+    every role the entry points executed on the way (``dsw_trace_begin`` / ``dsw_trace_end``), timed by HIP events on the
+    launch stream inside the running step."""
+
+    def __init__(self, capacity=65536):
+        self.capacity = int(capacity)
+        self.intervals = []
+
+    def __enter__(self):
+        check(load().dsw_trace_begin(self.capacity), "dsw_trace_begin")
+        return self
+
+    def __exit__(self, *exc):
+        import numpy as np
+
+        cap = self.capacity
+        roles, a0, a1, a2 = (np.zeros(cap, dtype=np.int32) for _ in range(4))
+        us = np.zeros(cap, dtype=np.float32)
+        n = int(load().dsw_trace_end(roles.ctypes.data, a0.ctypes.data, a1.ctypes.data, a2.ctypes.data, us.ctypes.data, cap))
+        if n < 0:
+            if exc[0] is None:
+                check(n, "dsw_trace_end")
+            return False
+        n = min(n, cap)
+        self.intervals = [(ROLE_NAMES.get(int(roles[i]), str(int(roles[i]))), int(a0[i]), int(a1[i]), int(a2[i]), float(us[i]))
+                          for i in range(n)]
+        return False
 
 
 def check(rc: int, what: str):

@@ -458,20 +458,27 @@ class _HipBackend:
         _native.check(rc, "dsw_cheb_bwd_res")
         return dx, dw, db
 
-    # (device, stream) -> the (zero-initialised, self-re-arming) ticket + partials workspace of dsw_rezero_param_grads.
+    # (device, stream handle) -> the (zero-initialised, self-re-arming) ticket + partials workspace of dsw_rezero_param_grads.
     # One per STREAM: calls sharing a workspace must be stream-ordered (include/dsw_hip.h), and backward branches may run on
-    # side streams (GradBucket's overlap mode, forked residual branches) - a per-device workspace raced there.
+    # side streams (GradBucket's overlap mode, forked residual branches, the capture stream of a HIP graph).  A recycled
+    # handle inherits the previous stream's workspace, which is sound: the kernel re-arms the ticket at the end of every call,
+    # so a workspace is only ever left half-armed by an aborted kernel (a device fault ends the process).  The cache is
+    # BOUNDED (least recently used entry dropped beyond _RPG_WS_MAX; torch's stream pool has 32 streams per device), so
+    # short-lived streams cannot leak workspaces without limit.
     _rpg_ws = {}
+    _RPG_WS_MAX = 64
 
     def rezero_param_grads(self, w, bias, dw_raw, db_raw, scale):
         lib = _native.load()
         ds = torch.empty_like(scale)
         nb = 0 if bias is None else bias.numel()
         key = (w.device, _stream(w))
-        ws = self._rpg_ws.get(key)
+        ws = self._rpg_ws.pop(key, None)
         if ws is None:
-            ws = self._rpg_ws[key] = torch.zeros(int(lib.dsw_rezero_param_grads_workspace_bytes()), dtype=torch.uint8,
-                                                 device=w.device)
+            ws = torch.zeros(int(lib.dsw_rezero_param_grads_workspace_bytes()), dtype=torch.uint8, device=w.device)
+            while len(self._rpg_ws) >= self._RPG_WS_MAX:
+                self._rpg_ws.pop(next(iter(self._rpg_ws)))
+        self._rpg_ws[key] = ws          # (re-)inserted last: dict order = recency
         with torch.cuda.device(w.device):
             rc = lib.dsw_rezero_param_grads(w.data_ptr(), _ptr(bias), dw_raw.data_ptr(), _ptr(db_raw) if nb else None,
                                             scale.data_ptr(), dw_raw.data_ptr(), _ptr(db_raw) if nb else None, ds.data_ptr(),

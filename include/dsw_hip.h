@@ -73,6 +73,39 @@ int dsw_version(void);
 /* Text for an error code. */
 const char* dsw_strerror(int code);
 
+/* Diagnostics switches the library's objects were compiled with: 0 for the product build; bit 0 = -DDSW_DIAG (environment
+ * overrides of the kernel selection), bit 1 = an ablation switch (-DDSW_ABLATION, -DDSW_ABL_*: wrong results by design).
+ * dsw_amd/_native.py refuses a flagged library unless it was asked for by path (DSW_HIP_LIB). */
+int dsw_build_flags(void);
+
+/* Launch tracing: per-role durations of the launches the entry points make, from HIP events recorded on the launch stream
+ * at the role boundaries (start of an entry point, end of each of its roles).  A benchmark opens a trace, runs steps the
+ * ordinary way (eagerly: nothing is recorded inside a stream capture) and reads the intervals back - every role timed
+ * INSIDE the step, with the caches in the state the step leaves them, which back-to-back calls of one kernel are not
+ * (isolated timings were 11-14 % off the in-step durations).  One trace at a time, process-wide.
+ *   dsw_trace_begin(capacity)  allocates `capacity` events (an entry point uses 2-4) and starts recording.
+ *   dsw_trace_end(...)         waits for the recorded events, writes up to `cap` intervals (role, three role-specific
+ *                              integers, microseconds) in recording order and returns the number of intervals (> cap:
+ *                              truncated), DSW_ERR_WORKSPACE if the event capacity overflowed, another error code on failure.
+ * aux: conv roles (V, Fin, Fout) [recurrences: (V, C, K)], SPMM roles (rows_out, rows_in, C), elementwise (n, kind, 0). */
+#define DSW_ROLE_SPMM 1            /* dsw_spmm_csr / dsw_spmm_csr_ld: one product (interpolation pooling and its transpose) */
+#define DSW_ROLE_SPMM2 2           /* dsw_spmm2_fused called directly */
+#define DSW_ROLE_SPMM_STAGED 3     /* dsw_spmm_staged called directly */
+#define DSW_ROLE_BASIS_FWD 4       /* forward recurrence launches (T_1 .. T_{K-1}) */
+#define DSW_ROLE_BASIS_ADJ 5       /* adjoint recurrence launches (dgrad planes -> dX) */
+#define DSW_ROLE_MIX_FWD 6         /* channel-mix GEMM of the forward */
+#define DSW_ROLE_FWD_ONE_LAUNCH 7  /* whole forward (hops + channel mix + bias) in one launch */
+#define DSW_ROLE_BWD_GEMM_FUSED 8  /* dW partials + db + dgrad planes in one pass over dY, + the partial reduce */
+#define DSW_ROLE_BWD_DGRAD 9       /* dgrad GEMM (planes G_k, or dX of a mix-first layer) */
+#define DSW_ROLE_BWD_WGRAD 10      /* dW / db (+ reduce) */
+#define DSW_ROLE_ZMIX 11           /* mix-first forward: plane GEMM Z_k = X W_k */
+#define DSW_ROLE_CLENSHAW_FWD 12   /* mix-first forward: Clenshaw recurrence on the output channels */
+#define DSW_ROLE_ELEMENTWISE 13    /* relu mask (kind 1), ReZero residual forward (2) / backward (3), ReZero parameter gradients (4) */
+#define DSW_ROLE_BWD_FUSED 14      /* dgrad + adjoint recurrence in one launch (dY -> dX) */
+#define DSW_ROLE_BASIS_DUAL 15     /* mix-first backward: Chebyshev basis of dY under L^T (on the output channels) */
+int dsw_trace_begin(int capacity);
+int dsw_trace_end(int32_t* roles, int32_t* aux0, int32_t* aux1, int32_t* aux2, float* us, int cap);
+
 /* Sparse operator times node-major activations with a fused axpby epilogue, per sample:
  *     Y[b,r,:] = alpha * sum_p vals[p] * X[b,colind[p],:] + beta * Z[b,r,:] + gamma * Z2[b,r,:]
  * X: [B, v_in, C]; Y, Z, Z2: [B, v_out, C]; Z / Z2 may be NULL; Y may alias Z or Z2 (not X).
