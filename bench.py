@@ -175,11 +175,12 @@ def _traffic(traffic_key, leg):
         return None
 
 
-def trace_steps(step_fn, n_steps, warm=5, capacity=1 << 16):
-    """Per-role durations INSIDE running steps: HIP events recorded by the library on the launch stream at the role
-    boundaries of its entry points (include/dsw_hip.h: dsw_trace_begin / dsw_trace_end) while `step_fn` - the very step the
-    timed region replays - runs eagerly, back to back.  Every kernel is timed in the cache state the step leaves it, which
-    isolated back-to-back calls of one kernel are not.  Returns {(role, aux0, aux1, aux2): {calls_per_step, avg_us,
+def trace_steps(step_fn, n_steps, warm=5, capacity=1 << 15):
+    """Per-role KERNEL durations inside running steps (include/dsw_hip.h: dsw_trace_begin / dsw_trace_end): while `step_fn`
+    - the very step the timed region replays - runs eagerly, back to back, the library launches each of its kernels with a
+    start / stop event pair attached to the dispatch (the timestamps a profiler's kernel trace reports; nothing extra on the
+    stream) and notes which role of which entry point the kernel belongs to.  Every kernel is timed in the cache state the
+    step leaves it, which isolated back-to-back calls of one kernel are not.  Returns {(role, aux0, aux1, aux2): {calls_per_step, avg_us,
     median_us, us_per_step}}."""
     from dsw_amd import _native
 
@@ -191,13 +192,16 @@ def trace_steps(step_fn, n_steps, warm=5, capacity=1 << 16):
             step_fn()
         torch.cuda.synchronize()
     agg = {}
-    for role, a0, a1, a2, us in tr.intervals:
-        agg.setdefault((role, a0, a1, a2), []).append(us)
+    for (role, a0, a1, a2, us), (span, nk, name) in zip(tr.intervals, tr.detail):
+        e = agg.setdefault((role, a0, a1, a2), {"us": [], "span": [], "nk": nk, "name": name})
+        e["us"].append(us)
+        e["span"].append(span)
     out = {}
-    for k, v in agg.items():
-        v.sort()
+    for k, e in agg.items():
+        v = sorted(e["us"])
         out[k] = {"calls_per_step": len(v) / n_steps, "avg_us": sum(v) / len(v), "median_us": v[len(v) // 2],
-                  "us_per_step": sum(v) / n_steps}
+                  "us_per_step": sum(v) / n_steps, "span_avg_us": sum(e["span"]) / len(v), "kernels": e["nk"],
+                  "longest_kernel": e["name"]}
     return out
 
 
@@ -307,7 +311,7 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
     def entry(role, kernels, sec, nbytes, calls, extra=None):
         d = {"role": role, "kernels": kernels, "avg_us": round(sec * 1e6, 2), "calls_per_step": calls,
              "algorithmic_bytes": int(nbytes), "achieved_GBs": round(nbytes / sec / 1e9, 1),
-             "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4), "timing": "in-step HIP events (dsw_trace)"}
+             "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4), "timing": "in-step kernel durations (dsw_trace)"}
         d.update(extra or {})
         return d
 
@@ -386,7 +390,7 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
                 "bytes_moved": None if m is None else int(m["hbm_bytes_per_call"]),
                 "frac_counter": None if m is None else round(m["hbm_bytes_per_call"] / sec / 1e9 / HBM_PEAK_GBS, 4)}
 
-    IN, ISO = "in-step HIP events (dsw_trace)", "ISOLATED leg: median of 3 regions of %d back-to-back calls" % steps
+    IN, ISO = "in-step kernel durations (dsw_trace: start / stop events attached to each dispatch)", "ISOLATED leg: median of 3 regions of %d back-to-back calls" % steps
     out = {
         "bound": "hbm",
         "kernel": ("SpMM recurrence launches of a timed step: " +
@@ -472,7 +476,7 @@ def pooling_leg(model, run_forward, steps, traffic_key=None, pmc_leg=None, trace
             # in-step: the product timed inside the running step (products of equal shape - a pooling and the transposed
             # unpooling of the same level - share one entry of the trace: their mean)
             sec = hit["avg_us"] * 1e-6
-            e["timing"] = "in-step HIP events (dsw_trace), mean over the step's products of this shape"
+            e["timing"] = "in-step kernel durations (dsw_trace), mean over the step's products of this shape"
         else:
             for _ in range(3):
                 F_.sparse_remap(o, t)
@@ -538,7 +542,7 @@ def mfma_leg(layer, x, T, steps, in_step=None):
     how = "ISOLATED leg (the step does not launch the stand-alone channel mix for this layer): %d back-to-back calls" % steps
     if in_step is not None:      # the step launches this GEMM: its in-step duration
         avg_s = in_step["avg_us"] * 1e-6
-        how = "in-step HIP events (dsw_trace)"
+        how = "in-step kernel durations (dsw_trace)"
     flops = 2.0 * N * Fin * K * Fout
     peak = MFMA_PEAK_TFLOPS["bf16" if bf16 else "f32"]
     ach = flops / avg_s / 1e12
@@ -1108,7 +1112,8 @@ def main():
                     "what": "every role the library's entry points ran in one step (eager, back to back), us per step",
                     "sum_us": round(tot, 1), "vs_ms_per_step": round(tot / (ms * 1e3), 4),
                     "roles": sorted(({"role": k[0], "aux": list(k[1:]), "calls_per_step": round(v["calls_per_step"], 2),
-                                      "avg_us": round(v["avg_us"], 2), "us_per_step": round(v["us_per_step"], 2)}
+                                      "avg_us": round(v["avg_us"], 2), "us_per_step": round(v["us_per_step"], 2),
+                                      "kernels": v["kernels"], "longest_kernel": v["longest_kernel"]}
                                      for k, v in traced.items()), key=lambda d: -d["us_per_step"])[:24]}
             if args.workload in ("unet", "c5"):
                 out["roofline"]["pooling"] = pooling_leg(model, lambda: model(x.detach()), max(10, args.steps), traffic_key=tkey,

@@ -6,40 +6,51 @@
 #include <mutex>
 #include <vector>
 
-// ---- launch tracing (dsw_trace_begin / dsw_trace_end): HIP events on the launch stream at the ROLE boundaries of the entry
-// points - forward launch, backward GEMM pass, adjoint recurrence, a pooling product ... - so that a benchmark can time each
-// role INSIDE a running step (the caches in the state the step leaves them) instead of in isolated back-to-back calls.
-// Off (one relaxed atomic load per entry point) unless a trace is open.
+// ---- launch tracing (dsw_trace_begin / dsw_trace_end; mechanism: dsw_common.h) ----------------------------------------
 namespace {
+struct DswTraceRec {
+    int role;                 // -1: a kernel launch; 0: start of an entry point; > 0: end of that role
+    int a0, a1, a2;
+    const char* name;         // kernel launches: the kernel expression of the launch site (static string)
+    hipEvent_t e0, e1;
+};
 struct DswTrace {
     std::mutex mu;
     std::atomic<bool> on{false};
-    std::vector<hipEvent_t> ev;
-    std::vector<int> role, a0, a1, a2;
-    int n = 0;
+    std::vector<hipEvent_t> ev;      // pool: two per kernel launch
+    std::vector<DswTraceRec> rec;
+    size_t n_ev = 0;
     bool overflow = false;
 };
 DswTrace g_trace;
 std::atomic<int> g_build_flags{0};
 
+static bool capturing(hipStream_t s) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); return true; }
+    return cs != hipStreamCaptureStatusNone;
+}
 static void trace_event(hipStream_t s, int role, int64_t a0, int64_t a1, int64_t a2) {
     if (!g_trace.on.load(std::memory_order_relaxed)) return;
     std::lock_guard<std::mutex> lk(g_trace.mu);
-    if (!g_trace.on.load(std::memory_order_relaxed)) return;
-    if (g_trace.n >= (int)g_trace.ev.size()) { g_trace.overflow = true; return; }
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        return;      // never inside a graph capture
-    }
-    if (hipEventRecord(g_trace.ev[g_trace.n], s) != hipSuccess) { (void)hipGetLastError(); return; }
-    g_trace.role[g_trace.n] = role; g_trace.a0[g_trace.n] = (int)a0; g_trace.a1[g_trace.n] = (int)a1; g_trace.a2[g_trace.n] = (int)a2;
-    ++g_trace.n;
+    if (!g_trace.on.load(std::memory_order_relaxed) || capturing(s)) return;
+    g_trace.rec.push_back(DswTraceRec{role, (int)a0, (int)a1, (int)a2, nullptr, nullptr, nullptr});
 }
-// start marker of an entry point (role 0: closes nothing) / end of a role (closes the interval since the previous event)
+// start marker of an entry point (role 0: closes nothing) / end of a role (owns the kernels since the previous marker)
 static inline void trace_start(dsw_stream_t s) { trace_event((hipStream_t)s, 0, 0, 0, 0); }
 static inline void trace_mark(dsw_stream_t s, int role, int64_t a0 = 0, int64_t a1 = 0, int64_t a2 = 0) { trace_event((hipStream_t)s, role, a0, a1, a2); }
 }  // namespace
+
+bool dsw_trace_kernel(const char* name, hipStream_t s, hipEvent_t* e0, hipEvent_t* e1) {
+    if (!g_trace.on.load(std::memory_order_relaxed)) return false;
+    std::lock_guard<std::mutex> lk(g_trace.mu);
+    if (!g_trace.on.load(std::memory_order_relaxed) || capturing(s)) return false;
+    if (g_trace.n_ev + 2 > g_trace.ev.size()) { g_trace.overflow = true; return false; }
+    *e0 = g_trace.ev[g_trace.n_ev++];
+    *e1 = g_trace.ev[g_trace.n_ev++];
+    g_trace.rec.push_back(DswTraceRec{-1, 0, 0, 0, name, *e0, *e1});
+    return true;
+}
 
 void dsw_trace_point(hipStream_t s, int role, int64_t a0, int64_t a1, int64_t a2) { trace_event(s, role, a0, a1, a2); }
 
@@ -53,7 +64,10 @@ int dsw_register_build_flags(int flags) {
 int dsw_spmm_launch_ld(const int* rowptr, const int* colind, const float* vals, int64_t v_out, int64_t v_in,
                        const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t B, int64_t C, float alpha, const void* Z,
                        float beta, const void* Z2, float gamma, int dtype, hipStream_t stream, int hints = 0,
-                       int64_t ldz = 0);
+                       int64_t ldz = 0, const int* long_list = nullptr, int n_long = 0, int long_thr = 0);
+int dsw_remap_launch(const dsw_remap_plan* plan, const int* rowptr, const int* colind, const float* vals, int64_t v_out,
+                     int64_t v_in, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t B, int64_t C, const void* Z,
+                     int64_t ldz, float beta, int dtype, hipStream_t stream);
 int dsw_spmm_launch(const int* rowptr, const int* colind, const float* vals, int64_t v_out, int64_t v_in,
                     const void* X, void* Y, int64_t B, int64_t C, float alpha, const void* Z, float beta,
                     const void* Z2, float gamma, int dtype, hipStream_t stream, int hints = 0);
@@ -157,43 +171,69 @@ int dsw_trace_begin(int capacity) {
     if (capacity <= 0 || capacity > (1 << 20)) return DSW_ERR_BAD_ARG;
     std::lock_guard<std::mutex> lk(g_trace.mu);
     if (g_trace.on.load()) return DSW_ERR_BAD_ARG;          // one trace at a time
-    g_trace.ev.assign((size_t)capacity, nullptr);
-    for (int i = 0; i < capacity; ++i)
+    g_trace.ev.assign((size_t)capacity * 2, nullptr);
+    for (size_t i = 0; i < g_trace.ev.size(); ++i)
         if (hipEventCreate(&g_trace.ev[i]) != hipSuccess) {
-            for (int j = 0; j < i; ++j) (void)hipEventDestroy(g_trace.ev[j]);
+            for (size_t j = 0; j < i; ++j) (void)hipEventDestroy(g_trace.ev[j]);
             g_trace.ev.clear();
             return DSW_ERR_LAUNCH;
         }
-    g_trace.role.assign((size_t)capacity, 0); g_trace.a0.assign((size_t)capacity, 0); g_trace.a1.assign((size_t)capacity, 0);
-    g_trace.a2.assign((size_t)capacity, 0);
-    g_trace.n = 0; g_trace.overflow = false;
+    g_trace.rec.clear();
+    g_trace.rec.reserve((size_t)capacity * 2);
+    g_trace.n_ev = 0; g_trace.overflow = false;
     g_trace.on.store(true);
     return DSW_OK;
 }
 
-int dsw_trace_end(int32_t* roles, int32_t* aux0, int32_t* aux1, int32_t* aux2, float* us, int cap) {
+int dsw_trace_end(int32_t* roles, int32_t* aux0, int32_t* aux1, int32_t* aux2, float* us, float* span_us, int32_t* n_kernels,
+                  char* names, int name_stride, int cap) {
     std::lock_guard<std::mutex> lk(g_trace.mu);
     if (!g_trace.on.load()) return DSW_ERR_BAD_ARG;
     g_trace.on.store(false);
     int out = 0, rc = DSW_OK;
-    for (int i = 0; i < g_trace.n; ++i) {
-        if (hipEventSynchronize(g_trace.ev[i]) != hipSuccess) { rc = DSW_ERR_LAUNCH; break; }
-        if (g_trace.role[i] == 0 || i == 0) continue;
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, g_trace.ev[i - 1], g_trace.ev[i]) != hipSuccess) { rc = DSW_ERR_LAUNCH; break; }
-        if (out < cap && roles && us) {
-            roles[out] = g_trace.role[i];
-            if (aux0) aux0[out] = g_trace.a0[i];
-            if (aux1) aux1[out] = g_trace.a1[i];
-            if (aux2) aux2[out] = g_trace.a2[i];
-            us[out] = ms * 1000.f;
+    // kernels between two markers belong to the role of the closing marker; kernels launched outside every entry point's
+    // markers (none today) are dropped at the next start marker
+    double sum_ms = 0.0;
+    int nk = 0;
+    float longest = -1.f;
+    const char* longest_name = nullptr;
+    hipEvent_t first = nullptr, last = nullptr;
+    for (const DswTraceRec& r : g_trace.rec) {
+        if (rc != DSW_OK) break;
+        if (r.role == -1) {
+            float ms = 0.f;
+            if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { rc = DSW_ERR_LAUNCH; break; }
+            sum_ms += ms; ++nk;
+            if (ms > longest) { longest = ms; longest_name = r.name; }
+            if (!first) first = r.e0;
+            last = r.e1;
+            continue;
         }
-        ++out;
+        if (r.role > 0 && nk > 0) {
+            float span = 0.f;
+            if (hipEventElapsedTime(&span, first, last) != hipSuccess) { rc = DSW_ERR_LAUNCH; break; }
+            if (out < cap && roles && us) {
+                roles[out] = r.role;
+                if (aux0) aux0[out] = r.a0;
+                if (aux1) aux1[out] = r.a1;
+                if (aux2) aux2[out] = r.a2;
+                us[out] = (float)(sum_ms * 1000.0);
+                if (span_us) span_us[out] = span * 1000.f;
+                if (n_kernels) n_kernels[out] = nk;
+                if (names && name_stride > 1) {
+                    int i = 0;
+                    for (; longest_name && longest_name[i] && i < name_stride - 1; ++i) names[(size_t)out * name_stride + i] = longest_name[i];
+                    names[(size_t)out * name_stride + i] = 0;
+                }
+            }
+            ++out;
+        }
+        sum_ms = 0.0; nk = 0; longest = -1.f; longest_name = nullptr; first = last = nullptr;
     }
     for (hipEvent_t e : g_trace.ev) (void)hipEventDestroy(e);
-    g_trace.ev.clear(); g_trace.role.clear(); g_trace.a0.clear(); g_trace.a1.clear(); g_trace.a2.clear();
+    g_trace.ev.clear(); g_trace.rec.clear();
     const bool ovf = g_trace.overflow;
-    g_trace.n = 0;
+    g_trace.n_ev = 0;
     if (rc != DSW_OK) { (void)hipGetLastError(); return rc; }
     return ovf ? DSW_ERR_WORKSPACE : out;
 }
@@ -234,6 +274,27 @@ int dsw_spmm_csr_ld(const int32_t* rowptr, const int32_t* colind, const float* v
     trace_start(stream);
     const int rc = dsw_spmm_launch_ld(rowptr, colind, vals, v_out, v_in, X, ldx, Y, ldy, B, C, alpha, Z, beta, Z2, gamma, dtype,
                                       (hipStream_t)stream, 0, Z ? ldz : C);
+    trace_mark(stream, DSW_ROLE_SPMM, v_out, v_in, C);
+    return rc;
+}
+
+int dsw_remap_csr(const dsw_remap_plan* plan, const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t v_out,
+                  int64_t v_in, int64_t nnz, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t B, int64_t C,
+                  const void* Z, int64_t ldz, float beta, int dtype, dsw_stream_t stream) {
+    if (v_out < 0 || v_in < 0 || nnz < 0 || B < 0 || C < 0 || ldx < C || ldy < C || (Z && ldz < C)) return DSW_ERR_BAD_ARG;
+    if (v_out == 0 || B == 0 || C == 0) return DSW_OK;
+    if (!rowptr || !X || !Y || (nnz > 0 && (!colind || !vals))) return DSW_ERR_BAD_ARG;
+    if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
+    if (plan != nullptr) {
+        if (plan->kind < 0 || plan->kind > 2) return DSW_ERR_BAD_ARG;
+        // a regular plan certifies the STRUCTURE of this very matrix: shapes that cannot have it are refused, not reinterpreted
+        if (plan->kind == 1 && (plan->m < 1 || v_in != v_out * plan->m || nnz != v_in)) return DSW_ERR_BAD_ARG;
+        if (plan->kind == 2 && (plan->m < 1 || v_out != v_in * plan->m || nnz != v_out)) return DSW_ERR_BAD_ARG;
+        if (plan->kind == 0 && plan->n_long > 0 && (!plan->long_rows || plan->long_thr <= 0)) return DSW_ERR_BAD_ARG;
+    }
+    trace_start(stream);
+    const int rc = dsw_remap_launch(plan, rowptr, colind, vals, v_out, v_in, X, ldx, Y, ldy, B, C, Z, Z ? ldz : C, beta, dtype,
+                                    (hipStream_t)stream);
     trace_mark(stream, DSW_ROLE_SPMM, v_out, v_in, C);
     return rc;
 }

@@ -1,6 +1,7 @@
 // Shared device helpers for the dsw HIP library (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #define DSW_VERSION 100  // 0.1.0
@@ -58,8 +59,21 @@ static inline const char* dsw_diag_env(const char*) { return nullptr; }
 int dsw_register_build_flags(int flags);                                            // dsw_api.hip
 namespace { const int dsw_tu_build_flags_registered = dsw_register_build_flags(DSW_TU_F_DIAG | DSW_TU_F_ABL); }
 
-// launch tracing (dsw_trace_begin / dsw_trace_end, dsw_api.hip): role 0 = start marker of an entry point
-void dsw_trace_point(hipStream_t s, int role, int64_t a0, int64_t a1, int64_t a2);
+// Launch tracing (dsw_trace_begin / dsw_trace_end, dsw_api.hip).  While a trace is open every kernel of the library is
+// launched with a start / stop event pair ATTACHED TO ITS DISPATCH (hipExtLaunchKernelGGL: the timestamps of the kernel's own
+// completion signal - no marker packets between the kernels, so the launch sequence runs as it does without the trace), and
+// the entry points drop role markers (host-side sequence points, nothing on the stream) that say which role the kernels
+// since the previous marker belong to.  Off: one relaxed atomic load per launch.
+bool dsw_trace_kernel(const char* name, hipStream_t s, hipEvent_t* e0, hipEvent_t* e1);
+void dsw_trace_point(hipStream_t s, int role, int64_t a0, int64_t a1, int64_t a2);     // role 0 = start of an entry point
+#define DSW_LAUNCH(kern, grid, block, lds, stream, ...)                                                 \
+    do {                                                                                                  \
+        hipEvent_t dsw_e0_ = nullptr, dsw_e1_ = nullptr;                                                  \
+        if (dsw_trace_kernel(#kern, (stream), &dsw_e0_, &dsw_e1_))                                        \
+            hipExtLaunchKernelGGL(kern, grid, block, lds, stream, dsw_e0_, dsw_e1_, 0, __VA_ARGS__);      \
+        else                                                                                              \
+            hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                              \
+    } while (0)
 struct DswTraceScope {   // start marker now, the role's end marker when the entry point returns
     hipStream_t s; int role; int64_t a0, a1, a2;
     DswTraceScope(hipStream_t s_, int role_, int64_t a0_ = 0, int64_t a1_ = 0, int64_t a2_ = 0)

@@ -234,8 +234,8 @@ int dsw_fold_w_launch(const void* W, void* Wf, int64_t Fin, int64_t Fout, int64_
     if (K < 3 || !W || !Wf) return DSW_ERR_BAD_ARG;
     const int64_t n = Fin * K * Fout;
     const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    if (dtype == DSW_BF16) hipLaunchKernelGGL(fold_w_kernel<true>, dim3(blocks), dim3(256), 0, s, W, Wf, (int)Fin, (int)K, (int)Fout);
-    else hipLaunchKernelGGL(fold_w_kernel<false>, dim3(blocks), dim3(256), 0, s, W, Wf, (int)Fin, (int)K, (int)Fout);
+    if (dtype == DSW_BF16) DSW_LAUNCH(fold_w_kernel<true>, dim3(blocks), dim3(256), 0, s, W, Wf, (int)Fin, (int)K, (int)Fout);
+    else DSW_LAUNCH(fold_w_kernel<false>, dim3(blocks), dim3(256), 0, s, W, Wf, (int)Fin, (int)K, (int)Fout);
     return dsw_check_launch();
 }
 
@@ -243,9 +243,9 @@ int dsw_relu_inplace_launch(void* y, int64_t n, int dtype, hipStream_t s) {
     if (n <= 0) return DSW_OK;
     const int vec = dsw_aligned16(y) ? 1 : 0;
     if (dtype == DSW_F32)
-        hipLaunchKernelGGL((relu_kernel<false, false>), dim3(ew_blocks(n, vec ? 4 : 1)), dim3(EW_THREADS), 0, s, nullptr, y, y, (long)n, vec);
+        DSW_LAUNCH((relu_kernel<false, false>), dim3(ew_blocks(n, vec ? 4 : 1)), dim3(EW_THREADS), 0, s, nullptr, y, y, (long)n, vec);
     else
-        hipLaunchKernelGGL((relu_kernel<true, false>), dim3(ew_blocks(n, vec ? 8 : 1)), dim3(EW_THREADS), 0, s, nullptr, y, y, (long)n, vec);
+        DSW_LAUNCH((relu_kernel<true, false>), dim3(ew_blocks(n, vec ? 8 : 1)), dim3(EW_THREADS), 0, s, nullptr, y, y, (long)n, vec);
     return dsw_check_launch();
 }
 
@@ -260,9 +260,9 @@ int dsw_relu_bwd(const void* dY, const void* Y, void* dYm, int64_t n, int dtype,
     hipStream_t s = (hipStream_t)stream;
     DswTraceScope trace_(s, DSW_ROLE_ELEMENTWISE, n, 1, 0);
     if (dtype == DSW_F32)
-        hipLaunchKernelGGL((relu_kernel<false, true>), dim3(ew_blocks(n, vec ? 4 : 1)), dim3(EW_THREADS), 0, s, dY, Y, dYm, (long)n, vec);
+        DSW_LAUNCH((relu_kernel<false, true>), dim3(ew_blocks(n, vec ? 4 : 1)), dim3(EW_THREADS), 0, s, dY, Y, dYm, (long)n, vec);
     else
-        hipLaunchKernelGGL((relu_kernel<true, true>), dim3(ew_blocks(n, vec ? 8 : 1)), dim3(EW_THREADS), 0, s, dY, Y, dYm, (long)n, vec);
+        DSW_LAUNCH((relu_kernel<true, true>), dim3(ew_blocks(n, vec ? 8 : 1)), dim3(EW_THREADS), 0, s, dY, Y, dYm, (long)n, vec);
     return dsw_check_launch();
 }
 
@@ -280,10 +280,10 @@ int dsw_rezero_residual_fwd(const void* c, const void* r, const void* w, void* y
     hipStream_t s = (hipStream_t)stream;
     DswTraceScope trace_(s, DSW_ROLE_ELEMENTWISE, n, 2, 0);
     if (dtype == DSW_F32)
-        hipLaunchKernelGGL(rezero_fwd_kernel<false>, dim3(ew_blocks(n, vec ? 4 : 1)), dim3(EW_THREADS), 0, s, c, r, w, y,
+        DSW_LAUNCH(rezero_fwd_kernel<false>, dim3(ew_blocks(n, vec ? 4 : 1)), dim3(EW_THREADS), 0, s, c, r, w, y,
                            (long)n, vec);
     else if (dtype == DSW_BF16)
-        hipLaunchKernelGGL(rezero_fwd_kernel<true>, dim3(ew_blocks(n, vec ? 8 : 1)), dim3(EW_THREADS), 0, s, c, r, w, y,
+        DSW_LAUNCH(rezero_fwd_kernel<true>, dim3(ew_blocks(n, vec ? 8 : 1)), dim3(EW_THREADS), 0, s, c, r, w, y,
                            (long)n, vec);
     else
         return DSW_ERR_BAD_DTYPE;
@@ -302,10 +302,10 @@ int dsw_rezero_residual_fwd_ld(const void* c, const void* r, const void* w, void
     DswTraceScope trace_(s, DSW_ROLE_ELEMENTWISE, rows * C, 2, 0);
     const int cpr = (int)(C / V);
     if (dtype == DSW_F32)
-        hipLaunchKernelGGL(rezero_fwd_ld_kernel<false>, dim3(ew_blocks(rows * C, V)), dim3(EW_THREADS), 0, s, c, r, w, y,
+        DSW_LAUNCH(rezero_fwd_ld_kernel<false>, dim3(ew_blocks(rows * C, V)), dim3(EW_THREADS), 0, s, c, r, w, y,
                            (long)rows, cpr, (long)ldy);
     else
-        hipLaunchKernelGGL(rezero_fwd_ld_kernel<true>, dim3(ew_blocks(rows * C, V)), dim3(EW_THREADS), 0, s, c, r, w, y,
+        DSW_LAUNCH(rezero_fwd_ld_kernel<true>, dim3(ew_blocks(rows * C, V)), dim3(EW_THREADS), 0, s, c, r, w, y,
                            (long)rows, cpr, (long)ldy);
     return dsw_check_launch();
 }
@@ -320,10 +320,10 @@ int dsw_rezero_param_grads_launch(const void* W, const void* bias, const void* d
     nb = nb < 1 ? 1 : (nb > RPG_BLOCKS ? RPG_BLOCKS : nb);
     float* ws = static_cast<float*>(workspace);
     if (dtype == DSW_F32)
-        hipLaunchKernelGGL(rezero_param_grads_kernel<false>, dim3(nb), dim3(256), 0, stream, W, bias, dW_raw, db_raw, scale, dW,
+        DSW_LAUNCH(rezero_param_grads_kernel<false>, dim3(nb), dim3(256), 0, stream, W, bias, dW_raw, db_raw, scale, dW,
                            db, dscale, (long)n_w, (long)n_b, ws);
     else
-        hipLaunchKernelGGL(rezero_param_grads_kernel<true>, dim3(nb), dim3(256), 0, stream, W, bias, dW_raw, db_raw, scale, dW,
+        DSW_LAUNCH(rezero_param_grads_kernel<true>, dim3(nb), dim3(256), 0, stream, W, bias, dW_raw, db_raw, scale, dW,
                            db, dscale, (long)n_w, (long)n_b, ws);
     return dsw_check_launch();
 }
@@ -343,11 +343,11 @@ int dsw_rezero_residual_bwd(const void* g, const void* c, const void* w, void* g
     float* partial = static_cast<float*>(workspace);
     const int nb = ew_blocks(n, !vec ? 1 : dtype == DSW_BF16 ? 8 : 4);
     if (dtype == DSW_F32) {
-        hipLaunchKernelGGL(rezero_bwd_kernel<false>, dim3(nb), dim3(EW_THREADS), 0, s, g, c, w, grad_c, partial, (long)n, vec);
-        hipLaunchKernelGGL(rezero_bwd_final_kernel<false>, dim3(1), dim3(256), 0, s, partial, nb, grad_w);
+        DSW_LAUNCH(rezero_bwd_kernel<false>, dim3(nb), dim3(EW_THREADS), 0, s, g, c, w, grad_c, partial, (long)n, vec);
+        DSW_LAUNCH(rezero_bwd_final_kernel<false>, dim3(1), dim3(256), 0, s, partial, nb, grad_w);
     } else {
-        hipLaunchKernelGGL(rezero_bwd_kernel<true>, dim3(nb), dim3(EW_THREADS), 0, s, g, c, w, grad_c, partial, (long)n, vec);
-        hipLaunchKernelGGL(rezero_bwd_final_kernel<true>, dim3(1), dim3(256), 0, s, partial, nb, grad_w);
+        DSW_LAUNCH(rezero_bwd_kernel<true>, dim3(nb), dim3(EW_THREADS), 0, s, g, c, w, grad_c, partial, (long)n, vec);
+        DSW_LAUNCH(rezero_bwd_final_kernel<true>, dim3(1), dim3(256), 0, s, partial, nb, grad_w);
     }
     return dsw_check_launch();
 }

@@ -356,7 +356,7 @@ int launch_ncb(const Fwd3Args& A, long nwg, size_t lds, hipStream_t stream) {
         if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)cheb3_fwd_fused_kernel<NST, NS1, N_, FULL>,             \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
             return DSW_ERR_LAUNCH;                                                                                      \
-        hipLaunchKernelGGL((cheb3_fwd_fused_kernel<NST, NS1, N_, FULL>), dim3((unsigned)nwg), dim3(NTHREADS), lds, stream, A); \
+        DSW_LAUNCH((cheb3_fwd_fused_kernel<NST, NS1, N_, FULL>), dim3((unsigned)nwg), dim3(NTHREADS), lds, stream, A); \
         break;                                                                                                          \
     }
     switch (A.Fout / 16) {

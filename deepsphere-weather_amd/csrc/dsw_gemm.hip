@@ -513,8 +513,8 @@ static int launch_ts_gemm_nt(const TsGemmParams& P, int col_tiles, hipStream_t s
     (res ? (const void*)ts_gemm_kernel<BF16, NT, RESIDENT_, ALIGNED_, true> : (const void*)ts_gemm_kernel<BF16, NT, RESIDENT_, ALIGNED_, false>)
 #define DSW_TSG_LAUNCH(RESIDENT_, ALIGNED_, GRID_, LDS_)                                                              \
     do {                                                                                                              \
-        if (res) hipLaunchKernelGGL((ts_gemm_kernel<BF16, NT, RESIDENT_, ALIGNED_, true>), GRID_, dim3(256), LDS_, stream, P);   \
-        else hipLaunchKernelGGL((ts_gemm_kernel<BF16, NT, RESIDENT_, ALIGNED_, false>), GRID_, dim3(256), LDS_, stream, P);      \
+        if (res) DSW_LAUNCH((ts_gemm_kernel<BF16, NT, RESIDENT_, ALIGNED_, true>), GRID_, dim3(256), LDS_, stream, P);   \
+        else DSW_LAUNCH((ts_gemm_kernel<BF16, NT, RESIDENT_, ALIGNED_, false>), GRID_, dim3(256), LDS_, stream, P);      \
     } while (0)
     if (resident) {
         const size_t lds = a_bytes + b_res;
@@ -829,8 +829,8 @@ static int dsw_wgrad_launch_impl(const void* X, const void* T, const void* dY, v
         S = (N + rps - 1) / rps;                                                                           \
         P.rows_per_slab = rps;                                                                             \
         dim3 grid((unsigned)S, (unsigned)groups, (unsigned)otiles);                                        \
-        if (aligned) hipLaunchKernelGGL((cheb_wgrad_kernel<BF, NW_, true>), grid, dim3(64 * NW_), 0, stream, P); \
-        else hipLaunchKernelGGL((cheb_wgrad_kernel<BF, NW_, false>), grid, dim3(64 * NW_), 0, stream, P);  \
+        if (aligned) DSW_LAUNCH((cheb_wgrad_kernel<BF, NW_, true>), grid, dim3(64 * NW_), 0, stream, P); \
+        else DSW_LAUNCH((cheb_wgrad_kernel<BF, NW_, false>), grid, dim3(64 * NW_), 0, stream, P);  \
     } while (0)
         if (dtype == DSW_F32) {
             if (nw == 1) DSW_WGRAD_LAUNCH(false, 1);
@@ -862,18 +862,18 @@ int dsw_wgrad_reduce_launch(const float* partial, int64_t S, int64_t Fin, int64_
     dim3 rgrid((unsigned)((total + 31) / 32));
     if (total <= 16384 && S > 64) {   // few outputs (<= 512 blocks), many slabs: 32 slab groups per block
         if (dtype == DSW_F32)
-            hipLaunchKernelGGL((cheb_wgrad_reduce_kernel<false, 32>), rgrid, dim3(1024), 0, stream, partial, (int)S,
+            DSW_LAUNCH((cheb_wgrad_reduce_kernel<false, 32>), rgrid, dim3(1024), 0, stream, partial, (int)S,
                                (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols, acc);
         else
-            hipLaunchKernelGGL((cheb_wgrad_reduce_kernel<true, 32>), rgrid, dim3(1024), 0, stream, partial, (int)S,
+            DSW_LAUNCH((cheb_wgrad_reduce_kernel<true, 32>), rgrid, dim3(1024), 0, stream, partial, (int)S,
                                (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols, acc);
         return dsw_check_launch();
     }
     if (dtype == DSW_F32)
-        hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, stream, partial, (int)S,
+        DSW_LAUNCH(cheb_wgrad_reduce_kernel<false>, rgrid, dim3(256), 0, stream, partial, (int)S,
                            (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols, acc);
     else
-        hipLaunchKernelGGL(cheb_wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, stream, partial, (int)S,
+        DSW_LAUNCH(cheb_wgrad_reduce_kernel<true>, rgrid, dim3(256), 0, stream, partial, (int)S,
                            (int)Fin, (int)Fout, (int)K, dW, db, (int)K_out, (int)k_off, db_cols, acc);
     return dsw_check_launch();
 }

@@ -328,7 +328,7 @@ int launch_x3(const TsGemmParams& P, int col_tiles, size_t lds, hipStream_t stre
     // XCD, so only the first of them fetches the A rows from HBM and the others hit that XCD's L2
     if (col_tiles > 1 && gx >= 8) gx &= ~7L;
     dim3 grid((unsigned)gx, (unsigned)col_tiles);
-    hipLaunchKernelGGL((ts_gemm_x3_kernel<NT, NSPLIT, IO, NWV>), grid, dim3(64 * NWV), lds, stream, P);
+    DSW_LAUNCH((ts_gemm_x3_kernel<NT, NSPLIT, IO, NWV>), grid, dim3(64 * NWV), lds, stream, P);
     return dsw_check_launch();
 }
 

@@ -494,7 +494,7 @@ int launch_x3s(const TsGemmParams& P0, int col_tiles, hipStream_t stream, char* 
         if (col_tiles > 1 && gx >= 8) gx &= ~7L;
     }
     dim3 grid((unsigned)gx, (unsigned)col_tiles);
-    hipLaunchKernelGGL((ts_gemm_x3s_kernel<NT, NWV, KFAST, RES, PRE>), grid, dim3(64 * NWV), lds, stream, P);
+    DSW_LAUNCH((ts_gemm_x3s_kernel<NT, NWV, KFAST, RES, PRE>), grid, dim3(64 * NWV), lds, stream, P);
     return dsw_check_launch();
 }
 
@@ -552,8 +552,8 @@ int dsw_ts_gemm_x3s_try_launch(const TsGemmParams& P, hipStream_t stream, int* r
     if (pre) {
         const long n_slots = (long)P.n_planes_a * chunks_ * col_tiles * (16L * 32 * nt);
         const int blocks = (int)((n_slots + 255) / 256 < 2048 ? (n_slots + 255) / 256 : 2048);
-        if (nt == 4) hipLaunchKernelGGL((x3s_presplit_kernel<128>), dim3(blocks), dim3(256), 0, stream, P, static_cast<unsigned*>(P.pre_ws), chunks_, col_tiles, flags, n_flags);
-        else hipLaunchKernelGGL((x3s_presplit_kernel<64>), dim3(blocks), dim3(256), 0, stream, P, static_cast<unsigned*>(P.pre_ws), chunks_, col_tiles, flags, n_flags);
+        if (nt == 4) DSW_LAUNCH((x3s_presplit_kernel<128>), dim3(blocks), dim3(256), 0, stream, P, static_cast<unsigned*>(P.pre_ws), chunks_, col_tiles, flags, n_flags);
+        else DSW_LAUNCH((x3s_presplit_kernel<64>), dim3(blocks), dim3(256), 0, stream, P, static_cast<unsigned*>(P.pre_ws), chunks_, col_tiles, flags, n_flags);
         if ((*rc = dsw_check_launch()) != DSW_OK) return 1;
     }
 #define DSW_X3S(NT_, NWV_)                                                                                          \

@@ -218,19 +218,19 @@ static unsigned narrow_grid(int64_t N, int rpb) {
 #define DSW_NARROW_LPR(KERNEL, LPR_, KF_, ...)                                               \
     if ((KF_) <= 8) {                                                                        \
         switch (LPR_) {                                                                      \
-            case 4: hipLaunchKernelGGL((KERNEL<4, 8>), __VA_ARGS__); break;                  \
-            case 8: hipLaunchKernelGGL((KERNEL<8, 8>), __VA_ARGS__); break;                  \
-            case 16: hipLaunchKernelGGL((KERNEL<16, 8>), __VA_ARGS__); break;                \
-            case 32: hipLaunchKernelGGL((KERNEL<32, 8>), __VA_ARGS__); break;                \
-            default: hipLaunchKernelGGL((KERNEL<64, 8>), __VA_ARGS__); break;                \
+            case 4: DSW_LAUNCH((KERNEL<4, 8>), __VA_ARGS__); break;                  \
+            case 8: DSW_LAUNCH((KERNEL<8, 8>), __VA_ARGS__); break;                  \
+            case 16: DSW_LAUNCH((KERNEL<16, 8>), __VA_ARGS__); break;                \
+            case 32: DSW_LAUNCH((KERNEL<32, 8>), __VA_ARGS__); break;                \
+            default: DSW_LAUNCH((KERNEL<64, 8>), __VA_ARGS__); break;                \
         }                                                                                    \
     } else {                                                                                 \
         switch (LPR_) {                                                                      \
-            case 4: hipLaunchKernelGGL((KERNEL<4, 16>), __VA_ARGS__); break;                 \
-            case 8: hipLaunchKernelGGL((KERNEL<8, 16>), __VA_ARGS__); break;                 \
-            case 16: hipLaunchKernelGGL((KERNEL<16, 16>), __VA_ARGS__); break;               \
-            case 32: hipLaunchKernelGGL((KERNEL<32, 16>), __VA_ARGS__); break;               \
-            default: hipLaunchKernelGGL((KERNEL<64, 16>), __VA_ARGS__); break;               \
+            case 4: DSW_LAUNCH((KERNEL<4, 16>), __VA_ARGS__); break;                 \
+            case 8: DSW_LAUNCH((KERNEL<8, 16>), __VA_ARGS__); break;                 \
+            case 16: DSW_LAUNCH((KERNEL<16, 16>), __VA_ARGS__); break;               \
+            case 32: DSW_LAUNCH((KERNEL<32, 16>), __VA_ARGS__); break;               \
+            default: DSW_LAUNCH((KERNEL<64, 16>), __VA_ARGS__); break;               \
         }                                                                                    \
     }
 

@@ -187,7 +187,7 @@ int dsw_maxval_pool_fwd(const int32_t* rowptr, const int32_t* colind, const floa
     const bool wide = (C % vec == 0) && dsw_aligned16(X) && dsw_aligned16(Y);
     const long total = B * v_out * (wide ? C / vec : C);
 #define DSW_POOL_FWD(BF, V_)                                                                                             \
-    hipLaunchKernelGGL((maxval_pool_fwd_kernel<BF, V_>), dim3(grid_for(total)), dim3(PT), 0, s, rowptr, colind, vals, X, \
+    DSW_LAUNCH((maxval_pool_fwd_kernel<BF, V_>), dim3(grid_for(total)), dim3(PT), 0, s, rowptr, colind, vals, X, \
                        Y, sel, (long)v_out, (long)v_in, (long)B, (int)C)
     if (dtype == DSW_BF16) { if (wide) DSW_POOL_FWD(true, 8); else DSW_POOL_FWD(true, 1); }
     else { if (wide) DSW_POOL_FWD(false, 4); else DSW_POOL_FWD(false, 1); }
@@ -207,7 +207,7 @@ int dsw_maxval_pool_bwd(const int32_t* rowptr_t, const int32_t* colind_t, int64_
     const bool wide = (C % vec == 0) && dsw_aligned16(dY) && dsw_aligned16(dX);
     const long total = B * v_fine * (wide ? C / vec : C);
 #define DSW_POOL_BWD(BF, V_)                                                                                               \
-    hipLaunchKernelGGL((maxval_pool_bwd_kernel<BF, V_>), dim3(grid_for(total)), dim3(PT), 0, s, rowptr_t, colind_t, dY, sel, \
+    DSW_LAUNCH((maxval_pool_bwd_kernel<BF, V_>), dim3(grid_for(total)), dim3(PT), 0, s, rowptr_t, colind_t, dY, sel, \
                        dX, (long)v_fine, (long)v_coarse, (long)B, (int)C)
     if (dtype == DSW_BF16) { if (wide) DSW_POOL_BWD(true, 8); else DSW_POOL_BWD(true, 1); }
     else { if (wide) DSW_POOL_BWD(false, 4); else DSW_POOL_BWD(false, 1); }
@@ -232,13 +232,13 @@ int dsw_maxval_unpool_fwd(const int32_t* sel, const void* X, void* Y, void* work
     int* winner = static_cast<int*>(workspace);
     if (hipMemsetAsync(winner, 0xFF, (size_t)need, s) != hipSuccess) return DSW_ERR_LAUNCH;   // -1 everywhere
     if (v_coarse > 0)
-        hipLaunchKernelGGL(maxval_unpool_mark_kernel, dim3(grid_for(B * v_coarse * C)), dim3(PT), 0, s, sel, winner,
+        DSW_LAUNCH(maxval_unpool_mark_kernel, dim3(grid_for(B * v_coarse * C)), dim3(PT), 0, s, sel, winner,
                            (long)v_coarse, (long)v_fine, (long)B, (int)C);
     if (dtype == DSW_BF16)
-        hipLaunchKernelGGL(maxval_unpool_fill_kernel<true>, dim3(grid_for(B * v_fine * C)), dim3(PT), 0, s, winner, X, Y,
+        DSW_LAUNCH(maxval_unpool_fill_kernel<true>, dim3(grid_for(B * v_fine * C)), dim3(PT), 0, s, winner, X, Y,
                            (long)v_coarse, (long)v_fine, (long)B, (int)C);
     else
-        hipLaunchKernelGGL(maxval_unpool_fill_kernel<false>, dim3(grid_for(B * v_fine * C)), dim3(PT), 0, s, winner, X, Y,
+        DSW_LAUNCH(maxval_unpool_fill_kernel<false>, dim3(grid_for(B * v_fine * C)), dim3(PT), 0, s, winner, X, Y,
                            (long)v_coarse, (long)v_fine, (long)B, (int)C);
     return dsw_check_launch();
 }
@@ -251,10 +251,10 @@ int dsw_maxval_unpool_bwd(const int32_t* sel, const void* dY, void* dX, int64_t 
     if (!sel || !dY || !dX) return DSW_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == DSW_BF16)
-        hipLaunchKernelGGL(maxval_unpool_bwd_kernel<true>, dim3(grid_for(B * v_coarse * C)), dim3(PT), 0, s, sel, dY, dX,
+        DSW_LAUNCH(maxval_unpool_bwd_kernel<true>, dim3(grid_for(B * v_coarse * C)), dim3(PT), 0, s, sel, dY, dX,
                            (long)v_coarse, (long)v_fine, (long)B, (int)C);
     else
-        hipLaunchKernelGGL(maxval_unpool_bwd_kernel<false>, dim3(grid_for(B * v_coarse * C)), dim3(PT), 0, s, sel, dY, dX,
+        DSW_LAUNCH(maxval_unpool_bwd_kernel<false>, dim3(grid_for(B * v_coarse * C)), dim3(PT), 0, s, sel, dY, dX,
                            (long)v_coarse, (long)v_fine, (long)B, (int)C);
     return dsw_check_launch();
 }

@@ -15,6 +15,7 @@
 //   * rows are consecutive in a workgroup, so in HEALPix nested order (Morton curve per face) the
 //     gathered neighbours of a 32..256-row tile mostly hit the CU's L1 / the XCD's L2.
 #include "dsw_common.h"
+#include "../../include/dsw_hip.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -90,29 +91,95 @@ struct Vec<true, 1> {
 
 // Long rows of spmm_csr_rowsplit: one WAVE per (row, sample).  Lane = (channel chunk c = lane % cpr, part p = lane / cpr);
 // part p takes entries p, p + parts, ..; the parts of a chunk are added up by xor-shuffles and part 0 runs the epilogue.
-// The waves first scan the row lengths 64 rows at a time (ballot; row r belongs to wave r % n_waves), so a launch without
-// long rows pays a few microseconds of a handful of extra blocks.  cpr is a power of two <= 64 (checked by the launcher).
+// cpr is a power of two <= 64 (checked by the launcher).
+template <bool BF16, int VEC>
+static __device__ __forceinline__ void spmm_long_row_one(
+    const int* __restrict__ rowptr, const int* __restrict__ colind, const float* __restrict__ vals,
+    const void* __restrict__ X, void* Y, const void* Z, const void* Z2, float alpha, float beta, float gamma,
+    int v_out, int v_in, int C, int cpr, int ldx, int ldy, int ldz, const int row, const int b) {
+    using V = Vec<BF16, VEC>;
+    const int lane = threadIdx.x & 63;
+    const int c0 = (lane & (cpr - 1)) * VEC;
+    const int part = lane / cpr, parts = 64 / cpr;
+    const size_t xs = (size_t)v_in * ldx;
+    const int s = rowptr[row], e = rowptr[row + 1];
+    const size_t xb = (size_t)b * xs + c0;
+    float acc[VEC];
+#pragma unroll
+    for (int jj = 0; jj < VEC; ++jj) acc[jj] = 0.f;
+    int q = s + part;
+    for (; q + 3 * parts < e; q += 4 * parts) {      // four entries per step: four gathers in flight
+        int col[4];
+        float a[4], x[4][VEC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { col[u] = colind[q + u * parts]; a[u] = vals[q + u * parts]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) V::load(X, xb + (size_t)col[u] * ldx, x[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int jj = 0; jj < VEC; ++jj) acc[jj] = fmaf(a[u], x[u][jj], acc[jj]);
+    }
+    for (; q < e; q += parts) {
+        float x[VEC];
+        V::load(X, xb + (size_t)colind[q] * ldx, x);
+        const float a = vals[q];
+#pragma unroll
+        for (int jj = 0; jj < VEC; ++jj) acc[jj] = fmaf(a, x[jj], acc[jj]);
+    }
+    for (int m = cpr; m < 64; m <<= 1) {
+#pragma unroll
+        for (int jj = 0; jj < VEC; ++jj) acc[jj] += __shfl_xor(acc[jj], m, 64);
+    }
+    if (part == 0) {
+        const size_t off = ((size_t)b * v_out + row) * (size_t)C + c0;
+        float o[VEC];
+#pragma unroll
+        for (int jj = 0; jj < VEC; ++jj) o[jj] = alpha * acc[jj];
+        if (Z != nullptr) {
+            float z[VEC];
+            V::load(Z, ((size_t)b * v_out + row) * (size_t)ldz + c0, z);
+#pragma unroll
+            for (int jj = 0; jj < VEC; ++jj) o[jj] = fmaf(beta, z[jj], o[jj]);
+        }
+        if (Z2 != nullptr) {
+            float z[VEC];
+            V::load(Z2, off, z);
+#pragma unroll
+            for (int jj = 0; jj < VEC; ++jj) o[jj] = fmaf(gamma, z[jj], o[jj]);
+        }
+        V::store(Y, ((size_t)b * v_out + row) * (size_t)ldy + c0, o);
+    }
+}
+
+// Which rows are long?  Without a plan the waves scan the row lengths 64 rows at a time (ballot; row r belongs to wave
+// r % n_waves), so a launch without long rows pays a few microseconds of a handful of extra blocks.  With a plan of the
+// operator (dsw_remap_plan: the remap matrices of the pooling layers) the long rows are LISTED: wave task t = (listed row
+// t / B, sample t % B), exactly as many blocks as the list needs, no scan.
 template <bool BF16, int VEC>
 static __device__ __forceinline__ void spmm_long_rows(
     const int* __restrict__ rowptr, const int* __restrict__ colind, const float* __restrict__ vals,
     const void* __restrict__ X, void* Y, const void* Z, const void* Z2, float alpha, float beta, float gamma,
     int v_out, int v_in, int C, int cpr, int B, int flags, int ldx, int ldy, int ldz, int long_thr, long lblock,
-    long lblocks) {
-    using V = Vec<BF16, VEC>;
+    long lblocks, const int* __restrict__ long_list, int n_long) {
     const int lane = threadIdx.x & 63;
-    // work item = (long row, sample): ONE sample per wave keeps this path within the registers of the main path (the
-    // kernel's allocation is the maximum of both) and gives B waves to every long row
     const long all_waves = lblocks * (blockDim.x >> 6);
     const long gwave = lblock * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (long_list != nullptr) {
+        const long tasks = (long)n_long * B;
+        for (long t = gwave; t < tasks; t += all_waves)
+            spmm_long_row_one<BF16, VEC>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, v_out, v_in, C, cpr, ldx, ldy,
+                                         ldz, long_list[t / B], (int)(t % B));
+        return;
+    }
+    // work item = (long row, sample): ONE sample per wave keeps this path within the registers of the main path (the
+    // kernel's allocation is the maximum of both) and gives B waves to every long row
     const int bsplit = (all_waves >= 2L * B) ? B : 1;
     const long n_waves = all_waves / bsplit;
     const long wave = gwave / bsplit;
     const int b_first = bsplit > 1 ? (int)(gwave % bsplit) : 0;
     const int b_step = bsplit > 1 ? B : 1;               // with bsplit > 1 the sample loop below runs once
     if (wave >= n_waves) return;
-    const int c0 = (lane & (cpr - 1)) * VEC;
-    const int part = lane / cpr, parts = 64 / cpr;
-    const size_t xs = (size_t)v_in * ldx;
     // row r belongs to wave r % n_waves: neighbouring long rows (the cells around a pole) go to different waves
     for (long kb = 0; kb * n_waves < v_out; kb += 64) {
         const long r = (kb + lane) * n_waves + wave;
@@ -122,56 +189,9 @@ static __device__ __forceinline__ void spmm_long_rows(
             const int j = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
             const int row = (int)((kb + j) * n_waves + wave);
-            const int s = rowptr[row], e = rowptr[row + 1];
-            for (int b = b_first; b < B; b += b_step) {
-                const size_t xb = (size_t)b * xs + c0;
-                float acc[VEC];
-#pragma unroll
-                for (int jj = 0; jj < VEC; ++jj) acc[jj] = 0.f;
-                int q = s + part;
-                for (; q + 3 * parts < e; q += 4 * parts) {      // four entries per step: four gathers in flight
-                    int col[4];
-                    float a[4], x[4][VEC];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { col[u] = colind[q + u * parts]; a[u] = vals[q + u * parts]; }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) V::load(X, xb + (size_t)col[u] * ldx, x[u]);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int jj = 0; jj < VEC; ++jj) acc[jj] = fmaf(a[u], x[u][jj], acc[jj]);
-                }
-                for (; q < e; q += parts) {
-                    float x[VEC];
-                    V::load(X, xb + (size_t)colind[q] * ldx, x);
-                    const float a = vals[q];
-#pragma unroll
-                    for (int jj = 0; jj < VEC; ++jj) acc[jj] = fmaf(a, x[jj], acc[jj]);
-                }
-                for (int m = cpr; m < 64; m <<= 1) {
-#pragma unroll
-                    for (int jj = 0; jj < VEC; ++jj) acc[jj] += __shfl_xor(acc[jj], m, 64);
-                }
-                if (part == 0) {
-                    const size_t off = ((size_t)b * v_out + row) * (size_t)C + c0;
-                    float o[VEC];
-#pragma unroll
-                    for (int jj = 0; jj < VEC; ++jj) o[jj] = alpha * acc[jj];
-                    if (Z != nullptr) {
-                        float z[VEC];
-                        V::load(Z, ((size_t)b * v_out + row) * (size_t)ldz + c0, z);
-#pragma unroll
-                        for (int jj = 0; jj < VEC; ++jj) o[jj] = fmaf(beta, z[jj], o[jj]);
-                    }
-                    if (Z2 != nullptr) {
-                        float z[VEC];
-                        V::load(Z2, off, z);
-#pragma unroll
-                        for (int jj = 0; jj < VEC; ++jj) o[jj] = fmaf(gamma, z[jj], o[jj]);
-                    }
-                    V::store(Y, ((size_t)b * v_out + row) * (size_t)ldy + c0, o);
-                }
-            }
+            for (int b = b_first; b < B; b += b_step)
+                spmm_long_row_one<BF16, VEC>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, v_out, v_in, C, cpr, ldx, ldy,
+                                             ldz, row, b);
         }
     }
 }
@@ -183,7 +203,7 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit(
     const void* __restrict__ X, void* Y, const void* Z, const void* Z2,
     float alpha, float beta, float gamma,
     int v_out, int v_in, int C, int cpr, int B, long row_blocks, int xcd_swizzle, int ldx, int ldy, int ldz,
-    int long_thr, long main_blocks) {
+    int long_thr, long main_blocks, const int* __restrict__ long_list, int n_long) {
     // ldx / ldy: elements between consecutive rows of X / Y (>= C: a channel slice of a wider node-major tensor, e.g.
     // one half of the decoder's concatenation buffer); ldz: the same for Z; Z2 is always dense [B, v_out, C]
     using V = Vec<BF16, VEC>;
@@ -197,7 +217,7 @@ __global__ __launch_bounds__(256) void spmm_csr_rowsplit(
     const long lblocks = (long)gridDim.x - main_blocks;   // they come FIRST in the grid (a multiple of 8: the XCD phase stays)
     if ((long)blockIdx.x < lblocks) {
         spmm_long_rows<BF16, VEC>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, v_out, v_in, C, cpr, B,
-                                      xcd_swizzle, ldx, ldy, ldz, long_thr, (long)blockIdx.x, lblocks);
+                                      xcd_swizzle, ldx, ldy, ldz, long_thr, (long)blockIdx.x, lblocks, long_list, n_long);
         return;
     }
     const long nwg = main_blocks;
@@ -378,15 +398,19 @@ int launch_tiled(const int* rowptr, const int* colind, const float* vals, const 
     const long tiles = (v_out + R - 1) / R;
     dim3 grid((unsigned)(tiles * B));
     const size_t lds = (size_t)R * C * es;
-    hipLaunchKernelGGL((spmm_csr_tiled<BF16, VEC>), grid, dim3(256), lds, stream, rowptr, colind, vals, X, Y,
+    DSW_LAUNCH((spmm_csr_tiled<BF16, VEC>), grid, dim3(256), lds, stream, rowptr, colind, vals, X, Y,
                        Z, Z2, alpha, beta, gamma, v_out, v_in, C, cpr, R, B);
     return dsw_check_launch();
 }
 
+// long rows of a launch: `list` (device, n_long rows, threshold thr) from a plan of the operator, or nullptr = scan
+struct LongRows { const int* list; int n_long; int thr; };
+
 template <bool BF16, int VEC, int NB>
 int launch_rowsplit(const int* rowptr, const int* colind, const float* vals, const void* X, void* Y,
                     const void* Z, const void* Z2, float alpha, float beta, float gamma, int v_out,
-                    int v_in, int C, int B, hipStream_t stream, int hints = 0, int ldx = 0, int ldy = 0, int ldz = 0) {
+                    int v_in, int C, int B, hipStream_t stream, int hints = 0, int ldx = 0, int ldy = 0, int ldz = 0,
+                    LongRows lrw = {nullptr, 0, 0}) {
     const int cpr = C / VEC;
     const long threads = (long)v_out * cpr;
     static const char* bs_env = dsw_diag_env("DSW_SPMM_BLOCK");   // diagnostics: threads per block (64..1024)
@@ -396,17 +420,147 @@ int launch_rowsplit(const int* rowptr, const int* colind, const float* vals, con
     static const char* sw = dsw_diag_env("DSW_SPMM_XCD");  // "0" disables the XCD-aware block order (diagnostics)
     // bit0: XCD block order, bit1: nt loads of Z/Z2, bit2: nt stores of Y (env overrides the caller's hints)
     const int swz = sw ? atoi(sw) : (1 | (hints & 6));
-    // long rows (see spmm_long_rows): a few trailing blocks scan for them and give each a whole wave
+    // long rows (see spmm_long_rows): blocks in front of the main ones give each a whole wave.  Listed by a plan: one wave
+    // task per (listed row, sample), four per block; otherwise a few blocks scan the row lengths
     const bool lr = (cpr & (cpr - 1)) == 0 && cpr <= 64 && bs % 64 == 0;
-    const int long_thr = lr ? 64 : 0;
-    long lblocks = lr ? (((long)v_out / 256 + 7) & ~7L) : 0;   // one wave per ~64 rows: a single scan step each
-    if (lblocks > 256) lblocks = 256;
-    if (lr && lblocks < 8) lblocks = 8;
+    const bool listed = lr && lrw.list != nullptr;
+    const int long_thr = listed ? lrw.thr : lr ? 64 : 0;
+    long lblocks;
+    if (listed) {
+        lblocks = (((long)lrw.n_long * B + (bs / 64) - 1) / (bs / 64) + 7) & ~7L;   // (a multiple of 8: the XCD phase stays)
+        if (lblocks > 4096) lblocks = 4096;
+    } else {
+        lblocks = lr ? (((long)v_out / 256 + 7) & ~7L) : 0;   // one wave per ~64 rows: a single scan step each
+        if (lblocks > 256) lblocks = 256;
+        if (lr && lblocks < 8) lblocks = 8;
+    }
     const long main_blocks = row_blocks * bgroups;
     dim3 grid((unsigned)(main_blocks + lblocks));
-    hipLaunchKernelGGL((spmm_csr_rowsplit<BF16, VEC, NB>), grid, dim3(bs), 0, stream, rowptr, colind,
+    DSW_LAUNCH((spmm_csr_rowsplit<BF16, VEC, NB>), grid, dim3(bs), 0, stream, rowptr, colind,
                        vals, X, Y, Z, Z2, alpha, beta, gamma, v_out, v_in, C, cpr, B, row_blocks, swz, ldx > 0 ? ldx : C,
-                       ldy > 0 ? ldy : C, ldz > 0 ? ldz : C, long_thr, main_blocks);
+                       ldy > 0 ? ldy : C, ldz > 0 ? ldz : C, long_thr, main_blocks, listed ? lrw.list : nullptr,
+                       listed ? lrw.n_long : 0);
+    return dsw_check_launch();
+}
+
+// ---- interpolation pooling between the levels of a REGULAR hierarchy (HEALPix nested: 4 children per parent) -------------
+// The remap matrix of such a pooling has m entries per row in columns m r .. m r + m - 1 (GROUPS: pooling, and the
+// transposed unpooling), its counterpart one entry per row in column r / m (BROADCAST: unpooling, and the transposed
+// pooling).  Both are pure streaming: no row pointers, no column indices, no dependent index -> address -> data chain -
+// 16-byte lanes, m row loads and one store (or one load and m stores), the weights read from the CSR values (any values:
+// the structure is what the plan certifies, dsw_amd/functional.py: CsrOperator.remap_plan).
+struct RemapArgs {
+    const float* vals;
+    const void* X;
+    void* Y;
+    const void* Z;      // optional epilogue operand (the other consumer's gradient of a forked tensor), row stride ldz
+    float beta;
+    int rows;           // GROUPS: output rows; BROADCAST: input rows
+    int m, C, cpr;
+    int ldx, ldy, ldz;
+};
+
+template <bool BF16, int VEC, int M>   // M: 4 = the HEALPix hierarchy, 0 = run-time m
+__global__ __launch_bounds__(256) void remap_groups_kernel(const RemapArgs P) {
+    using V = Vec<BF16, VEC>;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int r = (int)(gid / P.cpr);
+    if (r >= P.rows) return;
+    const int c0 = (int)(gid - (long)r * P.cpr) * VEC;
+    const int b = blockIdx.y;
+    const int m = M > 0 ? M : P.m;
+    const size_t xrow = ((size_t)b * P.rows + r) * (size_t)m;      // first input row of the group (v_in = m rows)
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    if constexpr (M == 4) {
+        const float4 w = *reinterpret_cast<const float4*>(P.vals + (size_t)r * 4);
+        const float wv[4] = {w.x, w.y, w.z, w.w};
+        float x[4][VEC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) V::load_nt(P.X, (xrow + u) * (size_t)P.ldx + c0, x[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] = fmaf(wv[u], x[u][j], acc[j]);
+    } else {
+        for (int u = 0; u < m; ++u) {
+            float x[VEC];
+            V::load_nt(P.X, (xrow + u) * (size_t)P.ldx + c0, x);
+            const float w = P.vals[(size_t)r * m + u];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] = fmaf(w, x[j], acc[j]);
+        }
+    }
+    const size_t orow = (size_t)b * P.rows + r;
+    if (P.Z != nullptr) {
+        float z[VEC];
+        V::load_nt(P.Z, orow * (size_t)P.ldz + c0, z);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = fmaf(P.beta, z[j], acc[j]);
+    }
+    V::store(P.Y, orow * (size_t)P.ldy + c0, acc);
+}
+
+template <bool BF16, int VEC, int M>
+__global__ __launch_bounds__(256) void remap_broadcast_kernel(const RemapArgs P) {
+    using V = Vec<BF16, VEC>;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int q = (int)(gid / P.cpr);
+    if (q >= P.rows) return;
+    const int c0 = (int)(gid - (long)q * P.cpr) * VEC;
+    const int b = blockIdx.y;
+    const int m = M > 0 ? M : P.m;
+    float x[VEC];
+    V::load_nt(P.X, ((size_t)b * P.rows + q) * (size_t)P.ldx + c0, x);
+    const size_t orow = ((size_t)b * P.rows + q) * (size_t)m;
+    if constexpr (M == 4) {
+        const float4 w = *reinterpret_cast<const float4*>(P.vals + (size_t)q * 4);
+        const float wv[4] = {w.x, w.y, w.z, w.w};
+        float z[4][VEC];
+        if (P.Z != nullptr) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) V::load_nt(P.Z, (orow + u) * (size_t)P.ldz + c0, z[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float o[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] = wv[u] * x[j];
+            if (P.Z != nullptr) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o[j] = fmaf(P.beta, z[u][j], o[j]);
+            }
+            V::store(P.Y, (orow + u) * (size_t)P.ldy + c0, o);
+        }
+    } else {
+        for (int u = 0; u < m; ++u) {
+            const float w = P.vals[(size_t)q * m + u];
+            float o[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] = w * x[j];
+            if (P.Z != nullptr) {
+                float z[VEC];
+                V::load_nt(P.Z, (orow + u) * (size_t)P.ldz + c0, z);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o[j] = fmaf(P.beta, z[j], o[j]);
+            }
+            V::store(P.Y, (orow + u) * (size_t)P.ldy + c0, o);
+        }
+    }
+}
+
+template <bool BF16, int VEC>
+int launch_remap_regular(int kind, const RemapArgs& A, int B, hipStream_t stream) {
+    const long threads = (long)A.rows * A.cpr;
+    dim3 grid((unsigned)((threads + 255) / 256), (unsigned)B);
+    if (kind == 1) {
+        if (A.m == 4) DSW_LAUNCH((remap_groups_kernel<BF16, VEC, 4>), grid, dim3(256), 0, stream, A);
+        else DSW_LAUNCH((remap_groups_kernel<BF16, VEC, 0>), grid, dim3(256), 0, stream, A);
+    } else {
+        if (A.m == 4) DSW_LAUNCH((remap_broadcast_kernel<BF16, VEC, 4>), grid, dim3(256), 0, stream, A);
+        else DSW_LAUNCH((remap_broadcast_kernel<BF16, VEC, 0>), grid, dim3(256), 0, stream, A);
+    }
     return dsw_check_launch();
 }
 
@@ -415,7 +569,9 @@ int launch_rowsplit(const int* rowptr, const int* colind, const float* vals, con
 // Internal C++ entry used by dsw_api.hip
 int dsw_spmm_launch_ld(const int* rowptr, const int* colind, const float* vals, int64_t v_out, int64_t v_in,
                        const void* X, int64_t ldx_, void* Y, int64_t ldy_, int64_t B, int64_t C, float alpha, const void* Z,
-                       float beta, const void* Z2, float gamma, int dtype, hipStream_t stream, int hints, int64_t ldz_) {
+                       float beta, const void* Z2, float gamma, int dtype, hipStream_t stream, int hints, int64_t ldz_,
+                       const int* long_list, int n_long, int long_thr) {
+    const LongRows lrw = {long_list, n_long, long_thr};
     if (ldz_ <= 0) ldz_ = C;
     if (ldx_ < C || ldy_ < C || ldz_ < C || ldx_ > INT32_MAX || ldy_ > INT32_MAX || ldz_ > INT32_MAX) return DSW_ERR_BAD_ARG;
     const int ldx = (int)ldx_, ldy = (int)ldy_, ldz = (int)ldz_;
@@ -453,22 +609,31 @@ int dsw_spmm_launch_ld(const int* rowptr, const int* colind, const float* vals, 
     const int nbf = nbs ? atoi(nbs) : 0;
     if (dtype == DSW_F32) {
         if (al && c % 4 == 0) {
-            if (nbf == 1) return launch_rowsplit<false, 4, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
-            if (nbf == 2) return launch_rowsplit<false, 4, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
-            if (b >= 4) return launch_rowsplit<false, 4, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
-            if (b >= 2) return launch_rowsplit<false, 4, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
-            return launch_rowsplit<false, 4, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
+            if (nbf == 1) return launch_rowsplit<false, 4, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz, lrw);
+            if (nbf == 2) return launch_rowsplit<false, 4, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz, lrw);
+            // planned remap products with few output rows (a pooling to a coarse level: 12 288 rows of 8 lanes): fewer samples
+            // per thread so that the launch has at least ~8 blocks per CU - the gathers are latency-bound chains, and with
+            // 3 blocks per CU (NB = 4) the chip waits on them instead of hiding them
+            if (lrw.list != nullptr) {
+                int nb = b >= 4 ? 4 : b >= 2 ? 2 : 1;
+                while (nb > 1 && ((long)vo * (c / 4) + 255) / 256 * ((b + nb - 1) / nb) < 2048) nb >>= 1;
+                if (nb == 1) return launch_rowsplit<false, 4, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz, lrw);
+                if (nb == 2) return launch_rowsplit<false, 4, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz, lrw);
+            }
+            if (b >= 4) return launch_rowsplit<false, 4, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz, lrw);
+            if (b >= 2) return launch_rowsplit<false, 4, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz, lrw);
+            return launch_rowsplit<false, 4, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz, lrw);
         }
-        if (b >= 4) return launch_rowsplit<false, 1, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
-        return launch_rowsplit<false, 1, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
+        if (b >= 4) return launch_rowsplit<false, 1, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz, lrw);
+        return launch_rowsplit<false, 1, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz, lrw);
     }
     if (dtype == DSW_BF16) {
         if (al && c % 8 == 0) {
-            if (b >= 2) return launch_rowsplit<true, 8, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
-            return launch_rowsplit<true, 8, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
+            if (b >= 2) return launch_rowsplit<true, 8, 2>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz, lrw);
+            return launch_rowsplit<true, 8, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz, lrw);
         }
-        if (b >= 4) return launch_rowsplit<true, 1, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
-        return launch_rowsplit<true, 1, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz);
+        if (b >= 4) return launch_rowsplit<true, 1, 4>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz, lrw);
+        return launch_rowsplit<true, 1, 1>(rowptr, colind, vals, X, Y, Z, Z2, alpha, beta, gamma, vo, vi, c, b, stream, hints, ldx, ldy, ldz, lrw);
     }
     return DSW_ERR_BAD_DTYPE;
 }
@@ -477,5 +642,30 @@ int dsw_spmm_launch(const int* rowptr, const int* colind, const float* vals, int
                     const void* X, void* Y, int64_t B, int64_t C, float alpha, const void* Z, float beta,
                     const void* Z2, float gamma, int dtype, hipStream_t stream, int hints) {
     return dsw_spmm_launch_ld(rowptr, colind, vals, v_out, v_in, X, C, Y, C, B, C, alpha, Z, beta, Z2, gamma, dtype, stream,
-                              hints, C);
+                              hints, C, nullptr, 0, 0);
+}
+
+// Interpolation-pooling product Y = M X (+ beta Z) with a plan of M (include/dsw_hip.h: dsw_remap_plan).
+int dsw_remap_launch(const dsw_remap_plan* plan, const int* rowptr, const int* colind, const float* vals, int64_t v_out,
+                     int64_t v_in, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t B, int64_t C, const void* Z,
+                     int64_t ldz, float beta, int dtype, hipStream_t stream) {
+    if (Z == nullptr) { beta = 0.f; ldz = C; }
+    const int vec = dtype == DSW_BF16 ? 8 : 4;
+    const bool al = dsw_aligned16(X) && dsw_aligned16(Y) && (Z == nullptr || dsw_aligned16(Z)) && dsw_aligned16(vals) &&
+                    ldx % vec == 0 && ldy % vec == 0 && ldz % vec == 0 && C % vec == 0;
+    const int kind = plan ? plan->kind : 0;
+    if ((kind == 1 || kind == 2) && al && plan->m >= 1 && B <= 65535 && v_out > 0 && v_in > 0 && B > 0 &&
+        ldx <= INT32_MAX && ldy <= INT32_MAX && ldz <= INT32_MAX && v_out <= INT32_MAX && v_in <= INT32_MAX &&
+        ((kind == 1 && v_in == v_out * plan->m) || (kind == 2 && v_out == v_in * plan->m))) {
+        RemapArgs A;
+        A.vals = vals; A.X = X; A.Y = Y; A.Z = Z; A.beta = beta;
+        A.rows = (int)(kind == 1 ? v_out : v_in); A.m = plan->m; A.C = (int)C; A.cpr = (int)(C / vec);
+        A.ldx = (int)ldx; A.ldy = (int)ldy; A.ldz = (int)ldz;
+        if (dtype == DSW_F32) return launch_remap_regular<false, 4>(kind, A, (int)B, stream);
+        if (dtype == DSW_BF16) return launch_remap_regular<true, 8>(kind, A, (int)B, stream);
+        return DSW_ERR_BAD_DTYPE;
+    }
+    const bool listed = plan != nullptr && plan->long_rows != nullptr && plan->long_thr > 0;
+    return dsw_spmm_launch_ld(rowptr, colind, vals, v_out, v_in, X, ldx, Y, ldy, B, C, 1.f, Z, beta, nullptr, 0.f, dtype, stream,
+                              0, ldz, listed ? plan->long_rows : nullptr, listed ? plan->n_long : 0, listed ? plan->long_thr : 0);
 }

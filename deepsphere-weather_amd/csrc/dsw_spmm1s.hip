@@ -443,7 +443,7 @@ int launch_h1(const Hop1Args& A, long nwg, size_t lds, hipStream_t stream) {
             hipFuncSetAttribute((const void*)spmm1_staged_kernel<BF16, NST, NS2, HZ_, HZ2_, OCC>,                 \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)              \
             return DSW_ERR_LAUNCH;                                                                                \
-        hipLaunchKernelGGL((spmm1_staged_kernel<BF16, NST, NS2, HZ_, HZ2_, OCC>), dim3((unsigned)nwg),            \
+        DSW_LAUNCH((spmm1_staged_kernel<BF16, NST, NS2, HZ_, HZ2_, OCC>), dim3((unsigned)nwg),            \
                            dim3(NTHREADS1), lds, stream, A);                                                      \
     } while (0)
     if (A.Z && A.Z2) DSW_H1_GO(true, true);
@@ -527,8 +527,8 @@ int dsw_spmm1s_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const
                 hipFuncSetAttribute((const void*)spmm1_dma_kernel<BF_, NST_, false, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsd) != hipSuccess)   \
                 return DSW_ERR_LAUNCH;                                                                               \
         }                                                                                                            \
-        if (A.Z) { hipLaunchKernelGGL((spmm1_dma_kernel<BF_, NST_, true, W_>), dim3((unsigned)nwg), dim3(NTHREADS1), ldsd, stream, A); }    \
-        else { hipLaunchKernelGGL((spmm1_dma_kernel<BF_, NST_, false, W_>), dim3((unsigned)nwg), dim3(NTHREADS1), ldsd, stream, A); }       \
+        if (A.Z) { DSW_LAUNCH((spmm1_dma_kernel<BF_, NST_, true, W_>), dim3((unsigned)nwg), dim3(NTHREADS1), ldsd, stream, A); }    \
+        else { DSW_LAUNCH((spmm1_dma_kernel<BF_, NST_, false, W_>), dim3((unsigned)nwg), dim3(NTHREADS1), ldsd, stream, A); }       \
         return dsw_check_launch();                                                                                   \
     } while (0)
 #define DSW_H1_DMA(BF_, NST_) do { if (plan->ell_w == 24) DSW_H1_DMA2(BF_, NST_, 24); else DSW_H1_DMA2(BF_, NST_, 32); } while (0)

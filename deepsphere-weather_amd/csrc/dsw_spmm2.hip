@@ -299,7 +299,7 @@ int launch_h2(const Hop2Args& A, long nwg, size_t lds, hipStream_t stream) {
             hipFuncSetAttribute((const void*)spmm2_fused_kernel<BF16, NST, true, Z2_, NS1, NS2, BYTEOFF, false>,          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
             return DSW_ERR_LAUNCH;                                                                               \
-        hipLaunchKernelGGL((spmm2_fused_kernel<BF16, NST, true, Z2_, NS1, NS2, BYTEOFF, false>), dim3((unsigned)nwg),     \
+        DSW_LAUNCH((spmm2_fused_kernel<BF16, NST, true, Z2_, NS1, NS2, BYTEOFF, false>), dim3((unsigned)nwg),     \
                            dim3(NTHREADS), lds, stream, A);                                                      \
     } while (0)
             if (A.Z2) DSW_H2_NOB(true); else DSW_H2_NOB(false);
@@ -313,7 +313,7 @@ int launch_h2(const Hop2Args& A, long nwg, size_t lds, hipStream_t stream) {
             hipFuncSetAttribute((const void*)spmm2_fused_kernel<BF16, NST, ZA_, Z2_, NS1, NS2, BYTEOFF>,                  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)             \
             return DSW_ERR_LAUNCH;                                                                               \
-        hipLaunchKernelGGL((spmm2_fused_kernel<BF16, NST, ZA_, Z2_, NS1, NS2, BYTEOFF>), dim3((unsigned)nwg),             \
+        DSW_LAUNCH((spmm2_fused_kernel<BF16, NST, ZA_, Z2_, NS1, NS2, BYTEOFF>), dim3((unsigned)nwg),             \
                            dim3(NTHREADS), lds, stream, A);                                                      \
         break;                                                                                                   \
     }

@@ -575,7 +575,7 @@ int launch_wbf16(WgradParams& P, int groups, int otiles, int64_t max_slabs, int6
     P.rows_per_slab = rps;
     *S_out = S;
     dim3 grid((unsigned)S, (unsigned)groups, (unsigned)zdim);
-    hipLaunchKernelGGL((cheb_wgrad_bf16_kernel<NW, NO, FUSE>), grid, dim3(NT_), lds, stream, P);
+    DSW_LAUNCH((cheb_wgrad_bf16_kernel<NW, NO, FUSE>), grid, dim3(NT_), lds, stream, P);
     return dsw_check_launch();
 }
 
@@ -604,7 +604,7 @@ int launch_wx3(WgradParams& P, int groups, int otiles, int64_t max_slabs, int64_
     P.rows_per_slab = rps;
     *S_out = S;
     dim3 grid((unsigned)S, (unsigned)groups, (unsigned)zdim);
-    hipLaunchKernelGGL((cheb_wgrad_x3_kernel<BF16IO, NSPLIT, NW, NO, FUSE>), grid, dim3(NT_), lds, stream, P);
+    DSW_LAUNCH((cheb_wgrad_x3_kernel<BF16IO, NSPLIT, NW, NO, FUSE>), grid, dim3(NT_), lds, stream, P);
     return dsw_check_launch();
 }
 

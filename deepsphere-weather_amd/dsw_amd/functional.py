@@ -49,6 +49,7 @@ class CsrOperator:
         self.shape = (int(shape[0]), int(shape[1]))
         self.nnz = int(colind.numel())
         self._t = None
+        self._remap = None        # remap plan (interpolation pooling products), built on first use
         self._plans = {}          # row_bytes -> device plan (or None)
         self._plans_by_rows = {}  # tile_rows -> host plan (or None): built once per tile size, shared by every row size
 
@@ -177,6 +178,45 @@ class CsrOperator:
                             best, plan = cost, cand
             self._plans[key] = None if plan is None else plan.to(self.device)
         return self._plans[key]
+
+    def remap_plan(self):
+        """Plan of this matrix as a REMAP (pooling) operator for ``dsw_remap_csr`` (include/dsw_hip.h: dsw_remap_plan), built
+        once: the structure of a regular hierarchy (m entries per row in columns m r .. m r + m - 1, or one entry per row in
+        column r / m - the HEALPix nested pooling / unpooling and their transposes) when the matrix has it, else the list of
+        its long rows (polar cells of a cross-sampling matrix)."""
+        if self._remap is None:
+            import ctypes
+
+            class _Plan(ctypes.Structure):
+                _fields_ = [("kind", ctypes.c_int32), ("m", ctypes.c_int32), ("long_thr", ctypes.c_int32),
+                            ("n_long", ctypes.c_int32), ("long_rows", ctypes.c_void_p)]
+
+            nrow, ncol = self.shape
+            kind, m, thr, long_rows = 0, 0, 0, None
+            if self.values.is_cuda and nrow > 0 and self.nnz > 0:
+                dev = self.device
+                if self.nnz == ncol and ncol % nrow == 0:          # GROUPS: m = ncol / nrow entries per row, identity columns
+                    mm = ncol // nrow
+                    if torch.equal(self.rowptr, torch.arange(0, self.nnz + 1, mm, device=dev, dtype=torch.int32)) and \
+                            torch.equal(self.colind, torch.arange(self.nnz, device=dev, dtype=torch.int32)):
+                        kind, m = 1, mm
+                if kind == 0 and self.nnz == nrow and nrow % ncol == 0:    # BROADCAST: one entry per row in column r / m
+                    mm = nrow // ncol
+                    if torch.equal(self.rowptr, torch.arange(nrow + 1, device=dev, dtype=torch.int32)) and \
+                            torch.equal(self.colind, torch.arange(nrow, device=dev, dtype=torch.int32) // mm):
+                        kind, m = 2, mm
+                if kind == 0:
+                    lens = self.rowptr[1:] - self.rowptr[:-1]
+                    # rows beyond twice the mean length (at least 16 entries) get whole waves: the lane-group-per-row path
+                    # then never walks a chain much longer than its average one
+                    thr = max(16, int(2.0 * self.nnz / nrow + 0.5))
+                    long_rows = torch.nonzero(lens > thr).flatten().to(torch.int32).contiguous()
+                    if long_rows.numel() == 0:
+                        long_rows = None
+            plan = _Plan(kind, m, thr if long_rows is not None else 0, 0 if long_rows is None else int(long_rows.numel()),
+                         None if long_rows is None else long_rows.data_ptr())
+            self._remap = (plan, long_rows)      # the list must outlive the plan
+        return self._remap[0]
 
     def transpose(self) -> "CsrOperator":
         """CSR of the transposed operator (built once, on first backward)."""
@@ -322,6 +362,26 @@ class _HipBackend:
                     _DTYPES[x.dtype], _stream(x),
                 )
         _native.check(rc, "dsw_spmm_csr")
+        return y
+
+    def remap(self, op, x, z=None, beta=0.0, out=None):
+        """Interpolation-pooling product ``op @ x (+ beta z)`` through ``dsw_remap_csr`` with the operator's remap plan."""
+        import ctypes
+
+        lib = _native.load()
+        B, v_in, C = x.shape
+        assert v_in == op.shape[1]
+        y = out if out is not None else torch.empty((B, op.shape[0], C), dtype=x.dtype, device=x.device)
+        ldx, ldy = row_stride(x), row_stride(y)
+        ldz = C if z is None else row_stride(z)
+        assert ldx is not None and ldy is not None and ldz is not None and y.shape == (B, op.shape[0], C)
+        assert z is None or z.shape == y.shape
+        plan = op.remap_plan()
+        with torch.cuda.device(x.device):
+            rc = lib.dsw_remap_csr(ctypes.addressof(plan), op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(),
+                                   op.shape[0], op.shape[1], op.nnz, x.data_ptr(), ldx, y.data_ptr(), ldy, B, C, _ptr(z), ldz,
+                                   beta, _DTYPES[x.dtype], _stream(x))
+        _native.check(rc, "dsw_remap_csr")
         return y
 
     def cheb_basis(self, op, x, K):
@@ -816,18 +876,25 @@ class _RezeroResidualFn(torch.autograd.Function):
         return gc, (g if ctx.needs_input_grad[1] else None), (gw if ctx.needs_input_grad[2] else None), None
 
 
+def _remap(be, op, x, z=None, beta=0.0, out=None):
+    """The remap product on the backend: the planned entry point of the HIP library, the plain product of a test backend."""
+    if hasattr(be, "remap"):
+        return be.remap(op, x, z=z, beta=beta, out=out)
+    return be.spmm(op, x, z=z, beta=beta, out=out)
+
+
 class _RemapFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, op, out):
         be = _backend_for(x)
         ctx.op = op
         ctx.be = be
-        return be.spmm(op, x if _rows_ok(x) else x.contiguous(), out=out.t if out is not None else None)
+        return _remap(be, op, x if _rows_ok(x) else x.contiguous(), out=out.t if out is not None else None)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
-        return ctx.be.spmm(ctx.op.transpose(), dy if _rows_ok(dy) else dy.contiguous()), None, None
+        return _remap(ctx.be, ctx.op.transpose(), dy if _rows_ok(dy) else dy.contiguous()), None, None
 
 
 class _RemapForkFn(torch.autograd.Function):
@@ -840,7 +907,7 @@ class _RemapForkFn(torch.autograd.Function):
         be = _backend_for(x)
         ctx.op = op
         ctx.be = be
-        return x.view_as(x), be.spmm(op, x if _rows_ok(x) else x.contiguous())
+        return x.view_as(x), _remap(be, op, x if _rows_ok(x) else x.contiguous())
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -849,9 +916,9 @@ class _RemapForkFn(torch.autograd.Function):
             return g_x, None
         dy = dy if _rows_ok(dy) else dy.contiguous()
         if g_x is None:
-            return ctx.be.spmm(ctx.op.transpose(), dy), None
+            return _remap(ctx.be, ctx.op.transpose(), dy), None
         g_x = g_x if _rows_ok(g_x) else g_x.contiguous()
-        return ctx.be.spmm(ctx.op.transpose(), dy, z=g_x, beta=1.0), None
+        return _remap(ctx.be, ctx.op.transpose(), dy, z=g_x, beta=1.0), None
 
 
 class _ConcatInPlaceFn(torch.autograd.Function):

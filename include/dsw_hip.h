@@ -78,15 +78,19 @@ const char* dsw_strerror(int code);
  * dsw_amd/_native.py refuses a flagged library unless it was asked for by path (DSW_HIP_LIB). */
 int dsw_build_flags(void);
 
-/* Launch tracing: per-role durations of the launches the entry points make, from HIP events recorded on the launch stream
- * at the role boundaries (start of an entry point, end of each of its roles).  A benchmark opens a trace, runs steps the
- * ordinary way (eagerly: nothing is recorded inside a stream capture) and reads the intervals back - every role timed
- * INSIDE the step, with the caches in the state the step leaves them, which back-to-back calls of one kernel are not
- * (isolated timings were 11-14 % off the in-step durations).  One trace at a time, process-wide.
- *   dsw_trace_begin(capacity)  allocates `capacity` events (an entry point uses 2-4) and starts recording.
- *   dsw_trace_end(...)         waits for the recorded events, writes up to `cap` intervals (role, three role-specific
- *                              integers, microseconds) in recording order and returns the number of intervals (> cap:
- *                              truncated), DSW_ERR_WORKSPACE if the event capacity overflowed, another error code on failure.
+/* Launch tracing: per-role durations of the kernels the entry points launch.  While a trace is open every kernel of the
+ * library is launched with a start / stop event pair attached to its own dispatch (hipExtLaunchKernelGGL: the timestamps of
+ * the kernel's completion signal, what a profiler's kernel trace reports - no marker packets between the kernels), and the
+ * entry points note on the host which role the kernels belong to.  A benchmark opens a trace, runs steps the ordinary way
+ * (eagerly: nothing is recorded inside a stream capture) and reads the roles back - every kernel timed INSIDE the step, with
+ * the caches in the state the step leaves them, which back-to-back calls of one kernel are not (isolated timings
+ * were 11-14 % off the in-step durations).  One trace at a time, process-wide.
+ *   dsw_trace_begin(capacity)  room for `capacity` kernel launches; starts recording.
+ *   dsw_trace_end(...)         waits for the recorded kernels and writes up to `cap` role records in launch order: role,
+ *                              three role-specific integers, us = SUM of the role's kernel durations, span_us = start of its
+ *                              first to end of its last kernel, n_kernels, and the launch-site name of its longest kernel
+ *                              (names: cap x name_stride chars).  Returns the number of records (> cap: truncated),
+ *                              DSW_ERR_WORKSPACE if the capacity overflowed, another error code on failure.
  * aux: conv roles (V, Fin, Fout) [recurrences: (V, C, K)], SPMM roles (rows_out, rows_in, C), elementwise (n, kind, 0). */
 #define DSW_ROLE_SPMM 1            /* dsw_spmm_csr / dsw_spmm_csr_ld: one product (interpolation pooling and its transpose) */
 #define DSW_ROLE_SPMM2 2           /* dsw_spmm2_fused called directly */
@@ -104,7 +108,8 @@ int dsw_build_flags(void);
 #define DSW_ROLE_BWD_FUSED 14      /* dgrad + adjoint recurrence in one launch (dY -> dX) */
 #define DSW_ROLE_BASIS_DUAL 15     /* mix-first backward: Chebyshev basis of dY under L^T (on the output channels) */
 int dsw_trace_begin(int capacity);
-int dsw_trace_end(int32_t* roles, int32_t* aux0, int32_t* aux1, int32_t* aux2, float* us, int cap);
+int dsw_trace_end(int32_t* roles, int32_t* aux0, int32_t* aux1, int32_t* aux2, float* us, float* span_us, int32_t* n_kernels,
+                  char* names, int name_stride, int cap);
 
 /* Sparse operator times node-major activations with a fused axpby epilogue, per sample:
  *     Y[b,r,:] = alpha * sum_p vals[p] * X[b,colind[p],:] + beta * Z[b,r,:] + gamma * Z2[b,r,:]
@@ -128,6 +133,30 @@ int dsw_spmm_csr(const int32_t* rowptr, const int32_t* colind, const float* vals
 int dsw_spmm_csr_ld(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t v_out, int64_t v_in,
                     int64_t nnz, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t B, int64_t C, float alpha,
                     const void* Z, int64_t ldz, float beta, const void* Z2, float gamma, int dtype, dsw_stream_t stream);
+
+/* Plan of an interpolation-pooling (remap) matrix, built once per matrix on the host (dsw_amd/functional.py:
+ * CsrOperator.remap_plan) - what lets RemapBlock's product (layers.py:956-964) and its transposed backward skip the generic
+ * CSR walk:
+ *   kind 1 (GROUPS)     every row has exactly m entries, in columns m r .. m r + m - 1 (v_in = m v_out): the pooling between two
+ *                       levels of a regular hierarchy (HEALPix nested order: 4 children per parent), and the transposed
+ *                       unpooling.  Pure streaming: m row loads, one store, weights = the CSR values (any values).
+ *   kind 2 (BROADCAST)  every row has exactly one entry, in column r / m (v_out = m v_in): the unpooling of such a hierarchy
+ *                       and the transposed pooling.  One row load, m stores.
+ *   kind 0 (GENERIC)    any matrix (pooling between different samplings): the rows with more than long_thr entries (polar
+ *                       cells of a cross-sampling matrix: up to hundreds) are LISTED, each gets whole waves; the launch needs
+ *                       no scan of the row lengths and the lane-group-per-row path never walks a long row. */
+typedef struct dsw_remap_plan {
+    int32_t kind, m;
+    int32_t long_thr, n_long;
+    const int32_t* long_rows;   /* device pointer, n_long rows (kind 0); NULL otherwise */
+} dsw_remap_plan;
+
+/* Y[b,r,:] = sum_p vals[p] X[b,colind[p],:] + beta Z[b,r,:] for a remap matrix with a plan (NULL plan = dsw_spmm_csr_ld with
+ * alpha = 1): row strides ldx / ldy / ldz as in dsw_spmm_csr_ld, Z optional.  The CSR arrays are always passed (kind 1 / 2 read
+ * only `vals`); a regular plan whose m does not fit the shape / nnz returns DSW_ERR_BAD_ARG. */
+int dsw_remap_csr(const dsw_remap_plan* plan, const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t v_out,
+                  int64_t v_in, int64_t nnz, const void* X, int64_t ldx, void* Y, int64_t ldy, int64_t B, int64_t C,
+                  const void* Z, int64_t ldz, float beta, int dtype, dsw_stream_t stream);
 
 /* Two applications of one square operator A (V x V) in a single launch, per sample:
  *     Y1 = a1 * (A U)  + b1 * Z1 + d1 * Z1b

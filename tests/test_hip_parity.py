@@ -316,6 +316,10 @@ def test_spmm_rows_with_hundreds_of_entries(dt, C, B):
     F_._HIP.spmm(op, x, 2.0, zc, -1.0, z2, 0.5, out=zc)       # in place (Y aliases Z)
     assert torch.equal(zc, y)
     assert torch.equal(F_._HIP.spmm(op, x, 2.0, z, -1.0, z2, 0.5), y)   # deterministic
+    # the planned remap entry point lists the long rows instead of scanning for them (other threshold, other grid): same sums
+    assert op.remap_plan().kind == 0 and op.remap_plan().n_long >= 4
+    assert orc.max_rel_err(F_._HIP.remap(op, x, z=z, beta=-1.0).float(),
+                           orc.remap_f64(m.indptr, m.indices, m.data, (vo, vi), x.float().cpu().numpy()) - f64(z)) <= tol
     xt = torch.from_numpy(recipes.rand(4, (B, vo, C))).to(DEV).to(dt)
     yt = F_._HIP.spmm(op.transpose(), xt)
     ref_t = orc.remap_backward_f64(m.indptr, m.indices, m.data, (vo, vi), xt.float().cpu().numpy())
@@ -655,6 +659,12 @@ def test_streaming_gemm_balanced_decomposition(N, Kd, Fout, epi):
     assert torch.equal(y1, y2)
     assert orc.max_rel_err(y1, ref.numpy()) <= TOL_F64
     assert orc.max_rel_err(y0, ref.numpy()) <= TOL_F64
+    # stress of the release ordering: a flag that became visible before its piece would show up as a run that
+    # differs from the others - 25 back-to-back launches, other data through the L2s in between
+    for i in range(25):
+        if i % 5 == 0:
+            x.mul_(0.5); run(ws); x.copy_(x_keep)
+        assert torch.equal(run(ws), y1), i
 
 
 def test_config_driven_training_driver(tmp_path):

@@ -1,0 +1,156 @@
+"""Round-5 additions, GPU only: launch tracing (dsw_trace_begin / dsw_trace_end), the N = 1 step with the N > 1 gradient
+handling, the refusal of diagnostics builds."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_launch_trace_reports_the_roles_of_a_step():
+    """One ConvCheb + one pooling forward / backward under a trace: the roles the entry points ran come back with plausible
+    durations, nothing is recorded once the trace is closed, and a second trace can be opened."""
+    from dsw_amd import _native, sphere
+    from modules.layers import ConvCheb, GeneralAvgPool, prepare_torch_laplacian
+
+    g = sphere.SphereHealpix(16, nest=True, k=8)
+    layer = ConvCheb(32, 64, 3, laplacian=prepare_torch_laplacian(g.L, lmax=1.9)).to(DEV)
+    pool = GeneralAvgPool(sphere.healpix_pool_matrices(16, nest=True)[0]).to(DEV)
+    x = torch.randn(4, 3072, 32, device=DEV, requires_grad=True)
+
+    def step():
+        y = layer(x)
+        z, _ = pool(y)
+        z.sum().backward()
+
+    step()
+    torch.cuda.synchronize()
+    for _ in range(2):
+        with _native.LaunchTrace(1024) as tr:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+        roles = {}
+        for role, a0, a1, a2, us in tr.intervals:
+            roles.setdefault(role, []).append((a0, a1, a2, us))
+        assert "spmm" in roles and len(roles["spmm"]) == 6                      # pooling forward + transposed backward
+        assert {(r[0], r[1], r[2]) for r in roles["spmm"]} == {(768, 3072, 64), (3072, 768, 64)}
+        fwd = roles.get("fwd_one_launch") or roles.get("basis_fwd")
+        assert fwd and len(fwd) == 3
+        assert "basis_adj" in roles or "bwd_fused" in roles
+        for rs in roles.values():
+            for _a0, _a1, _a2, us in rs:
+                assert 0.5 < us < 5000.0, rs
+    lib = _native.load()
+    assert lib.dsw_trace_end(None, None, None, None, None, None, None, None, 0, 0) < 0               # no trace open
+    assert lib.dsw_build_flags() == 0 or os.environ.get("DSW_HIP_LIB")
+
+
+def _bench(*extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                          "--min-timed-ms", "1000", "--no-cpu-baseline", *extra],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_n1_runs_the_n_gt_1_step_and_agrees():
+    """`--gpus 1 --grad-handling bucket` times the step every N > 1 rank runs (gradients in one flat bucket, weight-gradient
+    kernels adding into it) without the exchange: it must cost what the default N = 1 step costs (3 %), so that the first
+    scaling curve compares like with like; and the in-step role durations of the line add up to the
+    step (item 1)."""
+    a = _bench("--no-roofline")
+    b = _bench("--grad-handling", "bucket")
+    assert "bucket" in b["config"]["grad_handling"] and "autograd" in a["config"]["grad_handling"]
+    assert abs(a["ms_per_step"] - b["ms_per_step"]) <= 0.03 * a["ms_per_step"], (a["ms_per_step"], b["ms_per_step"])
+    r = b["roofline"]
+    assert r["launch_timing"].startswith("in-step"), r["launch_timing"]
+    assert 0.95 <= r["in_step_sum_vs_ms_per_step"] <= 1.05, r["in_step_sum_vs_ms_per_step"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+
+
+def _op_from_scipy(m):
+    from dsw_amd import functional as F_
+    from oracle import cheb_oracle as orc
+
+    return F_.CsrOperator.from_sparse_coo(orc.coo_from_scipy(m).float().to(DEV))
+
+
+@pytest.mark.parametrize("dt,C,B,m", [(torch.float32, 128, 8, 4), (torch.float32, 32, 3, 4), (torch.float32, 256, 1, 4),
+                                       (torch.float32, 64, 5, 3), (torch.float32, 16, 2, 7), (torch.bfloat16, 64, 4, 4),
+                                       (torch.float32, 20, 2, 4), (torch.float32, 33, 2, 4)])
+def test_remap_regular_hierarchy_kernels_equal_the_generic_product(dt, C, B, m):
+    """RemapBlock products of a regular hierarchy (m children per parent in consecutive rows: HEALPix nested) through the
+    planned entry point (`dsw_remap_csr`: streaming kernels without any CSR walk) - pooling (GROUPS), unpooling (BROADCAST)
+    and both transposes, with and without the fork's epilogue operand, dense and as channel slices of wider tensors - are
+    BIT-identical to the generic CSR product and match the fp64 oracle.  Arbitrary weights; an unaligned channel count
+    (33) takes the generic kernel through the same entry point."""
+    import numpy as np
+    from scipy import sparse
+    from dsw_amd import functional as F_
+    from oracle import cheb_oracle as orc
+
+    rng = np.random.default_rng(3)
+    vc = 5 * 77
+    vf = vc * m
+    rows = np.repeat(np.arange(vc), m)
+    pool = sparse.csr_matrix((rng.random(vf).astype(np.float32) + 0.1, (rows, np.arange(vf))), shape=(vc, vf))
+    unpool = sparse.csr_matrix((rng.random(vf).astype(np.float32) + 0.1, (np.arange(vf), rows)), shape=(vf, vc))
+    tol = 2e-6 if dt == torch.float32 else 1e-2
+    for mat, kind in ((pool, 1), (unpool, 2)):
+        op = _op_from_scipy(mat)
+        for o, k in ((op, kind), (op.transpose(), 3 - kind)):
+            plan = o.remap_plan()
+            assert (plan.kind, plan.m) == (k, m), (plan.kind, plan.m, k, m)
+            x = torch.randn(B, o.shape[1], C, device=DEV).to(dt)
+            z = torch.randn(B, o.shape[0], C, device=DEV).to(dt)
+            y = F_._HIP.remap(o, x)
+            assert torch.equal(y, F_._HIP.spmm(o, x))
+            yz = F_._HIP.remap(o, x, z=z, beta=1.0)
+            assert torch.equal(yz, F_._HIP.spmm(o, x, 1.0, z, 1.0))
+            sc = o.values.cpu().double().numpy()
+            msc = sparse.csr_matrix((sc, o.colind.cpu().numpy(), o.rowptr.cpu().numpy()), shape=o.shape)
+            ref = np.stack([msc @ x[b].float().cpu().double().numpy() for b in range(B)])
+            assert orc.max_rel_err(y.float(), ref) <= tol
+            if (C * x.element_size()) % 16 == 0:
+                wide_x = torch.randn(B, o.shape[1], C + 16, device=DEV).to(dt)
+                wide_y = torch.zeros(B, o.shape[0], 2 * C + 8, device=DEV).to(dt)
+                pad = 16 // x.element_size()
+                F_._HIP.remap(o, wide_x[..., pad:pad + C], out=wide_y[..., C:2 * C])
+                assert torch.equal(wide_y[..., C:2 * C], F_._HIP.spmm(o, wide_x[..., pad:pad + C].contiguous()))
+                assert float(wide_y[..., :C].abs().max()) == 0.0 and float(wide_y[..., 2 * C:].abs().max()) == 0.0
+
+
+def test_remap_plan_of_the_healpix_hierarchy_and_of_a_cross_sampling_matrix():
+    """The plans the product paths get: HEALPix nested pooling / unpooling = the regular kinds; a conservative matrix between
+    two different samplings = generic with its long (polar) rows listed - and the listed-rows launch equals the scanning
+    launch bit for bit, with and without the epilogue operand, on few samples and many."""
+    import numpy as np
+    from dsw_amd import functional as F_, sphere
+    from oracle import cheb_oracle as orc
+
+    pool_m, unpool_m = sphere.healpix_pool_matrices(8, nest=True)
+    po, uo = _op_from_scipy(pool_m), _op_from_scipy(unpool_m)
+    assert (po.remap_plan().kind, po.remap_plan().m) == (1, 4) and (uo.remap_plan().kind, uo.remap_plan().m) == (2, 4)
+    assert po.transpose().remap_plan().kind == 2 and uo.transpose().remap_plan().kind == 1
+    fine = sphere.SphereEquiangular(nlat=40, nlon=80, k=8)
+    coarse = sphere.SphereHealpix(4, nest=True, k=8)
+    pm, um = sphere.conservative_pool_matrices(fine.coords, coarse.coords)
+    for mat in (pm, um):
+        op = _op_from_scipy(mat)
+        for o in (op, op.transpose()):
+            plan = o.remap_plan()
+            lens = np.diff(o.rowptr.cpu().numpy())
+            assert plan.kind == 0
+            assert plan.n_long == int((lens > max(16, int(2.0 * o.nnz / o.shape[0] + 0.5))).sum())
+            for B in (1, 3, 8):
+                x = torch.randn(B, o.shape[1], 32, device=DEV)
+                z = torch.randn(B, o.shape[0], 32, device=DEV)
+                assert torch.equal(F_._HIP.remap(o, x), F_._HIP.spmm(o, x))
+                assert torch.equal(F_._HIP.remap(o, x, z=z, beta=1.0), F_._HIP.spmm(o, x, 1.0, z, 1.0))
