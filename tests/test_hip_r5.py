@@ -130,7 +130,7 @@ def test_remap_regular_hierarchy_kernels_equal_the_generic_product(dt, C, B, m):
 def test_remap_plan_of_the_healpix_hierarchy_and_of_a_cross_sampling_matrix():
     """The plans the product paths get: HEALPix nested pooling / unpooling = the regular kinds; a conservative matrix between
     two different samplings = generic with its long (polar) rows listed - and the listed-rows launch equals the scanning
-    launch bit for bit, with and without the epilogue operand, on few samples and many."""
+    launch to rounding, with and without the epilogue operand, on few samples and many."""
     import numpy as np
     from dsw_amd import functional as F_, sphere
     from oracle import cheb_oracle as orc
