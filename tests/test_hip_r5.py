@@ -152,5 +152,7 @@ def test_remap_plan_of_the_healpix_hierarchy_and_of_a_cross_sampling_matrix():
             for B in (1, 3, 8):
                 x = torch.randn(B, o.shape[1], 32, device=DEV)
                 z = torch.randn(B, o.shape[0], 32, device=DEV)
-                assert torch.equal(F_._HIP.remap(o, x), F_._HIP.spmm(o, x))
-                assert torch.equal(F_._HIP.remap(o, x, z=z, beta=1.0), F_._HIP.spmm(o, x, 1.0, z, 1.0))
+                # (rows between the plan's threshold and the scan's 64 entries are summed by a wave here, by a lane group
+                # there: equal to rounding, not bit for bit)
+                assert orc.max_rel_err(F_._HIP.remap(o, x), F_._HIP.spmm(o, x).cpu().numpy()) <= 1e-6
+                assert orc.max_rel_err(F_._HIP.remap(o, x, z=z, beta=1.0), F_._HIP.spmm(o, x, 1.0, z, 1.0).cpu().numpy()) <= 1e-6
