@@ -75,6 +75,9 @@ def parse():
                          "kernels add into - what every N > 1 run does; 'autograd' = zero_grad(set_to_none) + autograd's tensors; "
                          "'auto' = bucket when N > 1, autograd when N = 1.  `--gpus 1 --grad-handling bucket` runs the N > 1 step "
                          "without the exchange, so that a scaling curve compares like with like")
+    ap.add_argument("--kernel-trace-child", type=int, default=0,
+                    help="internal (graph_kernel_durations): build, capture, warm up, replay this many steps and exit - the "
+                         "process rocprofv3 traces to time the kernels inside the replayed graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--zero-inputs", action="store_true",
@@ -175,34 +178,162 @@ def _traffic(traffic_key, leg):
         return None
 
 
+def _kernel_base(name):
+    """Identifier of a kernel from a rocprofv3 name ("void (anonymous namespace)::spmm1_dma_kernel<false, 3>(Args)") or from a
+    launch-site expression of the library ("(spmm1_dma_kernel<BF16, NST>)")."""
+    n = name.strip()
+    if n.startswith("void "):
+        n = n[5:]
+    n = n.lstrip("(").strip()
+    cut = len(n)
+    for ch in "<(":
+        i = n.find(ch, 1 if n.startswith("(") else 0)
+        if i > 0:
+            cut = min(cut, i)
+    n = n[:cut]
+    while n.startswith("(anonymous namespace)::"):
+        n = n[len("(anonymous namespace)::"):]
+    return n.split("::")[-1].strip(" )")
+
+
 def trace_steps(step_fn, n_steps, warm=5, capacity=1 << 15):
-    """Per-role KERNEL durations inside running steps (include/dsw_hip.h: dsw_trace_begin / dsw_trace_end): while `step_fn`
-    - the very step the timed region replays - runs eagerly, back to back, the library launches each of its kernels with a
-    start / stop event pair attached to the dispatch (the timestamps a profiler's kernel trace reports; nothing extra on the
-    stream) and notes which role of which entry point the kernel belongs to.  Every kernel is timed in the cache state the
-    step leaves it, which isolated back-to-back calls of one kernel are not.  Returns {(role, aux0, aux1, aux2): {calls_per_step, avg_us,
-    median_us, us_per_step}}."""
+    """ORDER, ROLE and eager durations of the kernels of a step (include/dsw_hip.h: dsw_trace_begin / dsw_trace_end): while
+    `step_fn` - the very step the timed region replays - runs eagerly, the library launches each of its kernels with a start /
+    stop event pair attached to the dispatch and notes which role of which entry-point call the kernel belongs to.
+    Returns (roles, sequence): roles = {(role, aux0, aux1, aux2): {calls_per_step, avg_us, ...}} from the EAGER launches
+    (kernels launched eagerly carry heavier fences and run ~10 % longer than the same kernels replayed from a graph);
+    sequence = the library kernels of ONE step in launch order: [(call index within the step, role key, kernel base name)] -
+    what graph_kernel_durations() folds a rocprofv3 trace of the replayed graph with."""
     from dsw_amd import _native
 
     for _ in range(warm):
         step_fn()
     torch.cuda.synchronize()
+    per_step = []
     with _native.LaunchTrace(capacity) as tr:
         for _ in range(n_steps):
             step_fn()
         torch.cuda.synchronize()
+    kernels = tr.kernels
+    # split into steps: every step launches the same kernel sequence
+    L, rem = divmod(len(kernels), n_steps)
+    if rem or L == 0:
+        raise RuntimeError("launch trace: %d kernels over %d steps" % (len(kernels), n_steps))
+    seq0 = None
     agg = {}
-    for (role, a0, a1, a2, us), (span, nk, name) in zip(tr.intervals, tr.detail):
-        e = agg.setdefault((role, a0, a1, a2), {"us": [], "span": [], "nk": nk, "name": name})
-        e["us"].append(us)
-        e["span"].append(span)
+    for sidx in range(n_steps):
+        chunk = kernels[sidx * L:(sidx + 1) * L]
+        c0 = chunk[0][0]
+        seq = [(c - c0, (role, a0, a1, a2), _kernel_base(name)) for c, role, a0, a1, a2, _us, name in chunk]
+        if seq0 is None:
+            seq0 = seq
+        elif seq != seq0:
+            raise RuntimeError("launch trace: the steps did not launch identical kernel sequences")
+        calls = {}
+        for (c, key, _b), rec in zip(seq, chunk):
+            calls.setdefault((c, key), []).append(rec)
+        for (c, key), recs in calls.items():
+            e = agg.setdefault(key, {"us": [], "nk": len(recs), "name": max(recs, key=lambda r: r[5])[6]})
+            e["us"].append(sum(r[5] for r in recs))
     out = {}
     for k, e in agg.items():
         v = sorted(e["us"])
         out[k] = {"calls_per_step": len(v) / n_steps, "avg_us": sum(v) / len(v), "median_us": v[len(v) // 2],
-                  "us_per_step": sum(v) / n_steps, "span_avg_us": sum(e["span"]) / len(v), "kernels": e["nk"],
-                  "longest_kernel": e["name"]}
-    return out
+                  "us_per_step": sum(v) / n_steps, "kernels": e["nk"], "longest_kernel": e["name"],
+                  "timing": "EAGER launches (dsw_trace): ~10 % above the replayed graph's kernels"}
+    return out, seq0
+
+
+def graph_kernel_durations(seq, n_steps=40, timeout=420):
+    """Durations of the step's kernels INSIDE the replayed HIP graph: this script is run once more as a child under
+    `rocprofv3 --kernel-trace` (same arguments + --kernel-trace-child N: build, capture, warm up, replay N steps, exit), the
+    trace is sorted by start time, and the library kernels of its last N steps - identified by the launch order `seq` the
+    eager trace recorded, verified name by name - are averaged per position of the step.  Returns (roles, info) with
+    roles = {(role, aux0, aux1, aux2): {calls_per_step, avg_us, us_per_step, kernels}} or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rocprof is None:
+        return None, "rocprofv3 not found"
+    if any(k.startswith("ROCP") or k.startswith("ROCPROFILER") for k in os.environ):
+        return None, "already running under a profiler"
+    tmp = tempfile.mkdtemp(prefix="dsw_kt_", dir="/tmp")
+    try:
+        argv = [a for a in sys.argv[1:]]
+        cmd = ["timeout", "-k", "10", str(int(timeout)), rocprof, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "kt",
+               "--", sys.executable, os.path.abspath(__file__), *argv, "--kernel-trace-child", str(n_steps),
+               "--no-roofline", "--no-cpu-baseline"]
+        env = dict(os.environ, TMPDIR="/tmp")
+        proc = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
+        files = glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True)
+        if not files:
+            return None, "rocprofv3 left no kernel trace (exit code %s): %s" % (proc.returncode, (proc.stderr or "")[-300:])
+        rows = []
+        for f in files:
+            with open(f, newline="") as fh:
+                rd = csv.DictReader(fh)
+                keys = {k.lower(): k for k in (rd.fieldnames or [])}
+                kn, ks, ke = keys.get("kernel_name"), keys.get("start_timestamp"), keys.get("end_timestamp")
+                if not (kn and ks and ke):
+                    return None, "unexpected columns in the kernel trace: %s" % (rd.fieldnames,)
+                for r in rd:
+                    rows.append((int(r[ks]), int(r[ke]), r[kn]))
+        rows.sort()
+        bases = {b for _c, _k, b in seq}
+        lib = [(i, _kernel_base(nm)) for i, (_s, _e, nm) in enumerate(rows)]
+        lib = [(i, b) for i, b in lib if b in bases]
+        L = len(seq)
+        if len(lib) < n_steps * L:
+            return None, "the trace holds %d library kernels, expected at least %d" % (len(lib), n_steps * L)
+        tail = lib[-n_steps * L:]
+        want = [b for _c, _k, b in seq]
+        for st in range(n_steps):
+            got = [b for _i, b in tail[st * L:(st + 1) * L]]
+            if got != want:
+                bad = next(j for j in range(L) if got[j] != want[j])
+                return None, "kernel order of the replayed graph differs from the eager trace at position %d (%s vs %s)" % (
+                    bad, got[bad], want[bad])
+        pos_us = [0.0] * L
+        for st in range(n_steps):
+            for j in range(L):
+                s0, e0, _nm = rows[tail[st * L + j][0]]
+                pos_us[j] += (e0 - s0) * 1e-3 / n_steps
+        calls = {}
+        for j, (c, key, _b) in enumerate(seq):
+            calls.setdefault((c, key), []).append(pos_us[j])
+        roles = {}
+        for (c, key), durs in calls.items():
+            e = roles.setdefault(key, {"sum": 0.0, "n": 0, "nk": len(durs)})
+            e["sum"] += sum(durs)
+            e["n"] += 1
+        out = {k: {"calls_per_step": float(e["n"]), "avg_us": e["sum"] / e["n"], "us_per_step": e["sum"], "kernels": e["nk"],
+                   "timing": "in-graph kernel durations (rocprofv3 kernel trace of the replayed step graph, %d steps)" % n_steps}
+               for k, e in roles.items()}
+        # everything the graph ran in those steps (torch kernels included), and the wall time they spanned
+        first, last = tail[0][0], len(rows) - 1
+        all_us = sum((rows[i][1] - rows[i][0]) for i in range(first, last + 1)) * 1e-3 / n_steps
+        span_us = (rows[last][1] - rows[first][0]) * 1e-3 / n_steps
+        other = {}
+        libset = {i for i, _b in tail}
+        for i in range(first, last + 1):
+            if i not in libset:
+                b = _kernel_base(rows[i][2])
+                o = other.setdefault(b, [0, 0.0])
+                o[0] += 1
+                o[1] += (rows[i][1] - rows[i][0]) * 1e-3
+        info = {"steps": n_steps, "library_kernels_per_step": L, "all_kernels_us_per_step": round(all_us, 2),
+                "span_us_per_step": round(span_us, 2),
+                "other_kernels": sorted(({"kernel": b, "calls_per_step": round(c / n_steps, 2), "us_per_step": round(t / n_steps, 2)}
+                                         for b, (c, t) in other.items()), key=lambda d: -d["us_per_step"])[:8]}
+        return out, info
+    except Exception as exc:  # noqa: BLE001 - any failure: the caller keeps the eager durations and says so
+        return None, "%s: %s" % (type(exc).__name__, exc)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced=None, ms_per_step=None):
@@ -279,6 +410,8 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
                   4: "mix-first (recurrence on the output channels)"}
     fwd_rec_in_step = fwd_path in (0, 1, 2)
     traced = traced or {}
+    IN = next((v["timing"] for v in traced.values() if "timing" in v), "in-step kernel durations (dsw_trace)")
+    ISO = "ISOLATED leg: median of 3 regions of %d back-to-back calls" % steps
 
     def tr(role, a0, a1, a2):
         return traced.get((role, a0, a1, a2))
@@ -311,7 +444,7 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
     def entry(role, kernels, sec, nbytes, calls, extra=None):
         d = {"role": role, "kernels": kernels, "avg_us": round(sec * 1e6, 2), "calls_per_step": calls,
              "algorithmic_bytes": int(nbytes), "achieved_GBs": round(nbytes / sec / 1e9, 1),
-             "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4), "timing": "in-step kernel durations (dsw_trace)"}
+             "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4), "timing": IN}
         d.update(extra or {})
         return d
 
@@ -390,7 +523,6 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
                 "bytes_moved": None if m is None else int(m["hbm_bytes_per_call"]),
                 "frac_counter": None if m is None else round(m["hbm_bytes_per_call"] / sec / 1e9 / HBM_PEAK_GBS, 4)}
 
-    IN, ISO = "in-step kernel durations (dsw_trace: start / stop events attached to each dispatch)", "ISOLATED leg: median of 3 regions of %d back-to-back calls" % steps
     out = {
         "bound": "hbm",
         "kernel": ("SpMM recurrence launches of a timed step: " +
@@ -408,8 +540,7 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
                            "these launches (2 x FETCH_SIZE + WRITE_SIZE, tools/pmc_traffic.sh); a committed measurement, not "
                            "read in this run"),
         "bytes_per_launch": int(b_in / n_in), "avg_launch_us": round(t_in / n_in * 1e6, 2), "launches": n_in,
-        "launch_timing": (IN + ": the step the timed region replays, run eagerly back to back with the library's role "
-                          "markers on the launch stream" if have_trace and adj_s_iso is None else ISO),
+        "launch_timing": (IN if have_trace and adj_s_iso is None else ISO),
         "definition": "achieved = SURVEY 8d algorithmic bytes of these launches / their in-step time; frac_counter = measured "
                       "HBM bytes / the same time / 8 TB/s",
         "forward_recurrence": dict(rec_entry("fwd", _k1, False, n_fwd, fwd_s, fwd_b,
@@ -476,7 +607,7 @@ def pooling_leg(model, run_forward, steps, traffic_key=None, pmc_leg=None, trace
             # in-step: the product timed inside the running step (products of equal shape - a pooling and the transposed
             # unpooling of the same level - share one entry of the trace: their mean)
             sec = hit["avg_us"] * 1e-6
-            e["timing"] = "in-step kernel durations (dsw_trace), mean over the step's products of this shape"
+            e["timing"] = hit.get("timing", "in-step") + "; mean over the step's products of this shape"
         else:
             for _ in range(3):
                 F_.sparse_remap(o, t)
@@ -542,7 +673,7 @@ def mfma_leg(layer, x, T, steps, in_step=None):
     how = "ISOLATED leg (the step does not launch the stand-alone channel mix for this layer): %d back-to-back calls" % steps
     if in_step is not None:      # the step launches this GEMM: its in-step duration
         avg_s = in_step["avg_us"] * 1e-6
-        how = "in-step kernel durations (dsw_trace)"
+        how = in_step.get("timing", "in-step kernel durations")
     flops = 2.0 * N * Fin * K * Fout
     peak = MFMA_PEAK_TFLOPS["bf16" if bf16 else "f32"]
     ach = flops / avg_s / 1e12
@@ -999,6 +1130,13 @@ def main():
     # warm-up: the W steps asked for, plus one untimed pass of exactly the launch sequence the timed region uses
     # (the first replays of a freshly instantiated multi-step graph are slower than its steady state)
     run_steps(args.warmup)
+    if args.kernel_trace_child > 0:      # traced child: exactly these replays are the tail of the kernel trace
+        run_steps(args.kernel_trace_child)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     probe = timed_region(args.steps)
     # The contract times exactly K steps; K steps of this workload are a ~10 ms region at the driver's K = 20, short
     # enough for a single clock-ramp or scheduling hiccup to move the number by 10-20 %.  So the region is repeated
@@ -1096,12 +1234,27 @@ def main():
         if not args.no_roofline:
             # per-role durations inside running steps: the step of the timed region, launched eagerly back to back with the
             # library's role markers on the launch stream (a graph replay cannot carry them)
-            traced = None
+            traced = seq = None
+            trace_note = None
             try:
-                traced = trace_steps(lambda: (step(), sync_grads()), 10 if args.workload == "unet" else 40)
+                traced, seq = trace_steps(lambda: (step(), sync_grads()), 5 if args.workload == "unet" else 10)
             except Exception as exc:  # noqa: BLE001 - the line then says its legs are isolated
                 print("bench: launch trace unavailable (%s: %s); roofline legs are isolated timings" % (type(exc).__name__, exc),
                       file=sys.stderr)
+            graph_info = None
+            if traced is not None and graph is not None:
+                n_child = 10 if args.workload == "unet" else 40
+                n_child = max(GRAPH_STEPS, n_child // GRAPH_STEPS * GRAPH_STEPS) if graph_multi is not None else n_child
+                in_graph, graph_info = graph_kernel_durations(seq, n_child)
+                if in_graph is not None:
+                    for k, v in in_graph.items():
+                        v["eager_avg_us"] = round(traced[k]["avg_us"], 2) if k in traced else None
+                        v["longest_kernel"] = traced[k]["longest_kernel"] if k in traced else None
+                    traced = in_graph
+                else:
+                    trace_note = "in-graph durations unavailable (%s): EAGER kernel durations, ~10 %% above the replayed graph" % graph_info
+                    graph_info = None
+                    print("bench: " + trace_note, file=sys.stderr)
             out["roofline"] = roofline_leg(rl_layer, rl_x, max(10, args.steps), 5, traffic_key=tkey, traced=traced,
                                            ms_per_step=ms if args.workload in ("ns", "c3") else None)
             if rl_what is not None:
@@ -1109,11 +1262,15 @@ def main():
             if traced is not None:
                 tot = sum(v["us_per_step"] for v in traced.values())
                 out["roofline"]["traced_step"] = {
-                    "what": "every role the library's entry points ran in one step (eager, back to back), us per step",
+                    "what": "every role the library's entry points ran in one step, us per step: order and roles from the eager "
+                            "launch trace (dsw_trace), durations " + ("from the rocprofv3 kernel trace of the replayed graph"
+                                                                      if graph_info is not None else "from the EAGER launches"),
+                    "note": trace_note, "graph": graph_info,
                     "sum_us": round(tot, 1), "vs_ms_per_step": round(tot / (ms * 1e3), 4),
                     "roles": sorted(({"role": k[0], "aux": list(k[1:]), "calls_per_step": round(v["calls_per_step"], 2),
                                       "avg_us": round(v["avg_us"], 2), "us_per_step": round(v["us_per_step"], 2),
-                                      "kernels": v["kernels"], "longest_kernel": v["longest_kernel"]}
+                                      "kernels": v["kernels"], "longest_kernel": v.get("longest_kernel"),
+                                      "eager_avg_us": v.get("eager_avg_us")}
                                      for k, v in traced.items()), key=lambda d: -d["us_per_step"])[:24]}
             if args.workload in ("unet", "c5"):
                 out["roofline"]["pooling"] = pooling_leg(model, lambda: model(x.detach()), max(10, args.steps), traffic_key=tkey,

@@ -185,50 +185,44 @@ int dsw_trace_begin(int capacity) {
     return DSW_OK;
 }
 
-int dsw_trace_end(int32_t* roles, int32_t* aux0, int32_t* aux1, int32_t* aux2, float* us, float* span_us, int32_t* n_kernels,
-                  char* names, int name_stride, int cap) {
+int dsw_trace_end(int32_t* call, int32_t* roles, int32_t* aux0, int32_t* aux1, int32_t* aux2, float* us, char* names,
+                  int name_stride, int cap) {
     std::lock_guard<std::mutex> lk(g_trace.mu);
     if (!g_trace.on.load()) return DSW_ERR_BAD_ARG;
     g_trace.on.store(false);
-    int out = 0, rc = DSW_OK;
+    int out = 0, rc = DSW_OK, n_call = 0;
     // kernels between two markers belong to the role of the closing marker; kernels launched outside every entry point's
     // markers (none today) are dropped at the next start marker
-    double sum_ms = 0.0;
-    int nk = 0;
-    float longest = -1.f;
-    const char* longest_name = nullptr;
-    hipEvent_t first = nullptr, last = nullptr;
-    for (const DswTraceRec& r : g_trace.rec) {
-        if (rc != DSW_OK) break;
-        if (r.role == -1) {
-            float ms = 0.f;
-            if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { rc = DSW_ERR_LAUNCH; break; }
-            sum_ms += ms; ++nk;
-            if (ms > longest) { longest = ms; longest_name = r.name; }
-            if (!first) first = r.e0;
-            last = r.e1;
-            continue;
-        }
-        if (r.role > 0 && nk > 0) {
-            float span = 0.f;
-            if (hipEventElapsedTime(&span, first, last) != hipSuccess) { rc = DSW_ERR_LAUNCH; break; }
-            if (out < cap && roles && us) {
-                roles[out] = r.role;
-                if (aux0) aux0[out] = r.a0;
-                if (aux1) aux1[out] = r.a1;
-                if (aux2) aux2[out] = r.a2;
-                us[out] = (float)(sum_ms * 1000.0);
-                if (span_us) span_us[out] = span * 1000.f;
-                if (n_kernels) n_kernels[out] = nk;
-                if (names && name_stride > 1) {
-                    int i = 0;
-                    for (; longest_name && longest_name[i] && i < name_stride - 1; ++i) names[(size_t)out * name_stride + i] = longest_name[i];
-                    names[(size_t)out * name_stride + i] = 0;
+    size_t first = 0;     // first kernel record of the open interval
+    for (size_t i = 0; i < g_trace.rec.size() && rc == DSW_OK; ++i) {
+        const DswTraceRec& r = g_trace.rec[i];
+        if (r.role == -1) continue;
+        if (r.role > 0) {
+            bool any = false;
+            for (size_t j = first; j < i && rc == DSW_OK; ++j) {
+                const DswTraceRec& k = g_trace.rec[j];
+                if (k.role != -1) continue;
+                float ms = 0.f;
+                if (hipEventSynchronize(k.e1) != hipSuccess || hipEventElapsedTime(&ms, k.e0, k.e1) != hipSuccess) { rc = DSW_ERR_LAUNCH; break; }
+                if (out < cap && roles && us) {
+                    if (call) call[out] = n_call;
+                    roles[out] = r.role;
+                    if (aux0) aux0[out] = r.a0;
+                    if (aux1) aux1[out] = r.a1;
+                    if (aux2) aux2[out] = r.a2;
+                    us[out] = ms * 1000.f;
+                    if (names && name_stride > 1) {
+                        int c = 0;
+                        for (; k.name && k.name[c] && c < name_stride - 1; ++c) names[(size_t)out * name_stride + c] = k.name[c];
+                        names[(size_t)out * name_stride + c] = 0;
+                    }
                 }
+                ++out;
+                any = true;
             }
-            ++out;
+            if (any) ++n_call;
         }
-        sum_ms = 0.0; nk = 0; longest = -1.f; longest_name = nullptr; first = last = nullptr;
+        first = i + 1;
     }
     for (hipEvent_t e : g_trace.ev) (void)hipEventDestroy(e);
     g_trace.ev.clear(); g_trace.rec.clear();

@@ -32,7 +32,7 @@ SIGNATURES = {
     "dsw_strerror": (ctypes.c_char_p, [_int]),
     "dsw_build_flags": (_int, []),
     "dsw_trace_begin": (_int, [_int]),
-    "dsw_trace_end": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int]),
+    "dsw_trace_end": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int]),
     "dsw_spmm_csr": (
         _int,
         [_i32p, _i32p, _f32p, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _f32, _vp, _f32, _vp, _f32, _int, _vp],
@@ -147,15 +147,15 @@ ROLE_NAMES = {1: "spmm", 2: "spmm2", 3: "spmm_staged", 4: "basis_fwd", 5: "basis
 
 
 class LaunchTrace:
-    """``with LaunchTrace(capacity) as tr: ...steps...`` then ``tr.intervals``: list of (role name, aux0, aux1, aux2, us) for
-    every role the entry points executed on the way (``dsw_trace_begin`` / ``dsw_trace_end``); ``us`` = sum of the durations
-    of the role's kernels, each taken from the kernel's own dispatch (start / stop events attached to the launch) inside the
-    running step.  ``tr.detail[i]`` = (span_us, n_kernels, launch-site name of the longest kernel)."""
+    """``with LaunchTrace(capacity) as tr: ...steps...`` then ``tr.kernels``: one record per kernel the library launched on
+    the way, in launch order: (call index, role name, aux0, aux1, aux2, us, launch-site name) - ``call index`` numbers the role
+    calls (all kernels of one role of one entry-point call share it), ``us`` is the kernel's duration from the start / stop
+    events attached to its dispatch.  ``tr.intervals`` sums the kernels per role call: (role, aux0, aux1, aux2, us)."""
 
     def __init__(self, capacity=16384):
         self.capacity = int(capacity)
+        self.kernels = []
         self.intervals = []
-        self.detail = []
 
     def __enter__(self):
         check(load().dsw_trace_begin(self.capacity), "dsw_trace_begin")
@@ -165,20 +165,27 @@ class LaunchTrace:
         import numpy as np
 
         cap, stride = self.capacity, 96
-        roles, a0, a1, a2, nk = (np.zeros(cap, dtype=np.int32) for _ in range(5))
-        us, span = np.zeros(cap, dtype=np.float32), np.zeros(cap, dtype=np.float32)
+        call, roles, a0, a1, a2 = (np.zeros(cap, dtype=np.int32) for _ in range(5))
+        us = np.zeros(cap, dtype=np.float32)
         names = np.zeros(cap * stride, dtype=np.uint8)
-        n = int(load().dsw_trace_end(roles.ctypes.data, a0.ctypes.data, a1.ctypes.data, a2.ctypes.data, us.ctypes.data,
-                                     span.ctypes.data, nk.ctypes.data, names.ctypes.data, stride, cap))
+        n = int(load().dsw_trace_end(call.ctypes.data, roles.ctypes.data, a0.ctypes.data, a1.ctypes.data, a2.ctypes.data,
+                                     us.ctypes.data, names.ctypes.data, stride, cap))
         if n < 0:
             if exc[0] is None:
                 check(n, "dsw_trace_end")
             return False
         n = min(n, cap)
-        self.intervals = [(ROLE_NAMES.get(int(roles[i]), str(int(roles[i]))), int(a0[i]), int(a1[i]), int(a2[i]), float(us[i]))
-                          for i in range(n)]
-        self.detail = [(float(span[i]), int(nk[i]),
-                        bytes(names[i * stride:(i + 1) * stride]).split(b"\0", 1)[0].decode(errors="replace")) for i in range(n)]
+        self.kernels = [(int(call[i]), ROLE_NAMES.get(int(roles[i]), str(int(roles[i]))), int(a0[i]), int(a1[i]), int(a2[i]),
+                         float(us[i]), bytes(names[i * stride:(i + 1) * stride]).split(b"\0", 1)[0].decode(errors="replace"))
+                        for i in range(n)]
+        self.intervals = []
+        last = None
+        for c, role, x0, x1, x2, t, _name in self.kernels:
+            if c != last:
+                self.intervals.append([role, x0, x1, x2, 0.0])
+                last = c
+            self.intervals[-1][4] += t
+        self.intervals = [tuple(v) for v in self.intervals]
         return False
 
 

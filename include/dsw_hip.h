@@ -86,11 +86,14 @@ int dsw_build_flags(void);
  * the caches in the state the step leaves them, which back-to-back calls of one kernel are not (isolated timings
  * were 11-14 % off the in-step durations).  One trace at a time, process-wide.
  *   dsw_trace_begin(capacity)  room for `capacity` kernel launches; starts recording.
- *   dsw_trace_end(...)         waits for the recorded kernels and writes up to `cap` role records in launch order: role,
- *                              three role-specific integers, us = SUM of the role's kernel durations, span_us = start of its
- *                              first to end of its last kernel, n_kernels, and the launch-site name of its longest kernel
- *                              (names: cap x name_stride chars).  Returns the number of records (> cap: truncated),
- *                              DSW_ERR_WORKSPACE if the capacity overflowed, another error code on failure.
+ *   dsw_trace_end(...)         waits for the recorded kernels and writes up to `cap` KERNEL records in launch order: index of
+ *                              the role call the kernel belongs to, its role and three role-specific integers, the kernel's
+ *                              duration in us, and the launch-site name of the kernel (names: cap x name_stride chars).
+ *                              Returns the number of records (> cap: truncated), DSW_ERR_WORKSPACE if the capacity
+ *                              overflowed, another error code on failure.
+ * Kernels launched eagerly carry heavier release fences than the same kernels replayed from a HIP graph and run ~10 % longer
+ * (measured); bench.py therefore uses the trace for the ORDER and ROLE of the kernels of a step and takes their durations
+ * from a rocprofv3 kernel trace of the replayed graph.
  * aux: conv roles (V, Fin, Fout) [recurrences: (V, C, K)], SPMM roles (rows_out, rows_in, C), elementwise (n, kind, 0). */
 #define DSW_ROLE_SPMM 1            /* dsw_spmm_csr / dsw_spmm_csr_ld: one product (interpolation pooling and its transpose) */
 #define DSW_ROLE_SPMM2 2           /* dsw_spmm2_fused called directly */
@@ -108,8 +111,8 @@ int dsw_build_flags(void);
 #define DSW_ROLE_BWD_FUSED 14      /* dgrad + adjoint recurrence in one launch (dY -> dX) */
 #define DSW_ROLE_BASIS_DUAL 15     /* mix-first backward: Chebyshev basis of dY under L^T (on the output channels) */
 int dsw_trace_begin(int capacity);
-int dsw_trace_end(int32_t* roles, int32_t* aux0, int32_t* aux1, int32_t* aux2, float* us, float* span_us, int32_t* n_kernels,
-                  char* names, int name_stride, int cap);
+int dsw_trace_end(int32_t* call, int32_t* roles, int32_t* aux0, int32_t* aux1, int32_t* aux2, float* us, char* names,
+                  int name_stride, int cap);
 
 /* Sparse operator times node-major activations with a fused axpby epilogue, per sample:
  *     Y[b,r,:] = alpha * sum_p vals[p] * X[b,colind[p],:] + beta * Z[b,r,:] + gamma * Z2[b,r,:]

@@ -48,7 +48,7 @@ def test_launch_trace_reports_the_roles_of_a_step():
             for _a0, _a1, _a2, us in rs:
                 assert 0.5 < us < 5000.0, rs
     lib = _native.load()
-    assert lib.dsw_trace_end(None, None, None, None, None, None, None, None, 0, 0) < 0               # no trace open
+    assert lib.dsw_trace_end(None, None, None, None, None, None, None, 0, 0) < 0               # no trace open
     assert lib.dsw_build_flags() == 0 or os.environ.get("DSW_HIP_LIB")
 
 
@@ -70,8 +70,8 @@ def test_bench_n1_runs_the_n_gt_1_step_and_agrees():
     assert "bucket" in b["config"]["grad_handling"] and "autograd" in a["config"]["grad_handling"]
     assert abs(a["ms_per_step"] - b["ms_per_step"]) <= 0.03 * a["ms_per_step"], (a["ms_per_step"], b["ms_per_step"])
     r = b["roofline"]
-    assert r["launch_timing"].startswith("in-step"), r["launch_timing"]
-    assert 0.95 <= r["in_step_sum_vs_ms_per_step"] <= 1.05, r["in_step_sum_vs_ms_per_step"]
+    assert r["launch_timing"].startswith("in-graph"), (r["launch_timing"], r["traced_step"].get("note"))
+    assert 0.97 <= r["in_step_sum_vs_ms_per_step"] <= 1.03, r["in_step_sum_vs_ms_per_step"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
 
 
