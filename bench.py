@@ -129,7 +129,7 @@ class _C5Block(torch.nn.Module):
             y, (z, idx) = self.pool.forward_fork(y)
         else:
             z, idx = self.pool(y)
-        return y + self.unpool(self.conv_coarse(z), idx)
+        return self.unpool.forward_add(self.conv_coarse(z), y)      # y + unpool(...): the add rides in the product's epilogue
 
 
 def make_unet(wl, knn, device):

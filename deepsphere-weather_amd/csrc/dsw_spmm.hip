@@ -550,6 +550,106 @@ __global__ __launch_bounds__(256) void remap_broadcast_kernel(const RemapArgs P)
     }
 }
 
+// Generic remap rows of 6-30 entries (a pooling between two different samplings: 14 on average): PARTS lane groups share a
+// row - part p takes entries p, p + PARTS, ... four at a time (four index loads, then four row loads in flight), the parts are
+// added up by xor-shuffles and part 0 runs the epilogue.  With one lane group per row (spmm_csr_rowsplit) such a row is a chain
+// of 7+ dependent index -> data round trips and the launch has 3 blocks per CU: 31 us for 95 MB in the C5 step.  Lane
+// layout: chunk (cpr lanes) fastest, then part, then row; sample = blockIdx.y.  Listed long rows: the blocks in front.
+template <bool BF16, int VEC>
+__global__ __launch_bounds__(256) void remap_parts_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ colind, const float* __restrict__ vals,
+    const void* __restrict__ X, void* Y, const void* Z, float beta, int v_out, int v_in, int C, int cpr, int parts, int B,
+    int ldx, int ldy, int ldz, int long_thr, int lblocks, const int* __restrict__ long_list, int n_long) {
+    using V = Vec<BF16, VEC>;
+    if ((int)blockIdx.x < lblocks) {
+        const long all_waves = (long)lblocks * 4;
+        for (long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6); t < n_long; t += all_waves)
+            spmm_long_row_one<BF16, VEC>(rowptr, colind, vals, X, Y, Z, nullptr, 1.f, beta, 0.f, v_out, v_in, C, cpr, ldx, ldy, ldz,
+                                         long_list[t], (int)blockIdx.y);
+        return;
+    }
+    const int gl = cpr * parts;                               // lanes per row: a power of two <= 64
+    const long gid = ((long)blockIdx.x - lblocks) * 256 + threadIdx.x;
+    const int row = (int)(gid / gl);
+    if (row >= v_out) return;                                 // (whole lane groups leave together)
+    const int lg = (int)(gid - (long)row * gl);
+    const int part = lg / cpr;
+    const int c0 = (lg - part * cpr) * VEC;
+    const int b = blockIdx.y;
+    const int s = rowptr[row], e = rowptr[row + 1];
+    const bool mine = !(long_thr > 0 && e - s > long_thr);    // a wave of the front blocks owns a listed row
+    const size_t xb = (size_t)b * (size_t)v_in * ldx + c0;
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    if (mine) {
+        int q = s + part;
+        for (; q + 3 * parts < e; q += 4 * parts) {
+            int col[4];
+            float a[4], x[4][VEC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { col[u] = colind[q + u * parts]; a[u] = vals[q + u * parts]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) V::load(X, xb + (size_t)col[u] * ldx, x[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] = fmaf(a[u], x[u][j], acc[j]);
+        }
+        {   // up to three more entries of this part: loaded together as well
+            int col[3];
+            float a[3], x[3][VEC];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int qq = q + u * parts;
+                const bool ok = qq < e;
+                col[u] = ok ? colind[qq] : 0;
+                a[u] = ok ? vals[qq] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                if (q + u * parts < e) V::load(X, xb + (size_t)col[u] * ldx, x[u]);
+                else {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) x[u][j] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] = fmaf(a[u], x[u][j], acc[j]);
+        }
+    }
+    for (int m = cpr; m < gl; m <<= 1) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += __shfl_xor(acc[j], m, 64);
+    }
+    if (mine && part == 0) {
+        const size_t orow = (size_t)b * v_out + row;
+        if (Z != nullptr) {
+            float z[VEC];
+            V::load_nt(Z, orow * (size_t)ldz + c0, z);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] = fmaf(beta, z[j], acc[j]);
+        }
+        V::store(Y, orow * (size_t)ldy + c0, acc);
+    }
+}
+
+template <bool BF16, int VEC>
+int launch_remap_parts(const int* rowptr, const int* colind, const float* vals, const void* X, void* Y, const void* Z, float beta,
+                       int v_out, int v_in, int C, int parts, int B, int ldx, int ldy, int ldz, LongRows lrw, hipStream_t stream) {
+    const int cpr = C / VEC;
+    const long threads = (long)v_out * cpr * parts;
+    const bool listed = lrw.list != nullptr && lrw.n_long > 0;
+    int lblocks = listed ? (int)((((long)lrw.n_long + 3) / 4 + 7) & ~7L) : 0;
+    if (lblocks > 2048) lblocks = 2048;
+    dim3 grid((unsigned)((threads + 255) / 256 + lblocks), (unsigned)B);
+    DSW_LAUNCH((remap_parts_kernel<BF16, VEC>), grid, dim3(256), 0, stream, rowptr, colind, vals, X, Y, Z, beta, v_out, v_in, C,
+               cpr, parts, B, ldx, ldy, ldz, listed ? lrw.thr : 0, lblocks, listed ? lrw.list : nullptr, listed ? lrw.n_long : 0);
+    return dsw_check_launch();
+}
+
 template <bool BF16, int VEC>
 int launch_remap_regular(int kind, const RemapArgs& A, int B, hipStream_t stream) {
     const long threads = (long)A.rows * A.cpr;
@@ -666,6 +766,23 @@ int dsw_remap_launch(const dsw_remap_plan* plan, const int* rowptr, const int* c
         return DSW_ERR_BAD_DTYPE;
     }
     const bool listed = plan != nullptr && plan->long_rows != nullptr && plan->long_thr > 0;
+    // rows of 6+ entries on average (and every long row listed, or none long): lane groups share the rows
+    if (plan != nullptr && kind == 0 && plan->parts > 1 && al && B <= 65535 && B > 0 && v_out > 0 && v_in > 0 &&
+        ldx <= INT32_MAX && ldy <= INT32_MAX && ldz <= INT32_MAX && v_out <= INT32_MAX && v_in <= INT32_MAX) {
+        const int cpr = (int)(C / vec);
+        int parts = plan->parts;
+        while (parts > 1 && cpr * parts > 64) parts >>= 1;
+        if (parts > 1 && (cpr & (cpr - 1)) == 0 && (parts & (parts - 1)) == 0) {
+            const LongRows lrw = {listed ? plan->long_rows : nullptr, listed ? plan->n_long : 0, listed ? plan->long_thr : 0};
+            if (dtype == DSW_F32)
+                return launch_remap_parts<false, 4>(rowptr, colind, vals, X, Y, Z, beta, (int)v_out, (int)v_in, (int)C, parts,
+                                                    (int)B, (int)ldx, (int)ldy, (int)ldz, lrw, stream);
+            if (dtype == DSW_BF16)
+                return launch_remap_parts<true, 8>(rowptr, colind, vals, X, Y, Z, beta, (int)v_out, (int)v_in, (int)C, parts,
+                                                   (int)B, (int)ldx, (int)ldy, (int)ldz, lrw, stream);
+            return DSW_ERR_BAD_DTYPE;
+        }
+    }
     return dsw_spmm_launch_ld(rowptr, colind, vals, v_out, v_in, X, ldx, Y, ldy, B, C, 1.f, Z, beta, nullptr, 0.f, dtype, stream,
                               0, ldz, listed ? plan->long_rows : nullptr, listed ? plan->n_long : 0, listed ? plan->long_thr : 0);
 }

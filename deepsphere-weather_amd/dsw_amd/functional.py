@@ -22,6 +22,7 @@ __all__ = [
     "get_operator",
     "cheb_conv",
     "sparse_remap",
+    "sparse_remap_add",
     "cheb_basis",
     "maxval_pool",
     "maxval_unpool",
@@ -189,10 +190,11 @@ class CsrOperator:
 
             class _Plan(ctypes.Structure):
                 _fields_ = [("kind", ctypes.c_int32), ("m", ctypes.c_int32), ("long_thr", ctypes.c_int32),
-                            ("n_long", ctypes.c_int32), ("long_rows", ctypes.c_void_p)]
+                            ("n_long", ctypes.c_int32), ("long_rows", ctypes.c_void_p), ("parts", ctypes.c_int32),
+                            ("reserved", ctypes.c_int32)]
 
             nrow, ncol = self.shape
-            kind, m, thr, long_rows = 0, 0, 0, None
+            kind, m, thr, long_rows, parts = 0, 0, 0, None, 1
             if self.values.is_cuda and nrow > 0 and self.nnz > 0:
                 dev = self.device
                 if self.nnz == ncol and ncol % nrow == 0:          # GROUPS: m = ncol / nrow entries per row, identity columns
@@ -213,8 +215,12 @@ class CsrOperator:
                     long_rows = torch.nonzero(lens > thr).flatten().to(torch.int32).contiguous()
                     if long_rows.numel() == 0:
                         long_rows = None
+                    mean = self.nnz / nrow
+                    parts = 4 if mean >= 10 else 2 if mean >= 6 else 1
+                    if parts > 1 and long_rows is None and int(lens.max()) > thr:
+                        parts = 1
             plan = _Plan(kind, m, thr if long_rows is not None else 0, 0 if long_rows is None else int(long_rows.numel()),
-                         None if long_rows is None else long_rows.data_ptr())
+                         None if long_rows is None else long_rows.data_ptr(), parts, 0)
             self._remap = (plan, long_rows)      # the list must outlive the plan
         return self._remap[0]
 
@@ -921,6 +927,26 @@ class _RemapForkFn(torch.autograd.Function):
         return _remap(ctx.be, ctx.op.transpose(), dy, z=g_x, beta=1.0), None
 
 
+class _RemapAddFn(torch.autograd.Function):
+    """``M x + addend`` in one product (the addend is the epilogue operand of the remap kernels): an unpooling whose result
+    is added to a skip tensor of the fine level, without the separate read-read-write ``add`` pass over the fine tensor."""
+
+    @staticmethod
+    def forward(ctx, x, addend, op):
+        be = _backend_for(x)
+        ctx.op, ctx.be = op, be
+        return _remap(be, op, x if _rows_ok(x) else x.contiguous(), z=addend if _rows_ok(addend) else addend.contiguous(),
+                      beta=1.0)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = _remap(ctx.be, ctx.op.transpose(), g if _rows_ok(g) else g.contiguous())
+        return gx, (g if ctx.needs_input_grad[1] else None), None
+
+
 class _ConcatInPlaceFn(torch.autograd.Function):
     """``torch.cat((left, right), dim=2)`` when ``left`` and ``right`` already ARE the two channel slices of ``buf``:
     no data moves forward, backward hands out the two slices of the gradient."""
@@ -1088,6 +1114,19 @@ def sparse_remap(op: CsrOperator, x: torch.Tensor, out: torch.Tensor = None) -> 
         raise ValueError(f"remap matrix has {op.shape[1]} source nodes, input has {x.shape[1]}")
     _check_dtype(x)
     return _RemapFn.apply(x, op, _check_out(out, (x.shape[0], op.shape[0], x.shape[2]), x))
+
+
+def sparse_remap_add(op: CsrOperator, x: torch.Tensor, addend: torch.Tensor) -> torch.Tensor:
+    """``sparse_remap(op, x) + addend`` in one launch (``addend``: ``[B, Vd, F]``, e.g. the fine-level tensor an unpooled
+    coarse result is added to)."""
+    if x.dim() != 3 or addend.dim() != 3:
+        raise ValueError("expected input [B, V, F] and addend [B, Vd, F]")
+    if x.shape[1] != op.shape[1]:
+        raise ValueError(f"remap matrix has {op.shape[1]} source nodes, input has {x.shape[1]}")
+    if tuple(addend.shape) != (x.shape[0], op.shape[0], x.shape[2]):
+        raise ValueError("`addend` must have the shape of the product")
+    _check_dtype(x, addend)
+    return _RemapAddFn.apply(x, addend, op)
 
 
 def sparse_remap_fork(op: CsrOperator, x: torch.Tensor):

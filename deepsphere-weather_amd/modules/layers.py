@@ -296,6 +296,11 @@ class RemapBlock(_Fp32OperatorMixin, torch.nn.Module):
         U-Net: hand ``x_again`` to that consumer and its gradient is added inside this layer's backward product."""
         return _F.sparse_remap_fork(_F.get_operator(self.remap_matrix), x)
 
+    def forward_add(self, x, addend):
+        """``forward(x) + addend`` in one launch (extension): the addend rides in the epilogue of the product - an unpooled
+        coarse result added to a tensor of the fine level costs no separate pass."""
+        return _F.sparse_remap_add(_F.get_operator(self.remap_matrix), x, addend)
+
     def process_remap_matrix(self, mat):
         return convert_to_torch_sparse(mat)
 

@@ -152,6 +152,9 @@ typedef struct dsw_remap_plan {
     int32_t kind, m;
     int32_t long_thr, n_long;
     const int32_t* long_rows;   /* device pointer, n_long rows (kind 0); NULL otherwise */
+    int32_t parts;              /* kind 0: lane groups that share a row (1, 2 or 4: rows of 6+ entries on average are split so
+                                   that a row is not a chain of dependent index -> data round trips); 0 / 1 = one group per row */
+    int32_t reserved;
 } dsw_remap_plan;
 
 /* Y[b,r,:] = sum_p vals[p] X[b,colind[p],:] + beta Z[b,r,:] for a remap matrix with a plan (NULL plan = dsw_spmm_csr_ld with

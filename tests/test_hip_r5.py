@@ -156,3 +156,47 @@ def test_remap_plan_of_the_healpix_hierarchy_and_of_a_cross_sampling_matrix():
                 # there: equal to rounding, not bit for bit)
                 assert orc.max_rel_err(F_._HIP.remap(o, x), F_._HIP.spmm(o, x).cpu().numpy()) <= 1e-6
                 assert orc.max_rel_err(F_._HIP.remap(o, x, z=z, beta=1.0), F_._HIP.spmm(o, x, 1.0, z, 1.0).cpu().numpy()) <= 1e-6
+
+
+@pytest.mark.parametrize("dt,C,B", [(torch.float32, 32, 8), (torch.float32, 64, 3), (torch.float32, 128, 2), (torch.bfloat16, 32, 4),
+                                     (torch.float32, 16, 1)])
+def test_remap_rows_shared_by_lane_groups_and_the_fused_add(dt, C, B):
+    """Cross-sampling pooling (rows of 6-30 entries, polar rows listed): the lane-groups-per-row kernel of the planned entry
+    point against the fp64 oracle - forward, transposed, with empty rows - and `RemapBlock.forward_add` (the addend in the
+    product's epilogue) against `forward(x) + addend`, values and both gradients."""
+    import numpy as np
+    from scipy import sparse
+    from dsw_amd import functional as F_, sphere
+    from modules.layers import GeneralAvgUnpool
+    from oracle import cheb_oracle as orc
+
+    fine = sphere.SphereEquiangular(nlat=36, nlon=72, k=8)
+    coarse = sphere.SphereHealpix(8, nest=True, k=8)
+    pm, um = sphere.conservative_pool_matrices(fine.coords, coarse.coords)
+    pm = sparse.csr_matrix(pm).astype(np.float32)
+    pm = sparse.vstack([pm[:100], sparse.csr_matrix((3, pm.shape[1]), dtype=np.float32), pm[100:]]).tocsr()   # empty rows
+    tol = 2e-6 if dt == torch.float32 else 1e-2
+    op = _op_from_scipy(pm)
+    assert op.remap_plan().kind == 0 and op.remap_plan().parts in (2, 4)
+    x = torch.randn(B, pm.shape[1], C, device=DEV).to(dt)
+    z = torch.randn(B, pm.shape[0], C, device=DEV).to(dt)
+    P64 = pm.astype(np.float64)
+    ref = np.stack([P64 @ x[b].float().cpu().double().numpy() for b in range(B)])
+    assert orc.max_rel_err(F_._HIP.remap(op, x).float(), ref) <= tol
+    assert orc.max_rel_err(F_._HIP.remap(op, x, z=z, beta=1.0).float(), ref + z.float().cpu().double().numpy()) <= tol
+    xt = torch.randn(B, pm.shape[0], C, device=DEV).to(dt)
+    ref_t = np.stack([P64.T @ xt[b].float().cpu().double().numpy() for b in range(B)])
+    assert orc.max_rel_err(F_._HIP.remap(op.transpose(), xt).float(), ref_t) <= tol
+    if dt == torch.float32:
+        unpool = GeneralAvgUnpool(um).to(DEV)
+        xc = torch.randn(B, um.shape[1], C, device=DEV, requires_grad=True)
+        add = torch.randn(B, um.shape[0], C, device=DEV, requires_grad=True)
+        g = torch.randn(B, um.shape[0], C, device=DEV)
+        y1 = unpool.forward_add(xc, add)
+        y1.backward(g)
+        gx1, ga1 = xc.grad.clone(), add.grad.clone()
+        xc.grad = add.grad = None
+        y2 = unpool(xc) + add
+        y2.backward(g)
+        assert orc.max_rel_err(y1, y2.detach().cpu().numpy()) <= 1e-6
+        assert torch.equal(gx1, xc.grad) and torch.equal(ga1, add.grad)
