@@ -38,6 +38,9 @@ namespace {
 // they do not displace the gathered rows from L2 / Infinity Cache (NS step -1.4 % same-box)
 template <typename T4>
 static __device__ __forceinline__ void st16(char* p, const T4& v) {
+#ifdef DSW_ABL_F3_NOSTORE
+    if (p != nullptr) return;      // (never null here: keeps the operands alive)
+#endif
     typedef unsigned u32x4_nt __attribute__((ext_vector_type(4)));
     __builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, v), reinterpret_cast<u32x4_nt*>(p));
 }
@@ -91,6 +94,9 @@ static __device__ __forceinline__ void split3x8(const float (&f)[8], bf16x8_t& h
 // the three bf16 images of 4 consecutive channels of one tile row -> LDS (8 bytes per term)
 static __device__ __forceinline__ void split_store(unsigned char* __restrict__ simg, const int plane, const int row,
                                                    const unsigned c4, const float (&f)[4]) {
+#ifdef DSW_ABL_F3_NOSPLIT
+    return;
+#endif
     float r1[4], r2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -113,6 +119,9 @@ static __device__ __forceinline__ void split_store(unsigned char* __restrict__ s
 // and a spill costs a scratch access + s_waitcnt vmcnt(0) in the middle of the prefetch window.
 static __device__ __forceinline__ void gather_ell(const unsigned char* __restrict__ row_idx, const float* __restrict__ row_val,
                                                   const int W, const unsigned char* __restrict__ bufc, float (&acc)[4]) {
+#ifdef DSW_ABL_F3_NOGATHER      // ablation builds only (refused by _native.load unless named by DSW_HIP_LIB)
+    acc[0] = row_val[0]; return;
+#endif
     int j = 0;
     for (; j + 4 <= W; j += 4) {
         const unsigned w = *reinterpret_cast<const unsigned*>(row_idx + j);
@@ -303,6 +312,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
             acc[r] = bias4;
             fro[r] = row * 64u + (((unsigned)kc ^ ((row >> 2) & 2u)) << 4);
         }
+#ifndef DSW_ABL_F3_NOMFMA
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             bf16x8_t th[RBW], tm[RBW], tl[RBW];
@@ -327,6 +337,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
 #pragma unroll
             for (int r = 0; r < RBW; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], th[r], acc[r], 0, 0, 0);
         }
+#endif
 #pragma unroll
         for (int r = 0; r < RBW; ++r) {   // lane: row 16 (rb0 + r) + l15, output channels 16 cbk + 4 kc .. + 3
             const int row = 16 * (rb0 + r) + l15;

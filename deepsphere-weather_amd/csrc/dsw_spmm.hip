@@ -561,21 +561,31 @@ __global__ __launch_bounds__(256) void remap_parts_kernel(
     const void* __restrict__ X, void* Y, const void* Z, float beta, int v_out, int v_in, int C, int cpr, int parts, int B,
     int ldx, int ldy, int ldz, int long_thr, int lblocks, const int* __restrict__ long_list, int n_long) {
     using V = Vec<BF16, VEC>;
-    if ((int)blockIdx.x < lblocks) {
+    // grid: lblocks * B blocks for the listed long rows (they come first), then row_blocks * B main blocks
+    const long lb_all = (long)lblocks * B;
+    if ((long)blockIdx.x < lb_all) {
+        const int bl = (int)(blockIdx.x / lblocks);
         const long all_waves = (long)lblocks * 4;
-        for (long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6); t < n_long; t += all_waves)
+        for (long t = ((long)blockIdx.x - (long)bl * lblocks) * 4 + (threadIdx.x >> 6); t < n_long; t += all_waves)
             spmm_long_row_one<BF16, VEC>(rowptr, colind, vals, X, Y, Z, nullptr, 1.f, beta, 0.f, v_out, v_in, C, cpr, ldx, ldy, ldz,
-                                         long_list[t], (int)blockIdx.y);
+                                         long_list[t], bl);
         return;
     }
+    // XCD-aware order of the main blocks (hardware block i runs on XCD i % 8, each with a private L2): every XCD walks ONE
+    // contiguous range of (sample, row block) pairs - neighbouring destination rows share their source rows (2.2 destinations
+    // per source row in the C5 pooling), which a round-robin deal would fetch into two or three L2s
+    const long nwg = (long)gridDim.x - lb_all, orig = (long)blockIdx.x - lb_all;
+    const long q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const long wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const long row_blocks = nwg / B;
+    const int b = (int)(wg / row_blocks);
     const int gl = cpr * parts;                               // lanes per row: a power of two <= 64
-    const long gid = ((long)blockIdx.x - lblocks) * 256 + threadIdx.x;
+    const long gid = (wg - (long)b * row_blocks) * 256 + threadIdx.x;
     const int row = (int)(gid / gl);
     if (row >= v_out) return;                                 // (whole lane groups leave together)
     const int lg = (int)(gid - (long)row * gl);
     const int part = lg / cpr;
     const int c0 = (lg - part * cpr) * VEC;
-    const int b = blockIdx.y;
     const int s = rowptr[row], e = rowptr[row + 1];
     const bool mine = !(long_thr > 0 && e - s > long_thr);    // a wave of the front blocks owns a listed row
     const size_t xb = (size_t)b * (size_t)v_in * ldx + c0;
@@ -644,7 +654,9 @@ int launch_remap_parts(const int* rowptr, const int* colind, const float* vals, 
     const bool listed = lrw.list != nullptr && lrw.n_long > 0;
     int lblocks = listed ? (int)((((long)lrw.n_long + 3) / 4 + 7) & ~7L) : 0;
     if (lblocks > 2048) lblocks = 2048;
-    dim3 grid((unsigned)((threads + 255) / 256 + lblocks), (unsigned)B);
+    const long nblk = ((threads + 255) / 256 + lblocks) * (long)B;
+    if (nblk > 2147483647L) return DSW_ERR_BAD_ARG;
+    dim3 grid((unsigned)nblk);
     DSW_LAUNCH((remap_parts_kernel<BF16, VEC>), grid, dim3(256), 0, stream, rowptr, colind, vals, X, Y, Z, beta, v_out, v_in, C,
                cpr, parts, B, ldx, ldy, ldz, listed ? lrw.thr : 0, lblocks, listed ? lrw.list : nullptr, listed ? lrw.n_long : 0);
     return dsw_check_launch();

@@ -287,8 +287,13 @@ class RemapBlock(_Fp32OperatorMixin, torch.nn.Module):
         super().__init__()
         self.register_buffer("remap_matrix", self.process_remap_matrix(remap_matrix))
 
-    def forward(self, x, *args, out=None, **kwargs):
-        """``out`` (extension): a preallocated ``[B, V_dst, F]`` channel slice of a wider tensor to write into."""
+    def forward(self, x, *args, out=None, add=None, **kwargs):
+        """``out`` (extension): a preallocated ``[B, V_dst, F]`` channel slice of a wider tensor to write into.
+        ``add`` (extension): a ``[B, V_dst, F]`` tensor added to the product in the kernel's epilogue (see ``forward_add``)."""
+        if add is not None:
+            if out is not None:
+                raise ValueError("RemapBlock: `out` and `add` cannot be combined")
+            return _F.sparse_remap_add(_F.get_operator(self.remap_matrix), x, add)
         return _F.sparse_remap(_F.get_operator(self.remap_matrix), x, out=out)
 
     def forward_fork(self, x):
@@ -299,7 +304,7 @@ class RemapBlock(_Fp32OperatorMixin, torch.nn.Module):
     def forward_add(self, x, addend):
         """``forward(x) + addend`` in one launch (extension): the addend rides in the epilogue of the product - an unpooled
         coarse result added to a tensor of the fine level costs no separate pass."""
-        return _F.sparse_remap_add(_F.get_operator(self.remap_matrix), x, addend)
+        return self(x, add=addend)
 
     def process_remap_matrix(self, mat):
         return convert_to_torch_sparse(mat)
