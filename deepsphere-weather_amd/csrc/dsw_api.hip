@@ -142,6 +142,9 @@ int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X,
                             void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
                             int* rc, int relu);
 int dsw_cheb3_fwd_fused_eligible(const dsw_hop2_plan* plan, int64_t Fin, int64_t Fout, int64_t K, int dtype);
+int dsw_cheb3_bwd_fused_try(const dsw_hop2_plan* plan_t, int64_t V, const void* dY, const void* W, void* dX, int64_t B,
+                            int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int* rc);
+int dsw_cheb3_bwd_fused_eligible(const dsw_hop2_plan* plan_t, int64_t Fin, int64_t Fout, int64_t K, int dtype);
 int dsw_zdgrad_launch(const void* dY, const void* D, const void* W, void* dX, int64_t N, int64_t Fin, int64_t Fout,
                       int64_t K, int dtype, hipStream_t stream, const DswEpiExtra* extra = nullptr);
 
@@ -446,6 +449,11 @@ int dsw_cheb_mix_fwd(const void* X, const void* T, const void* W, const void* bi
 
 int dsw_cheb_mix_first(int64_t Fin, int64_t Fout, int64_t K) { return mix_first(Fin, Fout, K) ? 1 : 0; }
 
+int dsw_cheb_bwd_one_launch(const dsw_hop2_plan* plan_t, int64_t Fin, int64_t Fout, int64_t K, int dtype) {
+    if (mix_first(Fin, Fout, K)) return 0;
+    return dsw_cheb3_bwd_fused_eligible(plan_t, Fin, Fout, K, dtype);
+}
+
 int dsw_cheb_fwd_path(const dsw_hop2_plan* plan, int64_t Fin, int64_t Fout, int64_t K, int dtype) {
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     if (Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
@@ -657,6 +665,20 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
     // (staged one-hop plans only: inside a fused pair the subtracted plane is the staged input of the first hop - no pass
     // is saved there and the fold would only add work)
     const int folded = (K >= 3 && dX != nullptr && N > 0 && plan_t != nullptr && plan_t->hops == 1) ? 1 : 0;
+    if (dX != nullptr && N > 0 && !extras && K == 3 && rowptr_t != nullptr) {
+        // K = 3, 32 -> 64 channels, fp32, two-hop plan of L^T: dX straight from dY in one launch (dsw_bwd3.hip: the dgrad
+        // planes live in LDS only), the weight gradients from the plain wgrad pass - the planes never travel through HBM
+        int rcb = DSW_OK;
+        if (dsw_cheb3_bwd_fused_try(plan_t, V, dY, W, dX, B, Fin, Fout, K, dtype, s, &rcb)) {
+            trace_mark(stream, DSW_ROLE_BWD_FUSED, V, Fin, Fout);
+            if (rcb != DSW_OK) return rcb;
+            if (dW != nullptr) {
+                rcb = dsw_wgrad_launch(X, T, dY, dW, db, partial, N, Fin, Fout, K, dtype, s, accumulate);
+                trace_mark(stream, DSW_ROLE_BWD_WGRAD, V, Fin, Fout);
+            }
+            return rcb;
+        }
+    }
     if (dX != nullptr && dW != nullptr && N > 0 && !extras) {
         // small aligned fp32 layers: dgrad planes and dW partials from ONE pass over dY (dsw_wgrad_x3.hip, FUSE); the fold is
         // applied while that kernel fills its W^T panel

@@ -555,13 +555,13 @@ __global__ __launch_bounds__(256) void remap_broadcast_kernel(const RemapArgs P)
 // added up by xor-shuffles and part 0 runs the epilogue.  With one lane group per row (spmm_csr_rowsplit) such a row is a chain
 // of 7+ dependent index -> data round trips and the launch has 3 blocks per CU: 31 us for 95 MB in the C5 step.  Lane
 // layout: chunk (cpr lanes) fastest, then part, then row; sample = blockIdx.y.  Listed long rows: the blocks in front.
-template <bool BF16, int VEC>
+template <bool BF16, int VEC, int NB>
 __global__ __launch_bounds__(256) void remap_parts_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ colind, const float* __restrict__ vals,
     const void* __restrict__ X, void* Y, const void* Z, float beta, int v_out, int v_in, int C, int cpr, int parts, int B,
     int ldx, int ldy, int ldz, int long_thr, int lblocks, const int* __restrict__ long_list, int n_long) {
     using V = Vec<BF16, VEC>;
-    // grid: lblocks * B blocks for the listed long rows (they come first), then row_blocks * B main blocks
+    // grid: lblocks * B blocks for the listed long rows (they come first), then row_blocks * ceil(B / NB) main blocks
     const long lb_all = (long)lblocks * B;
     if ((long)blockIdx.x < lb_all) {
         const int bl = (int)(blockIdx.x / lblocks);
@@ -572,15 +572,17 @@ __global__ __launch_bounds__(256) void remap_parts_kernel(
         return;
     }
     // XCD-aware order of the main blocks (hardware block i runs on XCD i % 8, each with a private L2): every XCD walks ONE
-    // contiguous range of (sample, row block) pairs - neighbouring destination rows share their source rows (2.2 destinations
-    // per source row in the C5 pooling), which a round-robin deal would fetch into two or three L2s
+    // contiguous range of (sample group, row block) pairs - neighbouring destination rows share their source rows (2.2
+    // destinations per source row in the C5 pooling), which a round-robin deal would fetch into two or three L2s
     const long nwg = (long)gridDim.x - lb_all, orig = (long)blockIdx.x - lb_all;
     const long q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
     const long wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const long row_blocks = nwg / B;
-    const int b = (int)(wg / row_blocks);
+    const int bgroups = (B + NB - 1) / NB;
+    const long row_blocks = nwg / bgroups;
+    const int bg = (int)(wg / row_blocks);
+    const int b0 = bg * NB;
     const int gl = cpr * parts;                               // lanes per row: a power of two <= 64
-    const long gid = (wg - (long)b * row_blocks) * 256 + threadIdx.x;
+    const long gid = (wg - (long)bg * row_blocks) * 256 + threadIdx.x;
     const int row = (int)(gid / gl);
     if (row >= v_out) return;                                 // (whole lane groups leave together)
     const int lg = (int)(gid - (long)row * gl);
@@ -588,78 +590,90 @@ __global__ __launch_bounds__(256) void remap_parts_kernel(
     const int c0 = (lg - part * cpr) * VEC;
     const int s = rowptr[row], e = rowptr[row + 1];
     const bool mine = !(long_thr > 0 && e - s > long_thr);    // a wave of the front blocks owns a listed row
-    const size_t xb = (size_t)b * (size_t)v_in * ldx + c0;
-    float acc[VEC];
+    const size_t xs = (size_t)v_in * ldx;
+    size_t xb[NB];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    for (int i = 0; i < NB; ++i) xb[i] = (size_t)(b0 + i < B ? b0 + i : B - 1) * xs + c0;
+    float acc[NB][VEC];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[i][j] = 0.f;
     if (mine) {
-        int q = s + part;
-        for (; q + 3 * parts < e; q += 4 * parts) {
+        // four entries of this part per step: their indices and weights first, then 4 x NB row loads in flight - a row of the
+        // C5 pooling (14 entries, 4 parts) is ONE step: the wave's life is two memory round trips, not eight
+        for (int q = s + part; q < e; q += 4 * parts) {
             int col[4];
-            float a[4], x[4][VEC];
+            float a[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { col[u] = colind[q + u * parts]; a[u] = vals[q + u * parts]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) V::load(X, xb + (size_t)col[u] * ldx, x[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) acc[j] = fmaf(a[u], x[u][j], acc[j]);
-        }
-        {   // up to three more entries of this part: loaded together as well
-            int col[3];
-            float a[3], x[3][VEC];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 const int qq = q + u * parts;
                 const bool ok = qq < e;
                 col[u] = ok ? colind[qq] : 0;
                 a[u] = ok ? vals[qq] : 0.f;
             }
+            float x[4][NB][VEC];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                if (q + u * parts < e) V::load(X, xb + (size_t)col[u] * ldx, x[u]);
-                else {
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) x[u][j] = 0.f;
-                }
-            }
+                for (int i = 0; i < NB; ++i) V::load(X, xb[i] + (size_t)col[u] * ldx, x[u][i]);   // (padding entries: row 0, weight 0)
 #pragma unroll
-            for (int u = 0; u < 3; ++u)
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) acc[j] = fmaf(a[u], x[u][j], acc[j]);
+                for (int i = 0; i < NB; ++i)
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) acc[i][j] = fmaf(a[u], x[u][i][j], acc[i][j]);
         }
     }
     for (int m = cpr; m < gl; m <<= 1) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[j] += __shfl_xor(acc[j], m, 64);
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[i][j] += __shfl_xor(acc[i][j], m, 64);
     }
     if (mine && part == 0) {
-        const size_t orow = (size_t)b * v_out + row;
-        if (Z != nullptr) {
-            float z[VEC];
-            V::load_nt(Z, orow * (size_t)ldz + c0, z);
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) acc[j] = fmaf(beta, z[j], acc[j]);
+        for (int i = 0; i < NB; ++i) {
+            if (b0 + i >= B) break;
+            const size_t orow = (size_t)(b0 + i) * v_out + row;
+            if (Z != nullptr) {
+                float z[VEC];
+                V::load_nt(Z, orow * (size_t)ldz + c0, z);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[i][j] = fmaf(beta, z[j], acc[i][j]);
+            }
+            V::store(Y, orow * (size_t)ldy + c0, acc[i]);
         }
-        V::store(Y, orow * (size_t)ldy + c0, acc);
     }
 }
 
-template <bool BF16, int VEC>
-int launch_remap_parts(const int* rowptr, const int* colind, const float* vals, const void* X, void* Y, const void* Z, float beta,
-                       int v_out, int v_in, int C, int parts, int B, int ldx, int ldy, int ldz, LongRows lrw, hipStream_t stream) {
+template <bool BF16, int VEC, int NB>
+int launch_remap_parts_nb(const int* rowptr, const int* colind, const float* vals, const void* X, void* Y, const void* Z, float beta,
+                          int v_out, int v_in, int C, int parts, int B, int ldx, int ldy, int ldz, LongRows lrw, hipStream_t stream) {
     const int cpr = C / VEC;
     const long threads = (long)v_out * cpr * parts;
     const bool listed = lrw.list != nullptr && lrw.n_long > 0;
     int lblocks = listed ? (int)((((long)lrw.n_long + 3) / 4 + 7) & ~7L) : 0;
     if (lblocks > 2048) lblocks = 2048;
-    const long nblk = ((threads + 255) / 256 + lblocks) * (long)B;
+    const long nblk = (threads + 255) / 256 * ((B + NB - 1) / NB) + (long)lblocks * B;
     if (nblk > 2147483647L) return DSW_ERR_BAD_ARG;
     dim3 grid((unsigned)nblk);
-    DSW_LAUNCH((remap_parts_kernel<BF16, VEC>), grid, dim3(256), 0, stream, rowptr, colind, vals, X, Y, Z, beta, v_out, v_in, C,
+    DSW_LAUNCH((remap_parts_kernel<BF16, VEC, NB>), grid, dim3(256), 0, stream, rowptr, colind, vals, X, Y, Z, beta, v_out, v_in, C,
                cpr, parts, B, ldx, ldy, ldz, listed ? lrw.thr : 0, lblocks, listed ? lrw.list : nullptr, listed ? lrw.n_long : 0);
     return dsw_check_launch();
+}
+
+template <bool BF16, int VEC>
+int launch_remap_parts(const int* rowptr, const int* colind, const float* vals, const void* X, void* Y, const void* Z, float beta,
+                       int v_out, int v_in, int C, int parts, int B, int ldx, int ldy, int ldz, LongRows lrw, hipStream_t stream) {
+    // samples per thread: the index loads are shared and 4 x NB row loads are in flight per lane; as many as leave the launch
+    // at least ~4 blocks per CU
+    const long rb = ((long)v_out * (C / VEC) * parts + 255) / 256;
+    if (!BF16 && B >= 4 && rb * ((B + 3) / 4) >= 1024)
+        return launch_remap_parts_nb<BF16, VEC, 4>(rowptr, colind, vals, X, Y, Z, beta, v_out, v_in, C, parts, B, ldx, ldy, ldz, lrw, stream);
+    if (B >= 2 && rb * ((B + 1) / 2) >= 1024)
+        return launch_remap_parts_nb<BF16, VEC, 2>(rowptr, colind, vals, X, Y, Z, beta, v_out, v_in, C, parts, B, ldx, ldy, ldz, lrw, stream);
+    return launch_remap_parts_nb<BF16, VEC, 1>(rowptr, colind, vals, X, Y, Z, beta, v_out, v_in, C, parts, B, ldx, ldy, ldz, lrw, stream);
 }
 
 template <bool BF16, int VEC>

@@ -223,6 +223,11 @@ int dsw_cheb_mix_fwd(const void* X, const void* T, const void* W, const void* bi
  * (rows of Fout vs Fin channels) and to know whether T comes back as the basis. */
 int dsw_cheb_mix_first(int64_t Fin, int64_t Fout, int64_t K);
 
+/* 1 if dsw_cheb_bwd computes dX of this layer straight from dY in ONE launch (dgrad planes on the tile's two-ring in LDS,
+ * both L^T hops from LDS: dsw_bwd3.hip) - K = 3, 32 -> 64 channels, fp32, a two-hop plan of L^T.  The weight gradients then
+ * come from the plain wgrad pass; the dgrad planes never travel through HBM. */
+int dsw_cheb_bwd_one_launch(const dsw_hop2_plan* plan_t, int64_t Fin, int64_t Fout, int64_t K, int dtype);
+
 /* Which launch sequence dsw_cheb_fwd takes for a layer shape and plan (pointer alignment aside) - what a profile of a
  * training step should be read against:
  *   DSW_FWD_PLAIN_HOPS   one dsw_spmm_csr launch per hop, then the channel-mix GEMM

@@ -200,3 +200,72 @@ def test_remap_rows_shared_by_lane_groups_and_the_fused_add(dt, C, B):
         y2.backward(g)
         assert orc.max_rel_err(y1, y2.detach().cpu().numpy()) <= 1e-6
         assert torch.equal(gx1, xc.grad) and torch.equal(ga1, add.grad)
+
+
+@pytest.mark.parametrize("nside,knn,B", [(8, 8, 1), (8, 8, 3), (16, 8, 5), (16, 8, 16), (8, 20, 2)])
+def test_backward_in_one_launch_vs_oracle(nside, knn, B, monkeypatch):
+    """K = 3, 32 -> 64 channels, fp32 on a two-hop plan of L^T: dX straight from dY in one launch (dsw_bwd3.hip: dgrad planes on
+    the tile's two-ring in LDS, both L^T hops from LDS) + the plain wgrad pass, against the fp64 oracle - every sample, ragged
+    last tiles (a k = 20 graph of 768 nodes takes the staged one-hop plan instead: the generic route, same answer)."""
+    import ctypes
+    from dsw_amd import _native, functional as F_, sphere
+    from modules.layers import ConvCheb, prepare_torch_laplacian
+    from oracle import cheb_oracle as orc
+
+    monkeypatch.setattr(F_, "MIN_CLUSTERED_TILES", 1)
+    g = sphere.SphereHealpix(nside, nest=True, k=knn)
+    lap = prepare_torch_laplacian(g.L, lmax=1.9)
+    torch.manual_seed(nside + B)
+    layer = ConvCheb(32, 64, 3, laplacian=lap).to(DEV)
+    with torch.no_grad():
+        layer.bias.normal_(0, 0.1)
+    V = 12 * nside * nside
+    x = torch.randn(B, V, 32, device=DEV, requires_grad=True)
+    gy = torch.randn(B, V, 64, device=DEV)
+    y = layer(x)
+    y.backward(gy)
+    torch.cuda.synchronize()
+    opt = F_.get_operator(layer.laplacian).transpose()
+    pp, _keep = F_._plan_ptr(opt, x)
+    one = int(_native.load().dsw_cheb_bwd_one_launch(pp, 32, 64, 3, 0))
+    assert one == (1 if knn == 8 else 0)
+    rp, ci, va = orc.csr_arrays_from_coo(layer.laplacian.cpu())
+    xn, wn, bn = (t.detach().cpu().numpy() for t in (x, layer.weight, layer.bias))
+    dx64, dw64, db64 = orc.cheb_backward_f64(rp, ci, va, xn, wn, gy.cpu().numpy(), True)
+    assert orc.max_rel_err(x.grad, dx64) <= 2e-6
+    assert orc.max_rel_err(layer.weight.grad, dw64) <= 4e-6
+    assert orc.max_rel_err(layer.bias.grad, db64) <= 4e-6
+    # dX alone (frozen weights) takes the same launch; bit-identical, and repeatable
+    layer.weight.requires_grad_(False); layer.bias.requires_grad_(False)
+    x2 = x.detach().clone().requires_grad_(True)
+    layer(x2).backward(gy)
+    assert torch.equal(x2.grad, x.grad)
+
+
+def test_backward_in_one_launch_non_symmetric_operator(monkeypatch):
+    """The one-launch backward runs on the plan of the TRANSPOSED operator: a non-symmetric L (random row scaling of a HEALPix
+    Laplacian) pins L^T against the oracle's autograd-derived backward."""
+    import numpy as np
+    from scipy import sparse
+    from dsw_amd import functional as F_, sphere
+    from modules.layers import ConvCheb
+    from oracle import cheb_oracle as orc
+
+    monkeypatch.setattr(F_, "MIN_CLUSTERED_TILES", 1)
+    g = sphere.SphereHealpix(8, nest=True, k=8)
+    L = sparse.csr_matrix(g.L).astype(np.float64)
+    rng = np.random.default_rng(0)
+    L = sparse.diags(rng.uniform(0.3, 1.2, L.shape[0])) @ L * 0.5
+    L = sparse.csr_matrix(L).astype(np.float32)
+    L.sort_indices()
+    lap = orc.coo_from_scipy(L).float()
+    torch.manual_seed(3)
+    layer = ConvCheb(32, 64, 3, laplacian=lap).to(DEV)
+    x = torch.randn(4, 768, 32, device=DEV, requires_grad=True)
+    gy = torch.randn(4, 768, 64, device=DEV)
+    layer(x).backward(gy)
+    rp, ci, va = orc.csr_arrays_from_coo(layer.laplacian.cpu())
+    xn, wn = x.detach().cpu().numpy(), layer.weight.detach().cpu().numpy()
+    dx64, dw64, _db = orc.cheb_backward_f64(rp, ci, va, xn, wn, gy.cpu().numpy(), True)
+    assert orc.max_rel_err(x.grad, dx64) <= 2e-6
+    assert orc.max_rel_err(layer.weight.grad, dw64) <= 4e-6
