@@ -433,6 +433,8 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
     adj_s_iso = None
     if t_adj is not None:
         adj_s = t_adj["avg_us"] * 1e-6
+    elif t_bwdf is not None:
+        adj_s = None                 # the adjoint recurrence lives inside the one-launch backward: no launch of its own
     else:
         adj_s = adj_s_iso = timed(adj)
     out_mfma = mfma_leg(layer, x, T, steps, in_step=t_mix)

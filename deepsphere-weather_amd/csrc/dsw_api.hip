@@ -143,7 +143,8 @@ int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X,
                             int* rc, int relu);
 int dsw_cheb3_fwd_fused_eligible(const dsw_hop2_plan* plan, int64_t Fin, int64_t Fout, int64_t K, int dtype);
 int dsw_cheb3_bwd_fused_try(const dsw_hop2_plan* plan_t, int64_t V, const void* dY, const void* W, void* dX, int64_t B,
-                            int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int* rc);
+                            int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int* rc, void* ws,
+                            int64_t ws_bytes);
 int dsw_cheb3_bwd_fused_eligible(const dsw_hop2_plan* plan_t, int64_t Fin, int64_t Fout, int64_t K, int dtype);
 int dsw_zdgrad_launch(const void* dY, const void* D, const void* W, void* dX, int64_t N, int64_t Fin, int64_t Fout,
                       int64_t K, int dtype, hipStream_t stream, const DswEpiExtra* extra = nullptr);
@@ -669,7 +670,10 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
         // K = 3, 32 -> 64 channels, fp32, two-hop plan of L^T: dX straight from dY in one launch (dsw_bwd3.hip: the dgrad
         // planes live in LDS only), the weight gradients from the plain wgrad pass - the planes never travel through HBM
         int rcb = DSW_OK;
-        if (dsw_cheb3_bwd_fused_try(plan_t, V, dY, W, dX, B, Fin, Fout, K, dtype, s, &rcb)) {
+        // (scratch for the split W fragments: the weight-image region behind the wgrad partials)
+        const int64_t S_ = dsw_wgrad_slabs(N, Fin, Fout, K);
+        char* wfr = reinterpret_cast<char*>(partial) + round_up((S_ > 0 ? S_ : 1) * (K * Fin + 1) * Fout * 4, 256);
+        if (dsw_cheb3_bwd_fused_try(plan_t, V, dY, W, dX, B, Fin, Fout, K, dtype, s, &rcb, wfr, w_image_bytes(Fin, Fout, K, dtype))) {
             trace_mark(stream, DSW_ROLE_BWD_FUSED, V, Fin, Fout);
             if (rcb != DSW_OK) return rcb;
             if (dW != nullptr) {

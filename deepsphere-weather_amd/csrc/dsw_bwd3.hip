@@ -18,9 +18,15 @@
 // image of W (3 planes x 3 terms x 32 rows: 36 KB) is built once per workgroup; every dY row is split once, by the
 // thread that loaded it.
 //
-// 1024 threads, one workgroup per CU (141 KB of LDS at nside 64): 16 waves = the occupancy of the two 512-thread
-// workgroups of the forward kernel.  Per sample: NCH chunk steps (split-store chunk c, one barrier, MFMAs of chunk c
-// while the loads of the next sample's chunk c are in flight), then hop 1 and hop 2, each behind one barrier.
+// 512 threads, two workgroups per CU (79 KB of LDS at nside 64, <= 128 registers): the phases of a sample use one unit each
+// (vector ALU for the split, matrix cores, the LDS pipe for the hops) and only a second, independent workgroup overlaps
+// them - a first version with ONE 1024-thread workgroup per CU (W image in LDS, 141 KB) ran its 16 waves in lockstep
+// through five barriers per sample: 216 us against the 157 us of the launches it replaces.  What fits two workgroups:
+//   * the chunk image is single-buffered (two barriers per chunk step);
+//   * the W fragments live in REGISTERS: waves 0-3 hold plane 2 (needed on every row block), waves 4-7 planes 1 and 0'
+//     (1-ring / tile rows) - 48 registers, the MFMA work of the two groups is balanced (60 / 66 per wave and sample); the
+//     fragments come ready-made from a 36 KB image in the caller's workspace (bwd3_wprep_kernel: split once per call);
+//   * dY rows are prefetched two chunk steps ahead through a ring of two register slots.
 #include <cstdlib>
 #include "dsw_common.h"
 #include "../../include/dsw_hip.h"
@@ -34,14 +40,13 @@ static __device__ __forceinline__ void st16_nt(char* p, const T4& v) {
     __builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, v), reinterpret_cast<u32x4_nt*>(p));
 }
 
-constexpr int NTH = 1024;
+constexpr int NTH = 512;
 constexpr int XB = 128;          // bytes of a dX / G row in HBM (32 fp32 channels)
 constexpr int YB = 256;          // bytes of a dY row (64 fp32 channels)
 constexpr int GS = 144;          // LDS stride of a G row: 128 + 16 (the 16 rows of an accumulator store hit distinct banks)
 constexpr int IMG_TERM = 64 * 128;           // one term of a 64-row chunk image
 constexpr int IMG_BYTES = 3 * IMG_TERM;      // 24 KB
-constexpr int WIMG_PLANE = 3 * 32 * 128;     // [term][32 f][64 o bf16]
-constexpr int WIMG_BYTES = 3 * WIMG_PLANE;   // 36 KB
+constexpr int WFRAG_BYTES = 3 * 2 * 2 * 3 * 64 * 16;   // [plane][fb][ks][term][lane] x 16 B: the W fragments, 36 KB (workspace)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -54,7 +59,7 @@ struct Bwd3Args {
     const float* lval;
     const char* dY;
     char* dX;
-    const float* W;      // [32][3][64]
+    const unsigned char* wfrag;   // pre-split W fragments (bwd3_wprep_kernel)
     int V, n_tiles, max_n1, max_n2;
     int B, n_chunks, spc, ell_w;
     int explicit_tiles;
@@ -121,13 +126,37 @@ static __device__ __forceinline__ f32x4_t mfma6(const bf16x8_t (&a)[3], const bf
     return acc;
 }
 
-// NCH = ceil(max_n2 / 64): chunks of 64 list rows per sample
-template <int NCH>
+// W [32][3][64] -> fragment image [plane 0' = W_0 - W_2, W_1, W_2][fb][ks][term][lane]: lane l of the wave that owns dX channel
+// block fb gets, for k-step ks, the 8 dY channels o = 32 ks + 8 (l >> 4) .. + 7 of dX channel f = 16 fb + (l & 15), split
+// into its three bf16 terms.  (The subtraction of the raw plane K-1 at the top of the adjoint recurrence is folded into the
+// weights of plane 0.)
+__global__ __launch_bounds__(256) void bwd3_wprep_kernel(const float* __restrict__ W, unsigned char* __restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= 3 * 2 * 2 * 64) return;
+    const int lane = e & 63, ks = (e >> 6) & 1, fb = (e >> 7) & 1, plane = e >> 8;
+    const int f = 16 * fb + (lane & 15), o0 = 32 * ks + 8 * (lane >> 4);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        v[j] = W[((size_t)f * 3 + plane) * 64 + o0 + j];
+        if (plane == 0) v[j] -= W[((size_t)f * 3 + 2) * 64 + o0 + j];
+    }
+    float r1[8], r2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        r1[j] = v[j] - trunc_bf16(v[j]);
+        r2[j] = r1[j] - trunc_bf16(r1[j]);
+    }
+    uint4* dst = reinterpret_cast<uint4*>(out + ((size_t)((plane * 2 + fb) * 2 + ks) * 3) * 1024 + (size_t)lane * 16);
+    dst[0] = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+    dst[64] = make_uint4(pack2(r1[0], r1[1]), pack2(r1[2], r1[3]), pack2(r1[4], r1[5]), pack2(r1[6], r1[7]));
+    dst[128] = make_uint4(pack2(r2[0], r2[1]), pack2(r2[2], r2[3]), pack2(r2[4], r2[5]), pack2(r2[6], r2[7]));
+}
+
 __global__ __launch_bounds__(NTH, 4) void cheb3_bwd_fused_kernel(const Bwd3Args P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned char* img = lds;                                               // [2][3 terms][64 rows][128 B]
-    unsigned char* wimg = img + 2 * IMG_BYTES;                              // [3 planes][3 terms][32 f][128 B]
-    unsigned char* g2 = wimg + WIMG_BYTES;                                  // [max_n2][GS] G_2 on the 2-ring
+    unsigned char* img = lds;                                               // [3 terms][64 rows][128 B]
+    unsigned char* g2 = img + IMG_BYTES;                                    // [max_n2][GS] G_2 on the 2-ring
     unsigned char* g1 = g2 + (size_t)P.max_n2 * GS;                         // [max_n1][GS] G_1, then H_1, on the 1-ring
     unsigned char* g0 = g1 + (size_t)P.max_n1 * GS;                         // [64][GS]     G_0' on the tile
     float* ell_val = reinterpret_cast<float*>(g0 + 64 * GS);                // [max_n1][W]
@@ -148,6 +177,8 @@ __global__ __launch_bounds__(NTH, 4) void cheb3_bwd_fused_kernel(const Bwd3Args 
     const int tid = threadIdx.x;
     const int W = P.ell_w;
     const size_t y_sample = (size_t)P.V * YB, x_sample = (size_t)P.V * XB;
+    const int nch = (n2 + 63) >> 6;                  // chunk steps per sample of THIS tile
+    const int total = (b_end - b_begin) * nch;       // chunk steps of this workgroup
 
     int* lrp = reinterpret_cast<int*>(g1);           // local row pointers, parked in g1 until the ELL is built
     if (tid == 0) *tile_w = 2;
@@ -155,18 +186,26 @@ __global__ __launch_bounds__(NTH, 4) void cheb3_bwd_fused_kernel(const Bwd3Args 
     for (int i = tid; i <= n1; i += NTH) lrp[i] = P.lrowptr[rp_off + i];
     __syncthreads();
 
-    // staging role: list position 64 c + srow of chunk c, 16-byte lane sq (dY channels 4 sq .. 4 sq + 3)
+    // staging role: two slots per chunk - list positions 64 c + srow and 64 c + srow + 32, 16-byte lane sq (dY channels 4 sq ..)
     const int srow = tid >> 4;
     const unsigned sq = (unsigned)(tid & 15);
-    unsigned offY[NCH];
+    auto load_step = [&](const int b, const int c, u32x4 (&dst)[2]) __attribute__((always_inline)) {
+        const char* base = P.dY + (size_t)b * y_sample + sq * 16u;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) offY[c] = (unsigned)rows[min(64 * c + srow, n2 - 1)] * (unsigned)YB + sq * 16u;
-    u32x4 su[NCH];
-    if (b_begin < b_end) {
-        const size_t sb = (size_t)b_begin * y_sample;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) su[c] = *reinterpret_cast<const u32x4*>(P.dY + sb + offY[c]);
-    }
+        for (int j = 0; j < 2; ++j)
+            dst[j] = *reinterpret_cast<const u32x4*>(base + (size_t)((unsigned)rows[min(64 * c + srow + 32 * j, n2 - 1)] * (unsigned)YB));
+    };
+    // ring of two register slots: chunk step t lives in slot t & 1 and is requested two steps ahead
+    u32x4 ring0[2], ring1[2];
+    int pb = b_begin, pc = 0;                        // (sample, chunk) of the next step to request
+    auto advance_req = [&]() __attribute__((always_inline)) {
+        const int wrap = pc + 1 == nch ? 1 : 0;
+        pb += wrap;
+        pc = wrap ? 0 : pc + 1;
+    };
+    if (total > 0) { load_step(pb, pc, ring0); advance_req(); }
+    if (total > 1) { load_step(pb, pc, ring1); advance_req(); }
+
     // CSR -> ELL of the tile + 1-ring rows (as dsw_fwd3.hip)
     const int tile_nnz = lrp[n1];
     for (int t = tid; t < n1 * W; t += NTH) {
@@ -184,122 +223,113 @@ __global__ __launch_bounds__(NTH, 4) void cheb3_bwd_fused_kernel(const Bwd3Args 
         ell_idx[t] = (unsigned char)(live ? col : (unsigned)i);
         ell_val[t] = live ? val : 0.f;
     }
-    // split image of the weights: plane 0 = W_0 - W_2 (the subtraction of the raw plane K-1 at the top of the adjoint
-    // recurrence, folded into the weights), planes 1, 2 = W_1, W_2; image row = dX channel f, columns = dY channels o
-    for (int e = tid; e < 3 * 32 * 16; e += NTH) {
-        const int p = e / (32 * 16), f = (e / 16) & 31;
-        const unsigned q = (unsigned)(e & 15);
-        const float4 w = *reinterpret_cast<const float4*>(P.W + ((size_t)f * 3 + p) * 64 + 4 * q);
-        float v[4] = {w.x, w.y, w.z, w.w};
-        if (p == 0) {
-            const float4 w2 = *reinterpret_cast<const float4*>(P.W + ((size_t)f * 3 + 2) * 64 + 4 * q);
-            v[0] -= w2.x; v[1] -= w2.y; v[2] -= w2.z; v[3] -= w2.w;
-        }
-        split_store4(wimg + (size_t)p * WIMG_PLANE, 32 * 128, (unsigned)f, q, v);
+
+    // MFMA role of this wave: plane group pg (0: plane 2, needed on the whole 2-ring; 1: plane 1 on the 1-ring and plane 0' on
+    // the tile), dX channel block fb, row blocks 2 rbh and 2 rbh + 1 of every chunk
+    const int wave = tid >> 6, lane = tid & 63;
+    const int pg = wave >> 2, fb = wave & 1, rbh = (wave >> 1) & 1;
+    const unsigned l15 = (unsigned)(lane & 15), kc = (unsigned)(lane >> 4);
+    bf16x8_t wa[2][2][3];                            // [pg 0: plane 2, - | pg 1: plane 1, plane 0'][k-step][term]
+    {
+        const int planes[2] = {pg == 0 ? 2 : 1, 0};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    wa[a][ks][t] = *reinterpret_cast<const bf16x8_t*>(
+                        P.wfrag + ((size_t)(((planes[a] * 2 + fb) * 2 + ks) * 3 + t)) * 1024 + (size_t)lane * 16);
     }
-    __syncthreads();   // ELL and weight image complete (lrp in g1 dead)
+    __syncthreads();   // ELL complete (lrp in g1 dead)
     const int Wt = *tile_w;
 
-    // MFMA role of this wave: row block rb of a chunk (16 list rows), dX channel block fb (16 channels), plane group pg
-    // (0: plane 2 = needed on the whole 2-ring; 1: plane 1 on the 1-ring and plane 0' on the tile)
-    const int wave = tid >> 6, lane = tid & 63;
-    const int rb = wave & 3, fb = (wave >> 2) & 1, pg = wave >> 3;
-    const unsigned l15 = (unsigned)(lane & 15), kc = (unsigned)(lane >> 4);
-    const unsigned a_off0 = img_off(16u * fb + l15, kc), a_off1 = img_off(16u * fb + l15, 4u + kc);   // k-steps 0 / 1 of the W image
-    const unsigned b_off0 = img_off(16u * rb + l15, kc), b_off1 = img_off(16u * rb + l15, 4u + kc);   // ... of the chunk image
-    const unsigned g_st = (16u * rb + l15) * GS + (16u * fb + 4u * kc) * 4u;   // accumulator -> G row of the chunk, 16 bytes
-
-    // gather role (hops): list position grow, 16-byte chunk gc of the 128-byte row
-    const int grow = tid >> 3;
+    // gather role (hops): list position grp (+ 64 in the second pass of hop 1), 16-byte chunk of the 128-byte row
+    const int grp = tid >> 3;
     const unsigned gcb = (unsigned)(tid & 7) * 16u;
 
-    for (int b = b_begin; b < b_end; ++b) {
-        const size_t sb_next = (size_t)(b + 1 < b_end ? b + 1 : b) * y_sample;
+    int cb = b_begin, cc = 0;                        // (sample, chunk) of the current step
+    auto step = [&](u32x4 (&slot)[2], const int t) __attribute__((always_inline)) {
+        // ---- this step's rows -> split image; the slot then takes the step two ahead
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            unsigned char* im = img + (size_t)(c & 1) * IMG_BYTES;
-            {   // this sample's chunk c -> split image; its register then takes the next sample's chunk c
-                const float f4[4] = {__uint_as_float(su[c][0]), __uint_as_float(su[c][1]), __uint_as_float(su[c][2]),
-                                     __uint_as_float(su[c][3])};
-                split_store4(im, IMG_TERM, (unsigned)srow, sq, f4);
-                su[c] = *reinterpret_cast<const u32x4*>(P.dY + sb_next + offY[c]);
-            }
-            __syncthreads();   // image of chunk c complete; everybody is past the hops of the previous sample
-            const int p0 = 64 * c + 16 * rb;                // first list position of this wave's row block
-            const bool need = pg == 0 ? p0 < n2 : p0 < n1;  // uniform per wave
+        for (int j = 0; j < 2; ++j) {
+            const float f4[4] = {__uint_as_float(slot[j][0]), __uint_as_float(slot[j][1]), __uint_as_float(slot[j][2]),
+                                 __uint_as_float(slot[j][3])};
+            split_store4(img, IMG_TERM, (unsigned)(srow + 32 * j), sq, f4);
+        }
+        if (t + 2 < total) { load_step(pb, pc, slot); advance_req(); }
+        __syncthreads();   // image complete; everybody is past the hops of the previous sample
+        const int c = cc;
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            const int rb = 2 * rbh + h;
+            const int p0 = 64 * c + 16 * rb;                 // first list position of the row block
+            const bool need = pg == 0 ? p0 < n2 : p0 < n1;   // uniform per wave
             if (need) {
-                bf16x8_t bf0[3], bf1[3];
+                const bool tile_rows = pg == 1 && c == 0;    // plane 0' as well
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, acc0 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    bf0[t] = *reinterpret_cast<const bf16x8_t*>(im + (size_t)t * IMG_TERM + b_off0);
-                    bf1[t] = *reinterpret_cast<const bf16x8_t*>(im + (size_t)t * IMG_TERM + b_off1);
-                }
-                const int plane = pg == 0 ? 2 : 1;
-                {
-                    const unsigned char* wp = wimg + (size_t)plane * WIMG_PLANE;
-                    bf16x8_t a0[3], a1[3];
+                for (int ks = 0; ks < 2; ++ks) {             // one k-step of B fragments live at a time (registers)
+                    bf16x8_t bf[3];
+                    const unsigned o = img_off(16u * rb + l15, 4u * ks + kc);
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        a0[t] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * (32 * 128) + a_off0);
-                        a1[t] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * (32 * 128) + a_off1);
-                    }
-                    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-                    acc = mfma6(a0, bf0, acc);
-                    acc = mfma6(a1, bf1, acc);
-                    unsigned char* gdst = (pg == 0 ? g2 : g1) + (size_t)(64 * c) * GS + g_st;
-                    if (p0 + (int)l15 < (pg == 0 ? n2 : n1)) *reinterpret_cast<f32x4_t*>(gdst) = acc;
+                    for (int tt = 0; tt < 3; ++tt) bf[tt] = *reinterpret_cast<const bf16x8_t*>(img + (size_t)tt * IMG_TERM + o);
+                    acc = mfma6(wa[0][ks], bf, acc);
+                    if (tile_rows) acc0 = mfma6(wa[1][ks], bf, acc0);
                 }
-                if (pg == 1 && c == 0) {   // the tile rows: plane 0'
-                    const unsigned char* wp = wimg;
-                    bf16x8_t a0[3], a1[3];
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        a0[t] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * (32 * 128) + a_off0);
-                        a1[t] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * (32 * 128) + a_off1);
-                    }
-                    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-                    acc = mfma6(a0, bf0, acc);
-                    acc = mfma6(a1, bf1, acc);
-                    *reinterpret_cast<f32x4_t*>(g0 + g_st) = acc;
-                }
+                const unsigned gst = (unsigned)(p0 + (int)l15) * GS + (16u * fb + 4u * kc) * 4u;   // 16 bytes of a G row
+                if (p0 + (int)l15 < (pg == 0 ? n2 : n1)) *reinterpret_cast<f32x4_t*>((pg == 0 ? g2 : g1) + gst) = acc;
+                if (tile_rows) *reinterpret_cast<f32x4_t*>(g0 + gst) = acc0;
             }
         }
-        __syncthreads();   // G_2, G_1, G_0' complete
-        // ---- hop 1: H_1 = G_1 + 2 L^T G_2 on the tile + 1-ring rows, in place
-        if (grow < n1) {
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            gather_ell(ell_idx + (size_t)grow * W, ell_val + (size_t)grow * W, Wt, g2 + gcb, acc);
-            float4* hp = reinterpret_cast<float4*>(g1 + (size_t)grow * GS + gcb);
-            const float4 g = *hp;
-            *hp = make_float4(fmaf(2.f, acc[0], g.x), fmaf(2.f, acc[1], g.y), fmaf(2.f, acc[2], g.z), fmaf(2.f, acc[3], g.w));
+        __syncthreads();   // the image may be overwritten; after the last chunk: G_2, G_1, G_0' complete
+        if (c == nch - 1) {
+            // ---- hop 1: H_1 = G_1 + 2 L^T G_2 on the tile + 1-ring rows, in place
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = grp + 64 * k;
+                if (i < n1) {
+                    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                    gather_ell(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, g2 + gcb, acc);
+                    float4* hp = reinterpret_cast<float4*>(g1 + (size_t)i * GS + gcb);
+                    const float4 g = *hp;
+                    *hp = make_float4(fmaf(2.f, acc[0], g.x), fmaf(2.f, acc[1], g.y), fmaf(2.f, acc[2], g.z), fmaf(2.f, acc[3], g.w));
+                }
+            }
+            __syncthreads();
+            // ---- hop 2: dX = G_0' + L^T H_1 on the tile rows -> HBM
+            if (grp < rt) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                gather_ell(ell_idx + (size_t)grp * W, ell_val + (size_t)grp * W, Wt, g1 + gcb, acc);
+                const float4 g = *reinterpret_cast<const float4*>(g0 + (size_t)grp * GS + gcb);
+                const float4 o = make_float4(g.x + acc[0], g.y + acc[1], g.z + acc[2], g.w + acc[3]);
+                st16_nt(P.dX + (size_t)cb * x_sample + (size_t)rows[grp] * XB + gcb, o);
+            }
+            // (no barrier: the next step has one between its split-store and the first write to a G buffer)
         }
-        __syncthreads();
-        // ---- hop 2: dX = G_0' + L^T H_1 on the tile rows -> HBM
-        if (grow < rt) {
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            gather_ell(ell_idx + (size_t)grow * W, ell_val + (size_t)grow * W, Wt, g1 + gcb, acc);
-            const float4 g = *reinterpret_cast<const float4*>(g0 + (size_t)grow * GS + gcb);
-            const float4 o = make_float4(g.x + acc[0], g.y + acc[1], g.z + acc[2], g.w + acc[3]);
-            st16_nt(P.dX + (size_t)b * x_sample + (size_t)rows[grow] * XB + gcb, o);
-        }
-        // (no barrier here: the next sample's first chunk step has one before anything overwrites the G buffers)
+        const int last = c == nch - 1 ? 1 : 0;
+        cb += last;
+        cc = last ? 0 : c + 1;
+    };
+    for (int t = 0; t < total; t += 2) {
+        step(ring0, t);
+        if (t + 1 < total) step(ring1, t + 1);
     }
 }
 
 size_t bwd3_lds_bytes(const dsw_hop2_plan* plan) {
     const int ell_w = (plan->reserved + 3) & ~3;
-    size_t s = 2 * (size_t)IMG_BYTES + WIMG_BYTES + ((size_t)plan->max_n2 + plan->max_n1 + 64) * GS;
+    size_t s = (size_t)IMG_BYTES + ((size_t)plan->max_n2 + plan->max_n1 + 64) * GS;
     s += (size_t)plan->max_n1 * ell_w * 4 + (((size_t)plan->max_n1 * ell_w + 3) & ~(size_t)3);   // fp32 values + u8 positions
     s += (size_t)((plan->max_n2 + 3) & ~3) * 4 + 16;
     return (s + 15) & ~(size_t)15;
 }
 
-template <int NCH>
 int launch_bwd3(const Bwd3Args& A, long nwg, size_t lds, hipStream_t stream) {
-    if (hipFuncSetAttribute((const void*)cheb3_bwd_fused_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess)
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)cheb3_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DSW_ERR_LAUNCH;
-    DSW_LAUNCH((cheb3_bwd_fused_kernel<NCH>), dim3((unsigned)nwg), dim3(NTH), lds, stream, A);
+    DSW_LAUNCH(cheb3_bwd_fused_kernel, dim3((unsigned)nwg), dim3(NTH), lds, stream, A);
     return dsw_check_launch();
 }
 
@@ -311,34 +341,36 @@ int dsw_cheb3_bwd_fused_eligible(const dsw_hop2_plan* plan_t, int64_t Fin, int64
     if (env && env[0] == '0') return 0;
     if (dtype != DSW_F32 || K != 3 || Fin != 32 || Fout != 64) return 0;
     if (!plan_t || plan_t->hops == 1 || plan_t->tile_rows != 64 || !dsw_spmm2_supported(plan_t, Fin, dtype)) return 0;
-    if (plan_t->max_n2 > 255 || plan_t->max_n1 > 128) return 0;     // u8 list positions; hop 1 in one pass of the 1024 threads
-    if (bwd3_lds_bytes(plan_t) > 160 * 1024) return 0;
+    if (plan_t->max_n2 > 255 || plan_t->max_n1 > 128) return 0;     // u8 list positions; hop 1 in two passes of the 512 threads
+    if (bwd3_lds_bytes(plan_t) > 80 * 1024) return 0;               // two workgroups per CU or not at all
     return 1;
 }
 
 // dX from dY in one launch if the shape / plan allow it.  Returns 1 if it took the call (*rc = status), 0 if the caller
 // must use the generic sequence (dgrad planes + adjoint recurrence).
 int dsw_cheb3_bwd_fused_try(const dsw_hop2_plan* plan_t, int64_t V, const void* dY, const void* W, void* dX, int64_t B,
-                            int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int* rc) {
+                            int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int* rc, void* ws,
+                            int64_t ws_bytes) {
     if (!dsw_cheb3_bwd_fused_eligible(plan_t, Fin, Fout, K, dtype)) return 0;
     if (!dsw_aligned16(dY) || !dsw_aligned16(dX) || !dsw_aligned16(W)) return 0;
+    if (ws == nullptr || !dsw_aligned16(ws) || ws_bytes < WFRAG_BYTES) return 0;      // scratch for the split W fragments
     if ((unsigned long long)V * YB >= (1ull << 32)) return 0;           // 32-bit row offsets inside a sample
     if (V <= 0 || B <= 0) { *rc = DSW_OK; return 1; }
     Bwd3Args A;
     A.tile_meta = plan_t->tile_meta; A.s2_rows = plan_t->s2_rows; A.lrowptr = plan_t->lrowptr;
     A.lcol = plan_t->lcol; A.lval = plan_t->lval;
-    A.dY = static_cast<const char*>(dY); A.dX = static_cast<char*>(dX); A.W = static_cast<const float*>(W);
+    A.dY = static_cast<const char*>(dY); A.dX = static_cast<char*>(dX); A.wfrag = static_cast<const unsigned char*>(ws);
     A.V = (int)V; A.n_tiles = plan_t->n_tiles; A.max_n1 = plan_t->max_n1; A.max_n2 = plan_t->max_n2;
     A.B = (int)B; A.ell_w = (plan_t->reserved + 3) & ~3; A.explicit_tiles = plan_t->explicit_tiles;
-    // batch chunks: one workgroup per CU; rounds x (plan + weight image staging, about 2 samples' worth, + samples per chunk)
-    const long slots = dsw_device_cus();
+    // batch chunks: two workgroups per CU; rounds x (plan staging, about 1.5 samples' worth, + samples per chunk)
+    const long slots = 2 * dsw_device_cus();
     long chunks = 1;
     {
         double best = -1.0;
         const long cmax = B > 1 ? (B + 1) / 2 : 1;
         for (long c = 1; c <= cmax && c <= 16; ++c) {
             const long rounds = (plan_t->n_tiles * c + slots - 1) / slots;
-            const double cost = (double)rounds * (2.0 + (double)((B + c - 1) / c));
+            const double cost = (double)rounds * (1.5 + (double)((B + c - 1) / c));
             if (best < 0 || cost < best - 1e-9) { best = cost; chunks = c; }
         }
     }
@@ -347,12 +379,8 @@ int dsw_cheb3_bwd_fused_try(const dsw_hop2_plan* plan_t, int64_t V, const void* 
     const long nwg = (long)plan_t->n_tiles * A.n_chunks;
     if (nwg > 2147483647L) return 0;
     const size_t lds = bwd3_lds_bytes(plan_t);
-    const int nch = (plan_t->max_n2 + 63) / 64;
-    switch (nch) {
-        case 1: *rc = launch_bwd3<1>(A, nwg, lds, stream); break;
-        case 2: *rc = launch_bwd3<2>(A, nwg, lds, stream); break;
-        case 3: *rc = launch_bwd3<3>(A, nwg, lds, stream); break;
-        default: *rc = launch_bwd3<4>(A, nwg, lds, stream); break;
-    }
+    DSW_LAUNCH(bwd3_wprep_kernel, dim3(3), dim3(256), 0, stream, static_cast<const float*>(W), static_cast<unsigned char*>(ws));
+    if ((*rc = dsw_check_launch()) != DSW_OK) return 1;
+    *rc = launch_bwd3(A, nwg, lds, stream);
     return 1;
 }
