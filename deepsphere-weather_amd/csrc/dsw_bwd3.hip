@@ -23,9 +23,10 @@
 // them - a first version with ONE 1024-thread workgroup per CU (W image in LDS, 141 KB) ran its 16 waves in lockstep
 // through five barriers per sample: 216 us against the 157 us of the launches it replaces.  What fits two workgroups:
 //   * the chunk image is single-buffered (two barriers per chunk step);
-//   * the W fragments live in REGISTERS: waves 0-3 hold plane 2 (needed on every row block), waves 4-7 planes 1 and 0'
-//     (1-ring / tile rows) - 48 registers, the MFMA work of the two groups is balanced (60 / 66 per wave and sample); the
-//     fragments come ready-made from a 36 KB image in the caller's workspace (bwd3_wprep_kernel: split once per call);
+//   * the W fragments live in REGISTERS: waves 0-3 hold plane 2 (needed on every row block), waves 4-7 plane 1 (1-ring) - 24
+//     registers - and fetch plane 0' (tile rows: one chunk step per sample) when they need it; the MFMA work of the two groups
+//     is balanced (60 / 66 per wave and sample); the fragments come ready-made from a 36 KB image in the caller's workspace
+//     (bwd3_wprep_kernel: split once per call);
 //   * dY rows are prefetched two chunk steps ahead through a ring of two register slots.
 #include <cstdlib>
 #include "dsw_common.h"
@@ -43,7 +44,9 @@ static __device__ __forceinline__ void st16_nt(char* p, const T4& v) {
 constexpr int NTH = 512;
 constexpr int XB = 128;          // bytes of a dX / G row in HBM (32 fp32 channels)
 constexpr int YB = 256;          // bytes of a dY row (64 fp32 channels)
-constexpr int GS = 144;          // LDS stride of a G row: 128 + 16 (the 16 rows of an accumulator store hit distinct banks)
+constexpr int GS = 144;          // LDS stride of a G_2 row: 128 + 16 (the 16 rows of an accumulator store hit distinct banks)
+constexpr int GS1 = 128;         // ... of a G_1 / G_0' row: dense (the fattest nside-64 tile - 175 / 115 rows - must fit 80 KB;
+                                 // their accumulator stores take the 4-way conflict: 22 wave stores per sample)
 constexpr int IMG_TERM = 64 * 128;           // one term of a 64-row chunk image
 constexpr int IMG_BYTES = 3 * IMG_TERM;      // 24 KB
 constexpr int WFRAG_BYTES = 3 * 2 * 2 * 3 * 64 * 16;   // [plane][fb][ks][term][lane] x 16 B: the W fragments, 36 KB (workspace)
@@ -89,6 +92,7 @@ static __device__ __forceinline__ void split_store4(unsigned char* __restrict__ 
 
 // acc += sum_j val[j] * buf[pos[j]] over the first W entries of one ELL row (fp32 values + u8 list positions, padded with
 // {own row, 0}); bufc = G buffer + this lane's byte offset in a row; rows GS bytes apart
+template <unsigned GS>
 static __device__ __forceinline__ void gather_ell(const unsigned char* __restrict__ row_idx, const float* __restrict__ row_val,
                                                   const int W, const unsigned char* __restrict__ bufc, float (&acc)[4]) {
     int j = 0;
@@ -158,8 +162,8 @@ __global__ __launch_bounds__(NTH, 4) void cheb3_bwd_fused_kernel(const Bwd3Args 
     unsigned char* img = lds;                                               // [3 terms][64 rows][128 B]
     unsigned char* g2 = img + IMG_BYTES;                                    // [max_n2][GS] G_2 on the 2-ring
     unsigned char* g1 = g2 + (size_t)P.max_n2 * GS;                         // [max_n1][GS] G_1, then H_1, on the 1-ring
-    unsigned char* g0 = g1 + (size_t)P.max_n1 * GS;                         // [64][GS]     G_0' on the tile
-    float* ell_val = reinterpret_cast<float*>(g0 + 64 * GS);                // [max_n1][W]
+    unsigned char* g0 = g1 + (size_t)P.max_n1 * GS1;                        // [64][GS1]    G_0' on the tile
+    float* ell_val = reinterpret_cast<float*>(g0 + 64 * GS1);               // [max_n1][W]
     unsigned char* ell_idx = reinterpret_cast<unsigned char*>(ell_val + (size_t)P.max_n1 * P.ell_w);   // [max_n1][W] u8
     int* rows = reinterpret_cast<int*>(ell_idx + (((size_t)P.max_n1 * P.ell_w + 3) & ~(size_t)3));   // [max_n2] global row ids
     int* tile_w = rows + ((P.max_n2 + 3) & ~3);
@@ -229,17 +233,15 @@ __global__ __launch_bounds__(NTH, 4) void cheb3_bwd_fused_kernel(const Bwd3Args 
     const int wave = tid >> 6, lane = tid & 63;
     const int pg = wave >> 2, fb = wave & 1, rbh = (wave >> 1) & 1;
     const unsigned l15 = (unsigned)(lane & 15), kc = (unsigned)(lane >> 4);
-    bf16x8_t wa[2][2][3];                            // [pg 0: plane 2, - | pg 1: plane 1, plane 0'][k-step][term]
+    bf16x8_t wa[2][3];                               // [k-step][term] of plane 2 (pg 0) / plane 1 (pg 1): resident
+    const unsigned char* wf_lane = P.wfrag + (size_t)lane * 16;
     {
-        const int planes[2] = {pg == 0 ? 2 : 1, 0};
+        const int plane = pg == 0 ? 2 : 1;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-                    wa[a][ks][t] = *reinterpret_cast<const bf16x8_t*>(
-                        P.wfrag + ((size_t)(((planes[a] * 2 + fb) * 2 + ks) * 3 + t)) * 1024 + (size_t)lane * 16);
+            for (int t = 0; t < 3; ++t)
+                wa[ks][t] = *reinterpret_cast<const bf16x8_t*>(wf_lane + ((size_t)(((plane * 2 + fb) * 2 + ks) * 3 + t)) * 1024);
     }
     __syncthreads();   // ELL complete (lrp in g1 dead)
     const int Wt = *tile_w;
@@ -258,15 +260,25 @@ __global__ __launch_bounds__(NTH, 4) void cheb3_bwd_fused_kernel(const Bwd3Args 
             split_store4(img, IMG_TERM, (unsigned)(srow + 32 * j), sq, f4);
         }
         if (t + 2 < total) { load_step(pb, pc, slot); advance_req(); }
-        __syncthreads();   // image complete; everybody is past the hops of the previous sample
         const int c = cc;
+        const bool tile_rows = pg == 1 && c == 0;    // plane 0' as well: on the tile rows, i.e. in the first chunk of a sample
+        // plane 0' fragments (tile rows only: one chunk step in nch) are fetched per use from the image in the workspace (L1 / L2
+        // hits, issued here, needed behind the barrier): resident they cost the 24 registers that decide between 128 and spills
+        bf16x8_t w0[2][3];
+        if (tile_rows) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt)
+                    w0[ks][tt] = *reinterpret_cast<const bf16x8_t*>(wf_lane + ((size_t)(((0 * 2 + fb) * 2 + ks) * 3 + tt)) * 1024);
+        }
+        __syncthreads();   // image complete; everybody is past the hops of the previous sample
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
             const int rb = 2 * rbh + h;
             const int p0 = 64 * c + 16 * rb;                 // first list position of the row block
             const bool need = pg == 0 ? p0 < n2 : p0 < n1;   // uniform per wave
             if (need) {
-                const bool tile_rows = pg == 1 && c == 0;    // plane 0' as well
                 f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, acc0 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {             // one k-step of B fragments live at a time (registers)
@@ -274,12 +286,17 @@ __global__ __launch_bounds__(NTH, 4) void cheb3_bwd_fused_kernel(const Bwd3Args 
                     const unsigned o = img_off(16u * rb + l15, 4u * ks + kc);
 #pragma unroll
                     for (int tt = 0; tt < 3; ++tt) bf[tt] = *reinterpret_cast<const bf16x8_t*>(img + (size_t)tt * IMG_TERM + o);
-                    acc = mfma6(wa[0][ks], bf, acc);
-                    if (tile_rows) acc0 = mfma6(wa[1][ks], bf, acc0);
+                    acc = mfma6(wa[ks], bf, acc);
+                    if (tile_rows) acc0 = mfma6(w0[ks], bf, acc0);
                 }
-                const unsigned gst = (unsigned)(p0 + (int)l15) * GS + (16u * fb + 4u * kc) * 4u;   // 16 bytes of a G row
-                if (p0 + (int)l15 < (pg == 0 ? n2 : n1)) *reinterpret_cast<f32x4_t*>((pg == 0 ? g2 : g1) + gst) = acc;
-                if (tile_rows) *reinterpret_cast<f32x4_t*>(g0 + gst) = acc0;
+                const unsigned gcol = (16u * fb + 4u * kc) * 4u;                                  // 16 bytes of a G row
+                const unsigned grow_ = (unsigned)(p0 + (int)l15);
+                if (pg == 0) {
+                    if ((int)grow_ < n2) *reinterpret_cast<f32x4_t*>(g2 + grow_ * GS + gcol) = acc;
+                } else {
+                    if ((int)grow_ < n1) *reinterpret_cast<f32x4_t*>(g1 + grow_ * GS1 + gcol) = acc;
+                    if (tile_rows) *reinterpret_cast<f32x4_t*>(g0 + grow_ * GS1 + gcol) = acc0;
+                }
             }
         }
         __syncthreads();   // the image may be overwritten; after the last chunk: G_2, G_1, G_0' complete
@@ -290,8 +307,8 @@ __global__ __launch_bounds__(NTH, 4) void cheb3_bwd_fused_kernel(const Bwd3Args 
                 const int i = grp + 64 * k;
                 if (i < n1) {
                     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                    gather_ell(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, g2 + gcb, acc);
-                    float4* hp = reinterpret_cast<float4*>(g1 + (size_t)i * GS + gcb);
+                    gather_ell<GS>(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, g2 + gcb, acc);
+                    float4* hp = reinterpret_cast<float4*>(g1 + (size_t)i * GS1 + gcb);
                     const float4 g = *hp;
                     *hp = make_float4(fmaf(2.f, acc[0], g.x), fmaf(2.f, acc[1], g.y), fmaf(2.f, acc[2], g.z), fmaf(2.f, acc[3], g.w));
                 }
@@ -300,8 +317,8 @@ __global__ __launch_bounds__(NTH, 4) void cheb3_bwd_fused_kernel(const Bwd3Args 
             // ---- hop 2: dX = G_0' + L^T H_1 on the tile rows -> HBM
             if (grp < rt) {
                 float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                gather_ell(ell_idx + (size_t)grp * W, ell_val + (size_t)grp * W, Wt, g1 + gcb, acc);
-                const float4 g = *reinterpret_cast<const float4*>(g0 + (size_t)grp * GS + gcb);
+                gather_ell<GS1>(ell_idx + (size_t)grp * W, ell_val + (size_t)grp * W, Wt, g1 + gcb, acc);
+                const float4 g = *reinterpret_cast<const float4*>(g0 + (size_t)grp * GS1 + gcb);
                 const float4 o = make_float4(g.x + acc[0], g.y + acc[1], g.z + acc[2], g.w + acc[3]);
                 st16_nt(P.dX + (size_t)cb * x_sample + (size_t)rows[grp] * XB + gcb, o);
             }
@@ -319,7 +336,7 @@ __global__ __launch_bounds__(NTH, 4) void cheb3_bwd_fused_kernel(const Bwd3Args 
 
 size_t bwd3_lds_bytes(const dsw_hop2_plan* plan) {
     const int ell_w = (plan->reserved + 3) & ~3;
-    size_t s = (size_t)IMG_BYTES + ((size_t)plan->max_n2 + plan->max_n1 + 64) * GS;
+    size_t s = (size_t)IMG_BYTES + (size_t)plan->max_n2 * GS + ((size_t)plan->max_n1 + 64) * GS1;
     s += (size_t)plan->max_n1 * ell_w * 4 + (((size_t)plan->max_n1 * ell_w + 3) & ~(size_t)3);   // fp32 values + u8 positions
     s += (size_t)((plan->max_n2 + 3) & ~3) * 4 + 16;
     return (s + 15) & ~(size_t)15;

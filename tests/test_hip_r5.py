@@ -269,3 +269,19 @@ def test_backward_in_one_launch_non_symmetric_operator(monkeypatch):
     dx64, dw64, _db = orc.cheb_backward_f64(rp, ci, va, xn, wn, gy.cpu().numpy(), True)
     assert orc.max_rel_err(x.grad, dx64) <= 2e-6
     assert orc.max_rel_err(layer.weight.grad, dw64) <= 4e-6
+
+
+def test_north_star_shape_takes_the_one_launch_paths():
+    """The nside-64 k = 8 plan (fattest tile: 175 / 115 rows) must fit the LDS budgets of BOTH one-launch kernels - a silent
+    fall-back to the generic sequences would pass every parity test and cost 10 % of the headline step."""
+    from dsw_amd import _native, functional as F_, sphere
+    from modules.layers import prepare_torch_laplacian
+
+    g = sphere.SphereHealpix(64, nest=True, k=8)
+    op = F_.get_operator(prepare_torch_laplacian(g.L, lmax=1.95).to(DEV))
+    x = torch.empty(1, op.shape[0], 32, device=DEV)
+    lib = _native.load()
+    pf, _k1 = F_._plan_ptr(op, x)
+    pt, _k2 = F_._plan_ptr(op.transpose(), x)
+    assert int(lib.dsw_cheb_fwd_path(pf, 32, 64, 3, 0)) == 3           # DSW_FWD_ONE_LAUNCH
+    assert int(lib.dsw_cheb_bwd_one_launch(pt, 32, 64, 3, 0)) == 1
