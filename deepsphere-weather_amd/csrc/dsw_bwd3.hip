@@ -259,7 +259,6 @@ __global__ __launch_bounds__(NTH, 4) void cheb3_bwd_fused_kernel(const Bwd3Args 
                                  __uint_as_float(slot[j][3])};
             split_store4(img, IMG_TERM, (unsigned)(srow + 32 * j), sq, f4);
         }
-        if (t + 2 < total) { load_step(pb, pc, slot); advance_req(); }
         const int c = cc;
         const bool tile_rows = pg == 1 && c == 0;    // plane 0' as well: on the tile rows, i.e. in the first chunk of a sample
         // plane 0' fragments (tile rows only: one chunk step in nch) are fetched per use from the image in the workspace (L1 / L2
@@ -272,6 +271,12 @@ __global__ __launch_bounds__(NTH, 4) void cheb3_bwd_fused_kernel(const Bwd3Args 
                 for (int tt = 0; tt < 3; ++tt)
                     w0[ks][tt] = *reinterpret_cast<const bf16x8_t*>(wf_lane + ((size_t)(((0 * 2 + fb) * 2 + ks) * 3 + tt)) * 1024);
         }
+        // the slot takes the step two ahead - UNCONDITIONALLY (past the end: the last step again) and BEHIND the fragment loads:
+        // the loads retire in order, so the wait for the fragments leaves these two in flight (s_waitcnt vmcnt(2)); issued
+        // under a condition, or in front, the compiler must drain the queue at every step (a first build did: vmcnt(0) in
+        // front of the second k-step, i.e. an HBM round trip per chunk step, 210 us)
+        load_step(pb, pc, slot);
+        if (t + 3 < total) advance_req();
         __syncthreads();   // image complete; everybody is past the hops of the previous sample
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
@@ -328,10 +333,12 @@ __global__ __launch_bounds__(NTH, 4) void cheb3_bwd_fused_kernel(const Bwd3Args 
         cb += last;
         cc = last ? 0 : c + 1;
     };
-    for (int t = 0; t < total; t += 2) {
-        step(ring0, t);
-        if (t + 1 < total) step(ring1, t + 1);
+    int t = 0;
+    for (; t + 1 < total; t += 2) {    // (both steps unconditional inside the loop: the compiler can then count the loads of the
+        step(ring0, t);                //  other slot as younger than the ones it waits for - s_waitcnt vmcnt(2), not vmcnt(0))
+        step(ring1, t + 1);
     }
+    if (t < total) step(ring0, t);
 }
 
 size_t bwd3_lds_bytes(const dsw_hop2_plan* plan) {
