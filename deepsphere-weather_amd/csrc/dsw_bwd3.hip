@@ -78,6 +78,9 @@ static __device__ __forceinline__ unsigned img_off(const unsigned r, const unsig
 // the three bf16 images of 4 consecutive channels (quad q of the row's 16) of one image row -> LDS (8 bytes per term)
 static __device__ __forceinline__ void split_store4(unsigned char* __restrict__ img, const int term_stride, const unsigned row,
                                                     const unsigned q, const float (&f)[4]) {
+#ifdef DSW_ABL_B3_NOSPLIT       // ablation builds only (refused by _native.load unless named by DSW_HIP_LIB)
+    if (q < 64) return;
+#endif
     float r1[4], r2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -95,6 +98,9 @@ static __device__ __forceinline__ void split_store4(unsigned char* __restrict__ 
 template <unsigned GS>
 static __device__ __forceinline__ void gather_ell(const unsigned char* __restrict__ row_idx, const float* __restrict__ row_val,
                                                   const int W, const unsigned char* __restrict__ bufc, float (&acc)[4]) {
+#ifdef DSW_ABL_B3_NOGATHER
+    acc[0] = row_val[0]; return;
+#endif
     int j = 0;
     for (; j + 4 <= W; j += 4) {
         const unsigned w = *reinterpret_cast<const unsigned*>(row_idx + j);
@@ -121,6 +127,9 @@ static __device__ __forceinline__ void gather_ell(const unsigned char* __restric
 
 // six leading terms of the split product, smallest first: acc += A (3 terms) x B (3 terms)
 static __device__ __forceinline__ f32x4_t mfma6(const bf16x8_t (&a)[3], const bf16x8_t (&b)[3], f32x4_t acc) {
+#ifdef DSW_ABL_B3_NOMFMA
+    acc[0] += __builtin_bit_cast(f32x4_t, a[0])[0] + __builtin_bit_cast(f32x4_t, b[0])[0]; return acc;
+#endif
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
@@ -197,7 +206,11 @@ __global__ __launch_bounds__(NTH, 4) void cheb3_bwd_fused_kernel(const Bwd3Args 
         const char* base = P.dY + (size_t)b * y_sample + sq * 16u;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
+#ifdef DSW_ABL_B3_NOLOAD
+            dst[j] = u32x4{(unsigned)c, (unsigned)b, 0u, 0u};
+#else
             dst[j] = *reinterpret_cast<const u32x4*>(base + (size_t)((unsigned)rows[min(64 * c + srow + 32 * j, n2 - 1)] * (unsigned)YB));
+#endif
     };
     // ring of two register slots: chunk step t lives in slot t & 1 and is requested two steps ahead
     u32x4 ring0[2], ring1[2];
@@ -289,8 +302,14 @@ __global__ __launch_bounds__(NTH, 4) void cheb3_bwd_fused_kernel(const Bwd3Args 
                 for (int ks = 0; ks < 2; ++ks) {             // one k-step of B fragments live at a time (registers)
                     bf16x8_t bf[3];
                     const unsigned o = img_off(16u * rb + l15, 4u * ks + kc);
+#ifdef DSW_ABL_B3_NOFRAG
+#pragma unroll
+                    for (int tt = 0; tt < 3; ++tt) bf[tt] = wa[ks][tt];
+                    (void)o;
+#else
 #pragma unroll
                     for (int tt = 0; tt < 3; ++tt) bf[tt] = *reinterpret_cast<const bf16x8_t*>(img + (size_t)tt * IMG_TERM + o);
+#endif
                     acc = mfma6(wa[ks], bf, acc);
                     if (tile_rows) acc0 = mfma6(w0[ks], bf, acc0);
                 }
