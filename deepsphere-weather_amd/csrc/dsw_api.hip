@@ -450,9 +450,28 @@ int dsw_cheb_mix_fwd(const void* X, const void* T, const void* W, const void* bi
 
 int dsw_cheb_mix_first(int64_t Fin, int64_t Fout, int64_t K) { return mix_first(Fin, Fout, K) ? 1 : 0; }
 
-int dsw_cheb_bwd_one_launch(const dsw_hop2_plan* plan_t, int64_t Fin, int64_t Fout, int64_t K, int dtype) {
-    if (mix_first(Fin, Fout, K)) return 0;
+int dsw_cheb_dx_one_launch_supported(const dsw_hop2_plan* plan_t, int64_t Fin, int64_t Fout, int64_t K, int dtype) {
     return dsw_cheb3_bwd_fused_eligible(plan_t, Fin, Fout, K, dtype);
+}
+
+int64_t dsw_cheb_dx_one_launch_workspace_bytes(void) { return 3 * 2 * 2 * 3 * 64 * 16 + 256; }
+
+int dsw_cheb_dx_one_launch(const dsw_hop2_plan* plan_t, int64_t V, const void* dY, const void* W, void* dX, void* workspace,
+                           int64_t workspace_bytes, int64_t B, int64_t Fin, int64_t Fout, int64_t K, int dtype,
+                           dsw_stream_t stream) {
+    if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
+    if (V < 0 || B < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
+    if (!dsw_cheb3_bwd_fused_eligible(plan_t, Fin, Fout, K, dtype)) return DSW_ERR_BAD_ARG;
+    if (V == 0 || B == 0) return DSW_OK;
+    if (!dY || !W || !dX) return DSW_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < dsw_cheb_dx_one_launch_workspace_bytes()) return DSW_ERR_WORKSPACE;
+    char* wsa = reinterpret_cast<char*>(round_up((int64_t)(uintptr_t)workspace, 256));
+    int rc = DSW_OK;
+    trace_start(stream);
+    const int took = dsw_cheb3_bwd_fused_try(plan_t, V, dY, W, dX, B, Fin, Fout, K, dtype, (hipStream_t)stream, &rc, wsa,
+                                             workspace_bytes - (wsa - static_cast<char*>(workspace)));
+    trace_mark(stream, DSW_ROLE_BWD_FUSED, V, Fin, Fout);
+    return took ? rc : DSW_ERR_ALIGN;
 }
 
 int dsw_cheb_fwd_path(const dsw_hop2_plan* plan, int64_t Fin, int64_t Fout, int64_t K, int dtype) {
@@ -666,23 +685,8 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
     // (staged one-hop plans only: inside a fused pair the subtracted plane is the staged input of the first hop - no pass
     // is saved there and the fold would only add work)
     const int folded = (K >= 3 && dX != nullptr && N > 0 && plan_t != nullptr && plan_t->hops == 1) ? 1 : 0;
-    if (dX != nullptr && N > 0 && !extras && K == 3 && rowptr_t != nullptr) {
-        // K = 3, 32 -> 64 channels, fp32, two-hop plan of L^T: dX straight from dY in one launch (dsw_bwd3.hip: the dgrad
-        // planes live in LDS only), the weight gradients from the plain wgrad pass - the planes never travel through HBM
-        int rcb = DSW_OK;
-        // (scratch for the split W fragments: the weight-image region behind the wgrad partials)
-        const int64_t S_ = dsw_wgrad_slabs(N, Fin, Fout, K);
-        char* wfr = reinterpret_cast<char*>(partial) + round_up((S_ > 0 ? S_ : 1) * (K * Fin + 1) * Fout * 4, 256);
-        if (dsw_cheb3_bwd_fused_try(plan_t, V, dY, W, dX, B, Fin, Fout, K, dtype, s, &rcb, wfr, w_image_bytes(Fin, Fout, K, dtype))) {
-            trace_mark(stream, DSW_ROLE_BWD_FUSED, V, Fin, Fout);
-            if (rcb != DSW_OK) return rcb;
-            if (dW != nullptr) {
-                rcb = dsw_wgrad_launch(X, T, dY, dW, db, partial, N, Fin, Fout, K, dtype, s, accumulate);
-                trace_mark(stream, DSW_ROLE_BWD_WGRAD, V, Fin, Fout);
-            }
-            return rcb;
-        }
-    }
+    // (dsw_cheb_dx_one_launch - dX straight from dY, dgrad planes in LDS only - exists for the K = 3, 32 -> 64 fp32 shape and is
+    // NOT taken here: measured 203 us against the 157 us it has to beat)
     if (dX != nullptr && dW != nullptr && N > 0 && !extras) {
         // small aligned fp32 layers: dgrad planes and dW partials from ONE pass over dY (dsw_wgrad_x3.hip, FUSE); the fold is
         // applied while that kernel fills its W^T panel

@@ -202,13 +202,34 @@ def test_remap_rows_shared_by_lane_groups_and_the_fused_add(dt, C, B):
         assert torch.equal(gx1, xc.grad) and torch.equal(ga1, add.grad)
 
 
+def _dx_one_launch(layer, gy):
+    """dX through dsw_cheb_dx_one_launch (None when the plan / shape has no such launch)."""
+    from dsw_amd import _native, functional as F_
+
+    lib = _native.load()
+    opt = F_.get_operator(layer.laplacian).transpose()
+    B, V, Fout = gy.shape
+    Fin, K = layer.in_channels, layer.kernel_size
+    probe = torch.empty(1, V, Fin, device=DEV)
+    pp, _keep = F_._plan_ptr(opt, probe)
+    if pp is None or not int(lib.dsw_cheb_dx_one_launch_supported(pp, Fin, Fout, K, 0)):
+        return None
+    nws = int(lib.dsw_cheb_dx_one_launch_workspace_bytes())
+    ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+    dx = torch.full((B, V, Fin), float("nan"), device=DEV)
+    rc = lib.dsw_cheb_dx_one_launch(pp, V, gy.data_ptr(), layer.weight.detach().contiguous().data_ptr(), dx.data_ptr(), ws.data_ptr(),
+                                    nws, B, Fin, Fout, K, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    return dx
+
+
 @pytest.mark.parametrize("nside,knn,B", [(8, 8, 1), (8, 8, 3), (16, 8, 5), (16, 8, 16), (8, 20, 2)])
-def test_backward_in_one_launch_vs_oracle(nside, knn, B, monkeypatch):
-    """K = 3, 32 -> 64 channels, fp32 on a two-hop plan of L^T: dX straight from dY in one launch (dsw_bwd3.hip: dgrad planes on
-    the tile's two-ring in LDS, both L^T hops from LDS) + the plain wgrad pass, against the fp64 oracle - every sample, ragged
-    last tiles (a k = 20 graph of 768 nodes takes the staged one-hop plan instead: the generic route, same answer)."""
-    import ctypes
-    from dsw_amd import _native, functional as F_, sphere
+def test_dx_one_launch_vs_oracle(nside, knn, B, monkeypatch):
+    """dsw_cheb_dx_one_launch (dsw_bwd3.hip: K = 3, 32 -> 64 channels, fp32, two-hop plan of L^T - dgrad planes on the tile's
+    two-ring in LDS, both L^T hops from LDS) against the fp64 oracle and against the dX of dsw_cheb_bwd: every sample, ragged
+    last tiles, odd sample counts (a k = 20 graph takes the staged one-hop plan: not supported, says so)."""
+    from dsw_amd import functional as F_, sphere
     from modules.layers import ConvCheb, prepare_torch_laplacian
     from oracle import cheb_oracle as orc
 
@@ -217,33 +238,24 @@ def test_backward_in_one_launch_vs_oracle(nside, knn, B, monkeypatch):
     lap = prepare_torch_laplacian(g.L, lmax=1.9)
     torch.manual_seed(nside + B)
     layer = ConvCheb(32, 64, 3, laplacian=lap).to(DEV)
-    with torch.no_grad():
-        layer.bias.normal_(0, 0.1)
     V = 12 * nside * nside
     x = torch.randn(B, V, 32, device=DEV, requires_grad=True)
     gy = torch.randn(B, V, 64, device=DEV)
-    y = layer(x)
-    y.backward(gy)
-    torch.cuda.synchronize()
-    opt = F_.get_operator(layer.laplacian).transpose()
-    pp, _keep = F_._plan_ptr(opt, x)
-    one = int(_native.load().dsw_cheb_bwd_one_launch(pp, 32, 64, 3, 0))
-    assert one == (1 if knn == 8 else 0)
+    layer(x).backward(gy)
+    dx = _dx_one_launch(layer, gy)
+    assert (dx is not None) == (knn == 8)
+    if dx is None:
+        return
     rp, ci, va = orc.csr_arrays_from_coo(layer.laplacian.cpu())
-    xn, wn, bn = (t.detach().cpu().numpy() for t in (x, layer.weight, layer.bias))
-    dx64, dw64, db64 = orc.cheb_backward_f64(rp, ci, va, xn, wn, gy.cpu().numpy(), True)
-    assert orc.max_rel_err(x.grad, dx64) <= 2e-6
-    assert orc.max_rel_err(layer.weight.grad, dw64) <= 4e-6
-    assert orc.max_rel_err(layer.bias.grad, db64) <= 4e-6
-    # dX alone (frozen weights) takes the same launch; bit-identical, and repeatable
-    layer.weight.requires_grad_(False); layer.bias.requires_grad_(False)
-    x2 = x.detach().clone().requires_grad_(True)
-    layer(x2).backward(gy)
-    assert torch.equal(x2.grad, x.grad)
+    xn, wn = x.detach().cpu().numpy(), layer.weight.detach().cpu().numpy()
+    dx64, _dw, _db = orc.cheb_backward_f64(rp, ci, va, xn, wn, gy.cpu().numpy(), True)
+    assert orc.max_rel_err(dx, dx64) <= 2e-6
+    assert orc.max_rel_err(dx, x.grad.cpu().numpy()) <= 2e-6
+    assert torch.equal(_dx_one_launch(layer, gy), dx)          # repeatable
 
 
-def test_backward_in_one_launch_non_symmetric_operator(monkeypatch):
-    """The one-launch backward runs on the plan of the TRANSPOSED operator: a non-symmetric L (random row scaling of a HEALPix
+def test_dx_one_launch_non_symmetric_operator(monkeypatch):
+    """The one-launch dX runs on the plan of the TRANSPOSED operator: a non-symmetric L (random row scaling of a HEALPix
     Laplacian) pins L^T against the oracle's autograd-derived backward."""
     import numpy as np
     from scipy import sparse
@@ -261,27 +273,34 @@ def test_backward_in_one_launch_non_symmetric_operator(monkeypatch):
     lap = orc.coo_from_scipy(L).float()
     torch.manual_seed(3)
     layer = ConvCheb(32, 64, 3, laplacian=lap).to(DEV)
-    x = torch.randn(4, 768, 32, device=DEV, requires_grad=True)
+    x = torch.randn(4, 768, 32, device=DEV)
     gy = torch.randn(4, 768, 64, device=DEV)
-    layer(x).backward(gy)
+    dx = _dx_one_launch(layer, gy)
+    assert dx is not None
     rp, ci, va = orc.csr_arrays_from_coo(layer.laplacian.cpu())
-    xn, wn = x.detach().cpu().numpy(), layer.weight.detach().cpu().numpy()
-    dx64, dw64, _db = orc.cheb_backward_f64(rp, ci, va, xn, wn, gy.cpu().numpy(), True)
-    assert orc.max_rel_err(x.grad, dx64) <= 2e-6
-    assert orc.max_rel_err(layer.weight.grad, dw64) <= 4e-6
+    dx64, _dw, _db = orc.cheb_backward_f64(rp, ci, va, x.cpu().numpy(), layer.weight.detach().cpu().numpy(), gy.cpu().numpy(), True)
+    assert orc.max_rel_err(dx, dx64) <= 2e-6
 
 
-def test_north_star_shape_takes_the_one_launch_paths():
-    """The nside-64 k = 8 plan (fattest tile: 175 / 115 rows) must fit the LDS budgets of BOTH one-launch kernels - a silent
-    fall-back to the generic sequences would pass every parity test and cost 10 % of the headline step."""
+def test_north_star_shape_one_launch_paths_full_size():
+    """The nside-64 k = 8 plan (fattest tile: 175 / 115 rows) fits the LDS budgets of the one-launch forward (taken by
+    dsw_cheb_fwd: a silent fall-back would cost 10 % of the headline step) and of the one-launch dX, which agrees with the
+    dX of dsw_cheb_bwd in every element of the full north-star batch."""
     from dsw_amd import _native, functional as F_, sphere
-    from modules.layers import prepare_torch_laplacian
+    from modules.layers import ConvCheb, prepare_torch_laplacian
+    from oracle import cheb_oracle as orc
 
     g = sphere.SphereHealpix(64, nest=True, k=8)
-    op = F_.get_operator(prepare_torch_laplacian(g.L, lmax=1.95).to(DEV))
-    x = torch.empty(1, op.shape[0], 32, device=DEV)
+    lap = prepare_torch_laplacian(g.L, lmax=1.95)
+    torch.manual_seed(10)
+    layer = ConvCheb(32, 64, 3, laplacian=lap).to(DEV)
+    op = F_.get_operator(layer.laplacian)
+    x = torch.randn(16, op.shape[0], 32, device=DEV, requires_grad=True)
+    gy = torch.randn(16, op.shape[0], 64, device=DEV)
     lib = _native.load()
     pf, _k1 = F_._plan_ptr(op, x)
-    pt, _k2 = F_._plan_ptr(op.transpose(), x)
     assert int(lib.dsw_cheb_fwd_path(pf, 32, 64, 3, 0)) == 3           # DSW_FWD_ONE_LAUNCH
-    assert int(lib.dsw_cheb_bwd_one_launch(pt, 32, 64, 3, 0)) == 1
+    layer(x).backward(gy)
+    dx = _dx_one_launch(layer, gy)
+    assert dx is not None
+    assert orc.max_rel_err(dx, x.grad.cpu().numpy()) <= 2e-6

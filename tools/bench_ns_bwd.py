@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""dsw_cheb_bwd with dX only (the one-launch dgrad + adjoint at the north-star shape) replayed from a HIP graph: us per call.
-    DSW_HIP_LIB=_ab_libs/x.so python tools/bench_ns_bwd.py"""
+"""dX of the north-star layer from dY, replayed from HIP graphs: dsw_cheb_dx_one_launch (dsw_bwd3.hip) next to the dX-only
+dsw_cheb_bwd (dgrad GEMM + adjoint pair), us per call.    DSW_HIP_LIB=_ab_libs/x.so python tools/bench_ns_bwd.py"""
 import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(REPO, "deepsphere-weather_amd"), REPO]
@@ -25,34 +25,48 @@ ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
 pt, _k2 = F_._plan_ptr(opt, x)
 
 
+nws1 = int(lib.dsw_cheb_dx_one_launch_workspace_bytes())
+ws1 = torch.empty(nws1, dtype=torch.uint8, device="cuda")
+
+
+def one():
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.dsw_cheb_dx_one_launch(pt, V, dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ws1.data_ptr(), nws1, B, fin, fout, K, 0, st) == 0
+
+
 def bwd():
     st = torch.cuda.current_stream().cuda_stream
     assert lib.dsw_cheb_bwd(opt.rowptr.data_ptr(), opt.colind.data_ptr(), opt.values.data_ptr(), V, opt.nnz, x.data_ptr(), T.data_ptr(),
                             w.data_ptr(), dy.data_ptr(), dx.data_ptr(), None, None, ws.data_ptr(), nb, B, fin, fout, K, 0, st, pt) == 0
 
 
-s = torch.cuda.Stream()
-s.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(s):
-    for _ in range(3):
-        bwd()
-torch.cuda.current_stream().wait_stream(s)
-torch.cuda.synchronize()
-gr = torch.cuda.CUDAGraph()
-with torch.cuda.graph(gr):
-    for _ in range(20):
-        bwd()
-t_end = time.time() + 1.0
-while time.time() < t_end:
-    gr.replay()
-torch.cuda.synchronize()
-a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-ts = []
-for _ in range(5):
-    a.record()
-    for _ in range(20):
-        gr.replay()
-    b.record()
+def graphed_us(fn):
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
-    ts.append(a.elapsed_time(b) * 1e3 / 400)
-print("%s: dX-only backward %.1f us" % (os.environ.get("DSW_HIP_LIB", "product").split("/")[-1], sorted(ts)[2]), flush=True)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        for _ in range(20):
+            fn()
+    t_end = time.time() + 1.0
+    while time.time() < t_end:
+        gr.replay()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(5):
+        a.record()
+        for _ in range(20):
+            gr.replay()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3 / 400)
+    return sorted(ts)[2]
+
+
+print("%s: dX in one launch %.1f us | dX-only dsw_cheb_bwd (dgrad GEMM + adjoint pair) %.1f us" % (
+    os.environ.get("DSW_HIP_LIB", "product").split("/")[-1], graphed_us(one), graphed_us(bwd)), flush=True)
