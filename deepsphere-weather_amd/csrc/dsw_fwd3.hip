@@ -177,17 +177,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
     const long nwg = gridDim.x, orig = blockIdx.x;                          // XCD-aware order (see dsw_spmm2.hip)
     const long q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
     const long wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
-    // (tile, batch chunk) of this workgroup: CHUNK-major - all tiles of the first samples, then all tiles of the next - so that the
-    // launch sweeps the tensors in memory order (sample-major) and what it touched last is what the next launch of a step,
-    // walking the other way (dsw_wgrad_x3.hip), finds in the Infinity Cache; neighbouring workgroups = neighbouring tiles of
-    // the same samples either way (L2 sharing of the halo rows)
-#ifdef DSW_ORDER_OLD
     const int tile = (int)(wg / P.n_chunks);
     const int chunk = (int)(wg - (long)tile * P.n_chunks);
-#else
-    const int chunk = (int)(wg / P.n_tiles);
-    const int tile = (int)(wg - (long)chunk * P.n_tiles);
-#endif
     const int b_begin = chunk * P.spc;
     const int b_end = min(P.B, b_begin + P.spc);
     const int* meta = P.tile_meta + (size_t)tile * 6;

@@ -159,7 +159,6 @@ struct WgradParams {
     long N;
     int Fin, Fout, K;
     long rows_per_slab;
-    int interleave;      // 1: workgroup s takes the 32-row chunks s, s + S, s + 2 S .. of the flat rows, LAST first (see dsw_wgrad_x3.hip)
     int tiles_per_plane;    // ceil(Fin / 32)
     int t_vec, dy_vec;
     // mix-first backward (dW_k = X^T D_k): the dY side has `dy_planes` planes (plane 0 = dY, plane z >= 1 =

@@ -138,20 +138,6 @@ __global__ __launch_bounds__(64 * NW, FUSE ? 2 : 1) void cheb_wgrad_x3_kernel(co
     const bool do_db = blockIdx.y == 0 && zk == 0;
     const long n_begin = (long)blockIdx.x * P.rows_per_slab;
     const long n_end = (n_begin + P.rows_per_slab < P.N) ? n_begin + P.rows_per_slab : P.N;
-    // Row order.  Contiguous slabs (workgroup s streams rows [s rps, (s + 1) rps) upwards), or INTERLEAVED + DESCENDING (the fused
-    // dgrad variant): workgroup s takes the 32-row chunks s, s + S, s + 2 S, .. of the flat [B V] rows and walks them from
-    // the last to the first - at any moment all S workgroups work on ONE contiguous window of S x 32 rows that moves from the
-    // last sample to the first.  The launch is then ordered in TIME like the tensors are in memory, which is what lets the 256 MB
-    // Infinity Cache carry data between consecutive launches of a step: the T planes the forward wrote last (its last
-    // samples, chunk-major order in dsw_fwd3.hip) are read here first, and the dgrad planes written last (sample 0) are what
-    // the adjoint pair reads first.  (The partial sums of a workgroup are over other rows than with slabs: still one fixed
-    // order, bit-identical from run to run.)
-    const bool il = FUSE && P.interleave != 0;
-    const long S_il = gridDim.x;
-    const long chunks_il = il ? ((P.N / WR) - (long)blockIdx.x + S_il - 1) / S_il : 0;
-    auto crow = [&](const long ci) __attribute__((always_inline)) {
-        return il ? ((chunks_il - 1 - ci) * S_il + (long)blockIdx.x) * WR : n_begin + ci * WR;
-    };
     const void* A = (k == 0) ? P.X : P.T;
     const size_t abase = (k == 0) ? 0 : (size_t)(k - 1) * P.plane_stride;
     const void* dYp = zk == 0 ? P.dY : P.dY1;
@@ -202,11 +188,11 @@ __global__ __launch_bounds__(64 * NW, FUSE ? 2 : 1) void cheb_wgrad_x3_kernel(co
         }
     };
 
-    const long n_chunks = il ? (chunks_il > 0 ? chunks_il : 0) : (n_end - n_begin) / WR;     // ALIGNED: whole chunks only
+    const long n_chunks = (n_end - n_begin) / WR;     // ALIGNED: whole chunks only
     if (n_chunks > 0) {
-        fetch(crow(0), rt0, rd0);
-        fetch(crow(1 < n_chunks ? 1 : n_chunks - 1), rt1, rd1);
-        if constexpr (PF == 3) fetch(crow(2 < n_chunks ? 2 : n_chunks - 1), rt2, rd2);
+        fetch(n_begin, rt0, rd0);
+        fetch(n_begin + (1 < n_chunks ? 1 : n_chunks - 1) * WR, rt1, rd1);
+        if constexpr (PF == 3) fetch(n_begin + (2 < n_chunks ? 2 : n_chunks - 1) * WR, rt2, rd2);
     }
     const long n_pad = (n_chunks + PF - 1) / PF * PF;
 
@@ -249,7 +235,7 @@ __global__ __launch_bounds__(64 * NW, FUSE ? 2 : 1) void cheb_wgrad_x3_kernel(co
         __syncthreads();
         {
             const long nx = ci + PF;
-            fetch(crow(nx < n_chunks ? nx : n_chunks - 1), srt, srd);
+            fetch(n_begin + (nx < n_chunks ? nx : n_chunks - 1) * WR, srt, srd);
         }
         if (live && active) {
             const unsigned short* ta = tw + frag_off;
@@ -305,7 +291,7 @@ __global__ __launch_bounds__(64 * NW, FUSE ? 2 : 1) void cheb_wgrad_x3_kernel(co
                 }
                 float* Gp = (k == 0) ? static_cast<float*>(P.G0)
                                      : static_cast<float*>(P.Grest) + (size_t)(k - 1) * P.plane_stride;
-                const long nrow = crow(ci) + 4 * half;
+                const long nrow = n_begin + ci * WR + 4 * half;
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                     // plain stores: the adjoint pair reads these planes next, partly out of the Infinity Cache
@@ -616,11 +602,6 @@ int launch_wx3(WgradParams& P, int groups, int otiles, int64_t max_slabs, int64_
     if (rps < 4 * WR) rps = 4 * WR;
     const int64_t S = (P.N + rps - 1) / rps;
     P.rows_per_slab = rps;
-#ifdef DSW_ORDER_OLD          // A/B builds: contiguous slabs
-    P.interleave = 0;
-#else
-    P.interleave = (FUSE && P.N % WR == 0) ? 1 : 0;
-#endif
     *S_out = S;
     dim3 grid((unsigned)S, (unsigned)groups, (unsigned)zdim);
     DSW_LAUNCH((cheb_wgrad_x3_kernel<BF16IO, NSPLIT, NW, NO, FUSE>), grid, dim3(NT_), lds, stream, P);
