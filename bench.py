@@ -1029,7 +1029,7 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, **({"capture_error_mode": "thread_local"} if dist.is_initialized() else {})):
                 step()
             torch.cuda.synchronize()
             graph = g
@@ -1048,12 +1048,14 @@ def main():
             want = bucket.bucket.clone()
             g1 = gm = None
             try:
+                # ("thread_local": RCCL's watchdog thread polls events while this thread records - an error under the default
+                # global capture mode, and one that ends the process)
                 g1 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1):
+                with torch.cuda.graph(g1, capture_error_mode="thread_local"):
                     step()
                     sync_grads()
                 gm = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gm):
+                with torch.cuda.graph(gm, capture_error_mode="thread_local"):
                     for _ in range(GRAPH_STEPS):
                         step()
                         sync_grads()

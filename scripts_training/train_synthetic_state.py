@@ -162,7 +162,11 @@ class Trainer:
             # sit in the graph as well (N > 1: one replay = the whole step).  gloo's are host calls: they follow the replay.
             self.sync_in_graph = self.distributed and self.bucket.graph_capturable
             self.bucket.capturing = True      # the hooks must not enqueue collectives into the recording
-            with torch.cuda.graph(g):
+            # "thread_local": RCCL's watchdog thread polls the events of the warm-up collectives (hipEventQuery) while this
+            # thread records; under the default global capture mode such a call from ANOTHER thread is an error that ends the
+            # process (seen once in ~10 runs of the one-rank RCCL test: ProcessGroupNCCL watchdog abort)
+            mode = {"capture_error_mode": "thread_local"} if self.distributed else {}
+            with torch.cuda.graph(g, **mode):
                 self.loss = self._fwd_bwd()
                 if self.sync_in_graph:
                     self.bucket.finish()      # all chunks back to back, as nodes of the graph
