@@ -17,9 +17,11 @@ for t in default unet c3 k20; do cp $root/gpurun_out/prof_${tag}_$t/${tag}_${t}_
 bash tools/prof_stats.sh ${tag}_c5 --workload c5 --no-cpu-baseline --steps 20 > $out/stats_c5.txt 2>&1
 cp $root/gpurun_out/prof_${tag}_c5/${tag}_c5_kernel_stats.csv $out/${tag}_c5_kernel_stats.csv 2>/dev/null
 # SQ / TCC counters of the whole step (what each kernel is bound by), per workload
-bash tools/prof_pmc.sh ${tag}_ns > $out/${tag}_ns_pmc_summary.txt 2>&1
+BENCH_ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-roofline" bash tools/prof_pmc.sh ${tag}_ns > $out/${tag}_ns_pmc_summary.txt 2>&1
 BENCH_ARGS="--knn 20 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline" bash tools/prof_pmc.sh ${tag}_k20 > $out/${tag}_k20_pmc_summary.txt 2>&1
 BENCH_ARGS="--workload c3 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline" bash tools/prof_pmc.sh ${tag}_c3 > $out/${tag}_c3_pmc_summary.txt 2>&1
+BENCH_ARGS="--workload unet --steps 5 --warmup 2 --no-cpu-baseline --no-roofline" PMC_PASSES="A B C" bash tools/prof_pmc.sh ${tag}_unet > $out/${tag}_unet_pmc_summary.txt 2>&1
+BENCH_ARGS="--workload c5 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline" PMC_PASSES="A B" bash tools/prof_pmc.sh ${tag}_c5 > $out/${tag}_c5_pmc_summary.txt 2>&1
 # HBM bytes of exactly the launches the roofline entries time (bench.py --pmc-leg) -> profiles/spmm_traffic.json
 bash tools/pmc_traffic.sh ${tag} > $out/traffic.log 2>&1
 cp profiles/spmm_traffic.json $out/spmm_traffic.json

@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r05"
 
 
 def load(name):
@@ -69,7 +69,8 @@ for key, label in names.items():
         "%s us (%s-%s)" % (ps.get("median"), ps.get("p10"), ps.get("p90")) if ps else "-",
         "%.2g /s on %s threads of %s" % (cb["value"], cb.get("cores"), cb.get("host_cpus")) if cb else "-"))
 w("")
-w("`frac` = SURVEY 8(d) algorithmic bytes / HIP-event time / 8 TB/s; in brackets the same time against the HBM bytes the "
+w("`frac` = SURVEY 8(d) algorithmic bytes / IN-GRAPH kernel time / 8 TB/s (durations: rocprofv3 kernel trace of the replayed step "
+  "graph, folded per role by `bench.py`; legs the step does not launch are marked `leg only` and timed isolated); in brackets the same time against the HBM bytes the "
   "counters saw for exactly these launches (`profiles/spmm_traffic.json`, `tools/pmc_traffic.sh`: 2 x FETCH_SIZE + WRITE_SIZE). "
   "A fused pair keeps its intermediate plane on chip: its 8(d) fraction can exceed 1 while the counter fraction says what the "
   "memory system delivered; staged one-hop launches move slightly MORE than the 8(d) count (halo rows that miss L2).")
@@ -77,10 +78,11 @@ w("")
 ns = lines.get("ns_default")
 st = stats("%s_default_kernel_stats.csv" % tag)
 if ns and (ns.get("roofline") or {}).get("in_step"):
-    w("In-step kernels of the default command (`roofline.in_step`: HIP events on the launch stream, SURVEY 8d bytes) next to "
-      "rocprofv3 of the same command (`profiles/%s_default_kernel_stats.csv`):" % tag)
+    w("In-step kernels of the default command (`roofline.in_step`: in-graph kernel durations, SURVEY 8d bytes; their sum is %.3f of "
+      "`ms_per_step`) next to rocprofv3 `--stats` of the same command (`profiles/%s_default_kernel_stats.csv`):" % (
+          ns["roofline"].get("in_step_sum_vs_ms_per_step") or float("nan"), tag))
     w("")
-    w("| role | bench leg us | algorithmic MB -> fraction of 8 TB/s | rocprofv3 kernel (avg us, % of GPU time) |")
+    w("| role | in-graph us (bench.py) | algorithmic MB -> fraction of 8 TB/s | rocprofv3 kernel (avg us, % of GPU time) |")
     w("|---|---|---|---|")
     match = {"forward": "cheb3_fwd_fused_kernel", "backward GEMM": "cheb_wgrad_x3_kernel", "adjoint": "spmm2_fused_kernel<false, 3, true, true"}
     for e in ns["roofline"]["in_step"]:
@@ -96,6 +98,25 @@ for key, fn in (("ns_default", "default"), ("ns_k20", "k20"), ("c3", "c3"), ("un
     top = sorted(rows, key=lambda r_: -r_[1] * r_[2])[:7]
     w("%s (`profiles/%s_%s_kernel_stats.csv`), top kernels by total time: %s." % (
         key, tag, fn, "; ".join("`%s` %d x %.1f us (%.1f %%)" % (n[:46], c, us, pct) for n, c, us, pct in top)))
+    w("")
+for key in ("ns_k20", "c3", "unet", "c5"):
+    ts = ((lines.get(key) or {}).get("roofline") or {}).get("traced_step")
+    if not ts:
+        continue
+    g = ts.get("graph") or {}
+    w("Roles of one %s step (`roofline.traced_step`: order and roles from the library's launch trace, durations in-graph; library "
+      "kernels %.0f us + other kernels = %.0f us per step for %.0f us measured):" % (
+          key, ts["sum_us"], g.get("all_kernels_us_per_step", float("nan")), lines[key]["ms_per_step"] * 1e3))
+    w("")
+    w("| role | shape (V / rows, Fin / C, Fout / K) | calls / step | avg us | us / step |")
+    w("|---|---|---|---|---|")
+    for e in ts["roles"][:12]:
+        w("| %s | %s | %.0f | %.1f | %.1f |" % (e["role"], " x ".join(str(a) for a in e["aux"]), e["calls_per_step"], e["avg_us"], e["us_per_step"]))
+    oth = g.get("other_kernels") or []
+    if oth:
+        w("")
+        w("Kernels of that step that are not the library's (torch glue): " + "; ".join(
+            "`%s` %.1f x %.1f us" % (o["kernel"], o["calls_per_step"], o["us_per_step"] / max(o["calls_per_step"], 1e-9)) for o in oth[:6]) + ".")
     w("")
 for key in ("unet", "c5"):
     po = ((lines.get(key) or {}).get("roofline") or {}).get("pooling")

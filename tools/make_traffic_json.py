@@ -18,7 +18,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_path = os.path.join(ROOT, "profiles", "spmm_traffic.json")
 CALLS = 20
-KERNEL = re.compile(r"(spmm1_dma_kernel<[^>]*>|spmm1_staged_kernel<[^>]*>|spmm2_fused_kernel<[^>]*>|spmm_csr_rowsplit<[^>]*>|spmm_long_rows\w*<[^>]*>)")
+KERNEL = re.compile(r"(spmm1_dma_kernel<[^>]*>|spmm1_staged_kernel<[^>]*>|spmm2_fused_kernel<[^>]*>|spmm_csr_rowsplit<[^>]*>|remap_\w+_kernel<[^>]*>|spmm_long_rows\w*<[^>]*>)")
 tag, keys = sys.argv[1], sys.argv[2:]
 result = {}
 if os.path.exists(out_path):
