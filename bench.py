@@ -407,7 +407,7 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
     ppf, _k3 = F_._plan_ptr(op, x, Fout if mf else C) if K > 2 else (None, None)
     fwd_path = int(lib.dsw_cheb_fwd_path(ppf, C, Fout, K, dcode))
     path_names = {0: "plain hops + GEMM", 1: "fused hop pairs + GEMM", 2: "staged hops + GEMM", 3: "one launch (hops + channel mix)",
-                  4: "mix-first (recurrence on the output channels)"}
+                  4: "mix-first (recurrence on the output channels)", 5: "staged hop 1, then hop 2 + channel mix in one launch"}
     fwd_rec_in_step = fwd_path in (0, 1, 2)
     traced = traced or {}
     IN = next((v["timing"] for v in traced.values() if "timing" in v), "in-step kernel durations (dsw_trace)")
@@ -418,7 +418,8 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
 
     # ---- in-step durations of this layer's roles (None where the step does not run the role / nothing was traced) -------
     t_one = tr("fwd_one_launch", V, C, Fout)
-    t_bfwd = tr("basis_fwd", V, C, K)
+    t_h2m = tr("fwd_hop2_mix", V, C, Fout)             # forward path 5: hop 2 + channel mix in one launch ...
+    t_bfwd = tr("basis_fwd", V, C, 2 if t_h2m is not None else K)     # ... behind the staged hop 1 (traced as a K = 2 basis)
     t_mix = tr("mix_fwd", N, K * C, Fout)
     t_zmix, t_clen = tr("zmix", V, C, Fout), tr("clenshaw_fwd", V, Fout, K)
     t_gemm = tr("bwd_gemm_fused", V, C, Fout)
@@ -429,7 +430,7 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
 
     # forward recurrence alone: in the step where the step launches it, otherwise an isolated leg (north-star gate)
     fwd_s_iso = timed(fwd)
-    fwd_s = t_bfwd["avg_us"] * 1e-6 if (fwd_rec_in_step and t_bfwd is not None) else fwd_s_iso
+    fwd_s = t_bfwd["avg_us"] * 1e-6 if (fwd_rec_in_step and t_bfwd is not None and t_h2m is None) else fwd_s_iso
     adj_s_iso = None
     if t_adj is not None:
         adj_s = t_adj["avg_us"] * 1e-6
@@ -454,6 +455,16 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
     if t_one is not None:
         in_step.append(entry("forward (dsw_cheb_fwd)", "cheb3_fwd_fused: hops + channel mix + bias in ONE launch",
                              t_one["avg_us"] * 1e-6, wf_bytes, t_one["calls_per_step"], {"compulsory_bytes": compulsory_fwd}))
+    elif t_h2m is not None:
+        hop1_b = spmm_algorithmic_bytes(E, Lb, 2)[0]
+        if t_bfwd is not None:
+            in_step.append(entry("forward hop 1 (dsw_cheb_fwd: staged launch, T1 = L X)", "spmm1_dma", t_bfwd["avg_us"] * 1e-6, hop1_b,
+                                 t_bfwd["calls_per_step"]))
+        in_step.append(entry("forward hop 2 + channel mix + bias in ONE launch", "cheb3_hop2mix", t_h2m["avg_us"] * 1e-6,
+                             (fwd_b - hop1_b) + (K * E + yb_bytes), t_h2m["calls_per_step"],
+                             {"compulsory_bytes": int(2 * E + E + yb_bytes),
+                              "bytes_note": "algorithmic = hop 2 (3E + Lb) + the GEMM it replaces (K E in, Y out); compulsory = T1, X in, "
+                                            "T2 (kept for backward) and Y out"}))
     else:
         if t_bfwd is not None:
             in_step.append(entry("forward recurrence (dsw_cheb_fwd: basis launches)", "spmm2_fused / spmm1_dma / spmm_csr hops",
@@ -502,6 +513,8 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
         legs.append(("adj", n_adj, adj_s, bwd_b))
     if fwd_rec_in_step:
         legs.append(("fwd", n_fwd, fwd_s, fwd_b))
+    elif t_h2m is not None and t_bfwd is not None:     # hop 1 is a launch of its own; hop 2 lives in the fused launch (in_step)
+        legs.append(("fwd1", 1, t_bfwd["avg_us"] * 1e-6, spmm_algorithmic_bytes(E, Lb, 2)[0]))
     fused_bwd = t_bwdf is not None
     if fused_bwd:      # the adjoint recurrence lives inside the fused backward launch: that launch against the bytes it replaces
         legs.append(("bwdf", 1, t_bwdf["avg_us"] * 1e-6, yb_bytes + K * E + bwd_b))

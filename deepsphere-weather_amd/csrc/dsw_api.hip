@@ -142,6 +142,10 @@ int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X,
                             void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream,
                             int* rc, int relu);
 int dsw_cheb3_fwd_fused_eligible(const dsw_hop2_plan* plan, int64_t Fin, int64_t Fout, int64_t K, int dtype);
+int dsw_cheb3_hop2mix_eligible(const dsw_hop2_plan* plan, int64_t Fin, int64_t Fout, int64_t K, int dtype);
+int dsw_cheb3_hop2mix_try(const dsw_hop2_plan* plan, int64_t V, const void* X, const void* W, const void* bias, void* Y,
+                          void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int* rc,
+                          int relu, void (*after_hop1)(void*), void* ctx);
 int dsw_cheb3_bwd_fused_try(const dsw_hop2_plan* plan_t, int64_t V, const void* dY, const void* W, void* dX, int64_t B,
                             int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int* rc, void* ws,
                             int64_t ws_bytes);
@@ -479,6 +483,7 @@ int dsw_cheb_fwd_path(const dsw_hop2_plan* plan, int64_t Fin, int64_t Fout, int6
     if (Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
     if (mix_first(Fin, Fout, K)) return DSW_FWD_MIX_FIRST;
     if (dsw_cheb3_fwd_fused_eligible(plan, Fin, Fout, K, dtype)) return DSW_FWD_ONE_LAUNCH;
+    if (dsw_cheb3_hop2mix_eligible(plan, Fin, Fout, K, dtype)) return DSW_FWD_HOP1_THEN_ONE_LAUNCH;   // (given the basis buffer T)
     if (K > 1 && plan != nullptr && dsw_spmm1s_supported(plan, Fin, dtype)) return DSW_FWD_STAGED_HOPS;
     if (K > 2 && plan != nullptr && dsw_spmm2_supported(plan, Fin, dtype)) return DSW_FWD_FUSED_PAIRS;
     return DSW_FWD_PLAIN_HOPS;
@@ -553,6 +558,13 @@ static int cheb_fwd_impl(const int32_t* rowptr, const int32_t* colind, const flo
         int rcf = DSW_OK;
         if (dsw_cheb3_fwd_fused_try(plan, V, X, W, bias, Y, T, B, Fin, Fout, K, dtype, (hipStream_t)stream, &rcf, relu)) {
             trace_mark(stream, DSW_ROLE_FWD_ONE_LAUNCH, V, Fin, Fout);
+            return rcf;
+        }
+        // ... on a one-hop plan (dense stencils): staged hop 1, then hop 2 + channel mix in one launch
+        struct Hop1Ctx { dsw_stream_t s; int64_t V, Fin; } hc = {stream, V, Fin};
+        auto hop1_done = [](void* c) { auto* h = static_cast<Hop1Ctx*>(c); trace_mark(h->s, DSW_ROLE_BASIS_FWD, h->V, h->Fin, 2); };
+        if (dsw_cheb3_hop2mix_try(plan, V, X, W, bias, Y, T, B, Fin, Fout, K, dtype, (hipStream_t)stream, &rcf, relu, hop1_done, &hc)) {
+            trace_mark(stream, DSW_ROLE_FWD_HOP2_MIX, V, Fin, Fout);
             return rcf;
         }
     }

@@ -352,6 +352,201 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
     }
 }
 
+// ---- dense stencils (one-hop plans: the reference's default k = 20 graph, equiangular): hop 2 + channel mix in one launch ------
+// The whole-forward kernel above needs the tile's TWO-ring in LDS, which a 21-32-entry stencil does not leave room for
+// (114 KB).  Here hop 1 stays the staged launch of dsw_spmm1s.hip (T1 = L X through HBM / the Infinity Cache) and THIS kernel
+// is the rest of the forward: per (tile, sample) the T1 rows of the tile + 1-ring are staged in LDS, T2 = 2 L T1 - X is
+// gathered on the tile rows, X / T1 / T2 of the tile rows are split once into the bf16 images and the channel mix runs on
+// the matrix cores as above.  What it replaces re-read X, T1 and T2 (3 of its 5 tensor passes) in a separate GEMM launch:
+// NS at k = 20: hop 2 59 us + GEMM 112 us.  Two barriers per sample, 65 KB of LDS (two workgroups per CU).
+template <int NST, int NCB, bool FULL>
+__global__ __launch_bounds__(NTHREADS, 4) void cheb3_hop2mix_kernel(const Fwd3Args P) {
+    constexpr int RBW = NCB / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* bufT = lds;                                              // [max_n2][128] T1 on the tile + 1-ring
+    unsigned char* simg = bufT + (size_t)P.max_n2 * RB;                     // split images of the tile rows (36 KB)
+    float* ell_val = reinterpret_cast<float*>(simg + SPLIT_BYTES);          // [64][W]
+    unsigned char* ell_idx = reinterpret_cast<unsigned char*>(ell_val + (size_t)64 * P.ell_w);          // [64][W] u8
+    int* rows = reinterpret_cast<int*>(ell_idx + (size_t)64 * P.ell_w);     // [max_n2] global row ids (64 W is a multiple of 4)
+    int* tile_w = rows + ((P.max_n2 + 3) & ~3);
+
+    const long nwg = gridDim.x, orig = blockIdx.x;                          // XCD-aware order (see dsw_spmm2.hip)
+    const long q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const long wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+    const int tile = (int)(wg / P.n_chunks);
+    const int chunk = (int)(wg - (long)tile * P.n_chunks);
+    const int b_begin = chunk * P.spc;
+    const int b_end = min(P.B, b_begin + P.spc);
+    const int* meta = P.tile_meta + (size_t)tile * 6;
+    const int s2_off = meta[0], rt = meta[1], n2 = meta[2], nnz_off = meta[3], rp_off = meta[4];   // one-hop plan: n1 = tile rows
+    const int tid = threadIdx.x;
+    const int W = P.ell_w;
+    const size_t sample_bytes = (size_t)P.V * RB;
+
+    int* lrp = reinterpret_cast<int*>(simg);          // local row pointers of the tile rows, parked in the image area
+    if (tid == 0) *tile_w = 2;
+    for (int i = tid; i < n2; i += NTHREADS) rows[i] = P.s2_rows[s2_off + i];
+    for (int i = tid; i <= rt; i += NTHREADS) lrp[i] = P.lrowptr[rp_off + i];
+    __syncthreads();
+
+    const int grp = tid >> 3;                       // row of a 64-row pass
+    const unsigned c4 = (unsigned)(tid & 7);        // 16-byte chunk (4 channels) of this lane inside a row
+    const unsigned cb = c4 * 16;
+    const unsigned tile_off = (unsigned)rows[min(grp, rt - 1)] * (unsigned)RB + cb;    // this thread's tile row, sample-relative
+    auto offU = [&](const int k) __attribute__((always_inline)) {
+        return (unsigned)rows[min(grp + k * RPP, n2 - 1)] * (unsigned)RB + cb;
+    };
+    const char* T1in = P.T1;
+    u32x4 su[NST];
+    u32x4 xr = {0u, 0u, 0u, 0u};
+    if (b_begin < b_end) {
+        const size_t sb = (size_t)b_begin * sample_bytes;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) su[k] = *reinterpret_cast<const u32x4*>(T1in + sb + offU(k));
+        xr = *reinterpret_cast<const u32x4*>(P.X + sb + tile_off);
+    }
+    const int tile_nnz = lrp[rt];
+    for (int t = tid; t < rt * W; t += NTHREADS) {
+        const int i = t / W, j = t - i * W;
+        const int p0 = lrp[i], p1 = lrp[i + 1];
+        unsigned col = 0;
+        float val = 0.f;
+        if (tile_nnz > 0) {
+            const int p = max(0, min(p0 + j, tile_nnz - 1));
+            col = P.lcol[nnz_off + p];
+            val = P.lval[nnz_off + p];
+        }
+        if (j == 0 && p1 - p0 > 2) atomicMax(tile_w, p1 - p0);
+        const bool live = p0 + j < p1;
+        ell_idx[t] = (unsigned char)(live ? col : (unsigned)i);
+        ell_val[t] = live ? val : 0.f;
+    }
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int cbk = wave % NCB;
+    const int rb0 = (wave / NCB) * RBW;
+    const int l15 = lane & 15, kc = lane >> 4;
+    bf16x8_t wh[3], wm[3], wl[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = P.W[((size_t)(8 * kc + j) * 3 + s) * P.Fout + 16 * cbk + l15];
+        split3x8(f, wh[s], wm[s], wl[s]);
+    }
+    f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (P.bias != nullptr) bias4 = *reinterpret_cast<const f32x4_t*>(P.bias + 16 * cbk + 4 * kc);
+
+    __syncthreads();   // ELL complete (and lrp in the image area dead)
+    const int Wt = *tile_w;
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int i = grp + k * RPP;
+        if (i < n2) *reinterpret_cast<u32x4*>(bufT + (size_t)i * RB + cb) = su[k];
+    }
+
+    for (int b = b_begin; b < b_end; ++b) {
+        __syncthreads();   // A: bufT(b) complete; everybody is past the MFMA phase of sample b-1 (split images free)
+        const size_t sample = (size_t)b * sample_bytes;
+        u32x4 xn;
+        {   // next sample's rows: in flight under the gather
+            const size_t sb = (size_t)(b + 1 < b_end ? b + 1 : b) * sample_bytes;
+#pragma unroll
+            for (int k = 0; k < NST; ++k) su[k] = *reinterpret_cast<const u32x4*>(T1in + sb + offU(k));
+            xn = *reinterpret_cast<const u32x4*>(P.X + sb + tile_off);
+        }
+        // ---- T2 = 2 L T1 - X on the tile rows -> HBM; X, T1, T2 of the tile rows -> split images
+        if (FULL || grp < rt) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            gather_ell(ell_idx + (size_t)grp * W, ell_val + (size_t)grp * W, Wt, bufT + cb, acc);
+            const float xf[4] = {__uint_as_float(xr[0]), __uint_as_float(xr[1]), __uint_as_float(xr[2]), __uint_as_float(xr[3])};
+            const float t2[4] = {fmaf(2.f, acc[0], -xf[0]), fmaf(2.f, acc[1], -xf[1]), fmaf(2.f, acc[2], -xf[2]), fmaf(2.f, acc[3], -xf[3])};
+            st16(P.T2 + sample + tile_off,
+                 make_uint4(__float_as_uint(t2[0]), __float_as_uint(t2[1]), __float_as_uint(t2[2]), __float_as_uint(t2[3])));
+            split_store(simg, 2, grp, c4, t2);
+            const float4 t1 = *reinterpret_cast<const float4*>(bufT + (size_t)grp * RB + cb);
+            const float t1f[4] = {t1.x, t1.y, t1.z, t1.w};
+            split_store(simg, 1, grp, c4, t1f);
+            split_store(simg, 0, grp, c4, xf);
+        }
+        __syncthreads();   // C: nobody reads bufT of this sample any more; split images complete
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int i = grp + k * RPP;
+            if (i < n2) *reinterpret_cast<u32x4*>(bufT + (size_t)i * RB + cb) = su[k];
+        }
+        xr = xn;
+        // ---- Y[tile rows, 16 cbk ..+16] = [X | T1 | T2] W + bias on the matrix cores (as cheb3_fwd_fused_kernel)
+        f32x4_t acc[RBW];
+        unsigned fro[RBW];
+#pragma unroll
+        for (int r = 0; r < RBW; ++r) {
+            const unsigned row = 16u * (rb0 + r) + l15;
+            acc[r] = bias4;
+            fro[r] = row * 64u + (((unsigned)kc ^ ((row >> 2) & 2u)) << 4);
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            bf16x8_t th[RBW], tm[RBW], tl[RBW];
+#pragma unroll
+            for (int r = 0; r < RBW; ++r) {
+                const unsigned char* pb = simg + (size_t)s * (3 * 64 * 64) + fro[r];
+                th[r] = *reinterpret_cast<const bf16x8_t*>(pb);
+                tm[r] = *reinterpret_cast<const bf16x8_t*>(pb + 64 * 64);
+                tl[r] = *reinterpret_cast<const bf16x8_t*>(pb + 2 * 64 * 64);
+            }
+#pragma unroll
+            for (int r = 0; r < RBW; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], th[r], acc[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RBW; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], tl[r], acc[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RBW; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[s], tm[r], acc[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RBW; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[s], th[r], acc[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RBW; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], tm[r], acc[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RBW; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], th[r], acc[r], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < RBW; ++r) {
+            const int row = 16 * (rb0 + r) + l15;
+            if (P.relu) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[r][t] = acc[r][t] < 0.f ? 0.f : acc[r][t];
+            }
+            if (FULL || row < rt)
+                st16(P.Y + (size_t)b * ((size_t)P.V * P.Fout * 4) +
+                         (unsigned)(rows[FULL ? row : min(row, rt - 1)] * P.Fout * 4 + (16 * cbk + 4 * kc) * 4), acc[r]);
+        }
+    }
+}
+
+size_t hop2mix_lds_bytes(const dsw_hop2_plan* plan) {
+    const int ell_w = (plan->reserved + 3) & ~3;
+    size_t s = (size_t)plan->max_n2 * RB + SPLIT_BYTES + (size_t)64 * ell_w * 5;
+    s += (size_t)((plan->max_n2 + 3) & ~3) * 4 + 16;
+    return (s + 15) & ~(size_t)15;
+}
+
+template <int NST, bool FULL>
+int launch_h2m(const Fwd3Args& A, long nwg, size_t lds, hipStream_t stream) {
+#define DSW_H2M(N_)                                                                                                     \
+    case N_: {                                                                                                          \
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)cheb3_hop2mix_kernel<NST, N_, FULL>,                    \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return DSW_ERR_LAUNCH;                                                                                      \
+        DSW_LAUNCH((cheb3_hop2mix_kernel<NST, N_, FULL>), dim3((unsigned)nwg), dim3(NTHREADS), lds, stream, A);         \
+        break;                                                                                                          \
+    }
+    switch (A.Fout / 16) {
+        DSW_H2M(2) DSW_H2M(4)
+        default: return DSW_ERR_BAD_ARG;
+    }
+#undef DSW_H2M
+    return dsw_check_launch();
+}
+
 size_t fwd3_lds_bytes(const dsw_hop2_plan* plan) {
     const int ell_w = (plan->reserved + 3) & ~3;
     size_t s = (size_t)(plan->max_n1 + (size_t)plan->max_n2) * RB + SPLIT_BYTES;
@@ -439,6 +634,71 @@ int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X,
     else if (nst == 2 && ns1 <= 2) r = full ? launch_ncb<2, 2, true>(A, nwg, lds, stream) : launch_ncb<2, 2, false>(A, nwg, lds, stream);
     else if (nst == 3) r = full ? launch_ncb<3, 3, true>(A, nwg, lds, stream) : launch_ncb<3, 3, false>(A, nwg, lds, stream);
     else r = full ? launch_ncb<4, 4, true>(A, nwg, lds, stream) : launch_ncb<4, 4, false>(A, nwg, lds, stream);
+    *rc = r;
+    return 1;
+}
+
+int dsw_spmm1s_supported(const dsw_hop2_plan* plan, int64_t C, int dtype);
+int dsw_spmm1s_launch(const dsw_hop2_plan* plan, int64_t V, const void* U, const void* Z, const void* Z2, void* Y,
+                      int64_t B, int64_t C, float a, float b, float c, int dtype, hipStream_t stream, int stream_out);
+
+// 1 if the forward of this layer on a ONE-hop plan runs as: staged hop 1 (dsw_spmm1s.hip) + ONE launch for hop 2 and the channel mix
+int dsw_cheb3_hop2mix_eligible(const dsw_hop2_plan* plan, int64_t Fin, int64_t Fout, int64_t K, int dtype) {
+    static const char* env = dsw_diag_env("DSW_HOP2MIX");   // "0": staged hops + separate GEMM (diagnostics / A-B)
+    if (env && env[0] == '0') return 0;
+    if (dtype != DSW_F32 || K != 3 || Fin != 32 || (Fout != 32 && Fout != 64)) return 0;
+    if (!plan || plan->hops != 1 || plan->tile_rows != 64 || plan->reserved <= 0 || !dsw_spmm1s_supported(plan, Fin, dtype)) return 0;
+    if (plan->max_n2 > 255 || plan->max_n1 > 64) return 0;     // u8 list positions; tile rows = one pass
+    if (hop2mix_lds_bytes(plan) > 80 * 1024) return 0;          // two workgroups per CU or not at all
+    return (plan->max_n2 + RPP - 1) / RPP <= 3 ? 1 : 0;       // (4 staging slots spill)
+}
+
+// Runs the forward as hop 1 + (hop 2 + channel mix) if the shape / plan allow it.  Returns 1 if it took the call (*rc = status
+// of the launches, *stage = 1 after hop 1 for the caller's tracing), 0 if the caller must use the generic sequence.  T (the
+// basis planes kept for backward) is REQUIRED: T1 travels through it.
+int dsw_cheb3_hop2mix_try(const dsw_hop2_plan* plan, int64_t V, const void* X, const void* W, const void* bias, void* Y,
+                          void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int* rc,
+                          int relu, void (*after_hop1)(void*), void* ctx) {
+    if (T == nullptr || !dsw_cheb3_hop2mix_eligible(plan, Fin, Fout, K, dtype)) return 0;
+    if (!dsw_aligned16(X) || !dsw_aligned16(Y) || !dsw_aligned16(W) || (bias && !dsw_aligned16(bias)) || !dsw_aligned16(T)) return 0;
+    if (V <= 0 || B <= 0) { *rc = DSW_OK; return 1; }
+    const size_t planeb = (size_t)B * (size_t)V * RB;
+    // hop 1: T1 = L X (cached stores: the kernel below gathers it)
+    *rc = dsw_spmm1s_launch(plan, V, X, nullptr, nullptr, T, B, Fin, 1.f, 0.f, 0.f, dtype, stream, 0);
+    if (after_hop1) after_hop1(ctx);
+    if (*rc != DSW_OK) return 1;
+    const size_t lds = hop2mix_lds_bytes(plan);
+    const int nst = (plan->max_n2 + RPP - 1) / RPP;
+    Fwd3Args A;
+    A.tile_meta = plan->tile_meta; A.s2_rows = plan->s2_rows; A.lrowptr = plan->lrowptr;
+    A.lcol = plan->lcol; A.lval = plan->lval;
+    A.X = static_cast<const char*>(X);
+    A.T1 = static_cast<char*>(T);
+    A.T2 = static_cast<char*>(T) + planeb;
+    A.Y = static_cast<char*>(Y);
+    A.W = static_cast<const float*>(W); A.bias = static_cast<const float*>(bias);
+    A.V = (int)V; A.n_tiles = plan->n_tiles; A.max_n1 = plan->max_n1; A.max_n2 = plan->max_n2;
+    A.B = (int)B; A.ell_w = (plan->reserved + 3) & ~3; A.Fout = (int)Fout; A.relu = relu;
+    A.explicit_tiles = plan->explicit_tiles;
+    const long slots = 256L * ((160 * 1024) / (long)lds > 1 ? 2 : 1);
+    long chunks = 1;
+    {
+        double best = -1.0;
+        const long cmax = B > 1 ? (B + 1) / 2 : 1;
+        for (long c = 1; c <= cmax && c <= 16; ++c) {
+            const long rounds = (plan->n_tiles * c + slots - 1) / slots;
+            const double cost = (double)rounds * (1.5 + (double)((B + c - 1) / c));
+            if (best < 0 || cost < best - 1e-9) { best = cost; chunks = c; }
+        }
+    }
+    A.spc = (int)((B + chunks - 1) / chunks);
+    A.n_chunks = (int)((B + A.spc - 1) / A.spc);
+    const long nwg = (long)plan->n_tiles * A.n_chunks;
+    if (nwg > 2147483647L) { *rc = DSW_ERR_BAD_ARG; return 1; }
+    const bool full = (V % 64 == 0) && !plan->explicit_tiles;
+    int r;
+    if (nst <= 2) r = full ? launch_h2m<2, true>(A, nwg, lds, stream) : launch_h2m<2, false>(A, nwg, lds, stream);
+    else r = full ? launch_h2m<3, true>(A, nwg, lds, stream) : launch_h2m<3, false>(A, nwg, lds, stream);
     *rc = r;
     return 1;
 }

@@ -109,6 +109,7 @@ int dsw_build_flags(void);
 #define DSW_ROLE_CLENSHAW_FWD 12   /* mix-first forward: Clenshaw recurrence on the output channels */
 #define DSW_ROLE_ELEMENTWISE 13    /* relu mask (kind 1), ReZero residual forward (2) / backward (3), ReZero parameter gradients (4) */
 #define DSW_ROLE_BWD_FUSED 14      /* dgrad + adjoint recurrence in one launch (dY -> dX) */
+#define DSW_ROLE_FWD_HOP2_MIX 16     /* hop 2 + channel mix + bias of the forward in one launch (one-hop plans) */
 #define DSW_ROLE_BASIS_DUAL 15     /* mix-first backward: Chebyshev basis of dY under L^T (on the output channels) */
 int dsw_trace_begin(int capacity);
 int dsw_trace_end(int32_t* call, int32_t* roles, int32_t* aux0, int32_t* aux1, int32_t* aux2, float* us, char* names,
@@ -243,12 +244,15 @@ int dsw_cheb_dx_one_launch(const dsw_hop2_plan* plan_t, int64_t V, const void* d
  *   DSW_FWD_FUSED_PAIRS  hops pairwise in the two-hop kernel (plan->hops == 2), then the GEMM
  *   DSW_FWD_STAGED_HOPS  one staged launch per hop (plan->hops == 1: dense stencils), then the GEMM
  *   DSW_FWD_ONE_LAUNCH   both hops AND the channel mix in one launch (fp32, K = 3, Fin = 32, Fout 32 / 64, two-hop plan)
- *   DSW_FWD_MIX_FIRST    channel mix first, recurrence on the Fout channels (dsw_cheb_mix_first) */
+ *   DSW_FWD_MIX_FIRST    channel mix first, recurrence on the Fout channels (dsw_cheb_mix_first)
+ *   DSW_FWD_HOP1_THEN_ONE_LAUNCH  staged hop 1, then hop 2 AND the channel mix in one launch (fp32, K = 3, Fin = 32, Fout 32 / 64,
+ *                        one-hop plan: the reference's default k = 20 graph, equiangular; needs the basis buffer T) */
 #define DSW_FWD_PLAIN_HOPS 0
 #define DSW_FWD_FUSED_PAIRS 1
 #define DSW_FWD_STAGED_HOPS 2
 #define DSW_FWD_ONE_LAUNCH 3
 #define DSW_FWD_MIX_FIRST 4
+#define DSW_FWD_HOP1_THEN_ONE_LAUNCH 5
 int dsw_cheb_fwd_path(const dsw_hop2_plan* plan, int64_t Fin, int64_t Fout, int64_t K, int dtype);
 
 /* Whole ConvCheb.forward (layers.py:365-376) = dsw_cheb_basis_fwd + dsw_cheb_mix_fwd.

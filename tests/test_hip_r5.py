@@ -304,3 +304,47 @@ def test_north_star_shape_one_launch_paths_full_size():
     dx = _dx_one_launch(layer, gy)
     assert dx is not None
     assert orc.max_rel_err(dx, x.grad.cpu().numpy()) <= 2e-6
+
+
+@pytest.mark.parametrize("sampling,Fout,B,relu", [("healpix16", 64, 5, False), ("healpix16", 32, 2, True), ("healpix8", 64, 1, False),
+                                                   ("equiangular", 32, 3, False), ("equiangular", 64, 4, True)])
+def test_forward_hop1_then_one_launch_vs_oracle(sampling, Fout, B, relu, monkeypatch):
+    """Dense stencils (k = 20 HEALPix, equiangular: one-hop plans), K = 3, 32 input channels, fp32: the forward runs as the staged
+    hop 1 + ONE launch for hop 2 and the channel mix (dsw_fwd3.hip: cheb3_hop2mix_kernel) - output, the kept basis (through the
+    backward's weight gradients) and all gradients against the fp64 oracle; ragged last tiles, clustered tiles, fused ReLU."""
+    from dsw_amd import _native, functional as F_, sphere
+    from modules.layers import ConvCheb, prepare_torch_laplacian
+    from oracle import cheb_oracle as orc
+
+    monkeypatch.setattr(F_, "MIN_CLUSTERED_TILES", 1)
+    if sampling == "equiangular":
+        g = sphere.SphereEquiangular(nlat=30, nlon=60, k=20)
+    else:
+        g = sphere.SphereHealpix(int(sampling[7:]), nest=True, k=20)
+    lap = prepare_torch_laplacian(g.L, lmax=1.9)
+    torch.manual_seed(B + Fout)
+    layer = ConvCheb(32, Fout, 3, laplacian=lap).to(DEV)
+    with torch.no_grad():
+        layer.bias.normal_(0, 0.1)
+    V = g.L.shape[0]
+    x = torch.randn(B, V, 32, device=DEV, requires_grad=True)
+    gy = torch.randn(B, V, Fout, device=DEV)
+    op = F_.get_operator(layer.laplacian)
+    pp, _keep = F_._plan_ptr(op, x)
+    assert pp is not None and int(_native.load().dsw_cheb_fwd_path(pp, 32, Fout, 3, 0)) == 5      # DSW_FWD_HOP1_THEN_ONE_LAUNCH
+    y = layer.forward_activated(x, "relu") if relu else layer(x)
+    y.backward(gy)
+    rp, ci, va = orc.csr_arrays_from_coo(layer.laplacian.cpu())
+    xn, wn, bn = (t.detach().cpu().numpy() for t in (x, layer.weight, layer.bias))
+    y64 = orc.cheb_forward_f64(rp, ci, va, xn, wn, bn)
+    import numpy as np
+
+    g64 = gy.cpu().double().numpy()
+    if relu:
+        g64 = g64 * (y64 > 0)
+        y64 = np.maximum(y64, 0)
+    dx64, dw64, db64 = orc.cheb_backward_f64(rp, ci, va, xn, wn, g64, True)
+    assert orc.max_rel_err(y, y64) <= 2e-6
+    assert orc.max_rel_err(x.grad, dx64) <= 2e-6
+    assert orc.max_rel_err(layer.weight.grad, dw64) <= 4e-6
+    assert orc.max_rel_err(layer.bias.grad, db64) <= 4e-6
