@@ -10,7 +10,7 @@ for pass in "A FETCH_SIZE" "B WRITE_SIZE" "C SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU
   if [ -n "$PMC_PASSES" ] && ! echo " $PMC_PASSES " | grep -q " $p "; then continue; fi
   out=$root/gpurun_out/pmc_${tag}_$p
   mkdir -p $out
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $@ --output-format csv -d $out -o pmc -- python $root/bench.py ${BENCH_ARGS:---steps 10 --warmup 3 --no-cpu-baseline} > $out/run.log 2>&1
+  timeout -k 10 ${PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc $@ --output-format csv -d $out -o pmc -- python $root/bench.py ${BENCH_ARGS:---steps 10 --warmup 3 --no-cpu-baseline} > $out/run.log 2>&1
   echo "pass $p ($@): rc=$?"
 done
 cd $root
