@@ -244,7 +244,7 @@ def trace_steps(step_fn, n_steps, warm=5, capacity=1 << 15):
     return out, seq0
 
 
-def graph_kernel_durations(seq, n_steps=40, timeout=420):
+def graph_kernel_durations(seq, n_steps=40, timeout=150):
     """Durations of the step's kernels INSIDE the replayed HIP graph: this script is run once more as a child under
     `rocprofv3 --kernel-trace` (same arguments + --kernel-trace-child N: build, capture, warm up, replay N steps, exit), the
     trace is sorted by start time, and the library kernels of its last N steps - identified by the launch order `seq` the

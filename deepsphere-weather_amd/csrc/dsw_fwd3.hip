@@ -297,12 +297,13 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
             }
         }
         __syncthreads();   // C: nobody reads bufX / bufT of this sample any more; split images complete
-        // next sample's rows -> the (single) input buffer
+#ifdef DSW_STAGE_EARLY   // A/B builds: next sample's rows -> the (single) input buffer in front of the matrix phase
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             const int i = grp + k * RPP;
             if (i < n2) *reinterpret_cast<u32x4*>(bufX + (size_t)i * RB + cb) = su[k];
         }
+#endif
         // ---- phase 3: Y[tile rows, 16 cbk ..+16] = [X | T1 | T2] W + bias on the matrix cores, from the split images
         f32x4_t acc[RBW];
         unsigned fro[RBW];
@@ -349,6 +350,15 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
                 st16(P.Y + (size_t)b * ((size_t)P.V * P.Fout * 4) +
                          (unsigned)(rows[FULL ? row : min(row, rt - 1)] * P.Fout * 4 + (16 * cbk + 4 * kc) * 4), acc[r]);
         }
+#ifndef DSW_STAGE_EARLY
+        // next sample's rows -> the (single) input buffer, BEHIND the matrix phase (bufX is free since barrier C, the next
+        // barrier A publishes it): the loads get the whole sample to land
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int i = grp + k * RPP;
+            if (i < n2) *reinterpret_cast<u32x4*>(bufX + (size_t)i * RB + cb) = su[k];
+        }
+#endif
     }
 }
 
@@ -470,11 +480,13 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_hop2mix_kernel(const Fwd3Ar
             split_store(simg, 0, grp, c4, xf);
         }
         __syncthreads();   // C: nobody reads bufT of this sample any more; split images complete
+#ifdef DSW_STAGE_EARLY
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             const int i = grp + k * RPP;
             if (i < n2) *reinterpret_cast<u32x4*>(bufT + (size_t)i * RB + cb) = su[k];
         }
+#endif
         xr = xn;
         // ---- Y[tile rows, 16 cbk ..+16] = [X | T1 | T2] W + bias on the matrix cores (as cheb3_fwd_fused_kernel)
         f32x4_t acc[RBW];
@@ -519,6 +531,15 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_hop2mix_kernel(const Fwd3Ar
                 st16(P.Y + (size_t)b * ((size_t)P.V * P.Fout * 4) +
                          (unsigned)(rows[FULL ? row : min(row, rt - 1)] * P.Fout * 4 + (16 * cbk + 4 * kc) * 4), acc[r]);
         }
+#ifndef DSW_STAGE_EARLY
+        // next sample's T1 rows -> the (single) staging buffer: AFTER the matrix phase, so that the loads had the gather AND the
+        // matrix phase to land (bufT is free since barrier C; the next barrier A publishes it)
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int i = grp + k * RPP;
+            if (i < n2) *reinterpret_cast<u32x4*>(bufT + (size_t)i * RB + cb) = su[k];
+        }
+#endif
     }
 }
 
