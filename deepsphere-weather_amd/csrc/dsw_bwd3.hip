@@ -139,6 +139,28 @@ static __device__ __forceinline__ f32x4_t mfma6(const bf16x8_t (&a)[3], const bf
     return acc;
 }
 
+// the same six terms for TWO products that share the B operand (the two dX channel blocks of a row block), interleaved: two
+// independent accumulation chains keep the matrix pipe issuing while a result is still in flight
+static __device__ __forceinline__ void mfma6x2(const bf16x8_t (&a0)[3], const bf16x8_t (&a1)[3], const bf16x8_t (&b)[3],
+                                               f32x4_t& c0, f32x4_t& c1) {
+#ifdef DSW_ABL_B3_NOMFMA
+    c0[0] += __builtin_bit_cast(f32x4_t, a0[0])[0] + __builtin_bit_cast(f32x4_t, b[0])[0];
+    c1[0] += __builtin_bit_cast(f32x4_t, a1[0])[0]; return;
+#endif
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[2], b[0], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[2], b[0], c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[0], b[2], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[0], b[2], c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[1], b[1], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[1], b[1], c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[1], b[0], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[1], b[0], c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[0], b[1], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[0], b[1], c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[0], b[0], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[0], b[0], c1, 0, 0, 0);
+}
+
 // W [32][3][64] -> fragment image [plane 0' = W_0 - W_2, W_1, W_2][fb][ks][term][lane]: lane l of the wave that owns dX channel
 // block fb gets, for k-step ks, the 8 dY channels o = 32 ks + 8 (l >> 4) .. + 7 of dX channel f = 16 fb + (l & 15), split
 // into its three bf16 terms.  (The subtraction of the raw plane K-1 at the top of the adjoint recurrence is folded into the
@@ -360,6 +382,204 @@ __global__ __launch_bounds__(NTH, 4) void cheb3_bwd_fused_kernel(const Bwd3Args 
     if (t < total) step(ring0, t);
 }
 
+// ---- third build: ONE workgroup of 16 waves per CU, the weights in LDS, NO image of dY ----------------------------------------
+// A wave owns one row block (16 list rows) of the tile's two-ring for the whole batch: it loads the dY rows of its block
+// straight into the B-fragment layout of the MFMA (lane (n, kg): 8 consecutive dY channels of row n - two 16-byte loads per
+// k-step), splits them in registers and multiplies them with the W fragments of the planes its rows need (plane 2 on the
+// two-ring, plane 1 on the one-ring, plane 0' on the tile), read from a split image of the weights in LDS, both dX channel
+// blocks interleaved (two independent accumulation chains).  No staging of dY through LDS, no chunk steps: three barriers per
+// sample (G complete / hop 1 done / hop 2 done), as in the forward kernel.
+constexpr int NTH3 = 1024;
+constexpr int W3_PLANE = 3 * 32 * 128;       // [term][32 f][64 o bf16], 16-byte chunks swizzled by the row (img_off)
+constexpr int W3_BYTES = 3 * W3_PLANE;       // 36 KB
+
+struct Bwd3vArgs {
+    const int* tile_meta;
+    const int* s2_rows;
+    const int* lrowptr;
+    const unsigned short* lcol;
+    const float* lval;
+    const char* dY;
+    char* dX;
+    const float* W;      // [32][3][64]
+    int V, n_tiles, max_n1, max_n2;
+    int B, n_chunks, spc, ell_w;
+    int explicit_tiles;
+};
+
+static __device__ __forceinline__ void split8(const u32x4 lo, const u32x4 hi, bf16x8_t (&t)[3]) {
+    const float f[8] = {__uint_as_float(lo[0]), __uint_as_float(lo[1]), __uint_as_float(lo[2]), __uint_as_float(lo[3]),
+                        __uint_as_float(hi[0]), __uint_as_float(hi[1]), __uint_as_float(hi[2]), __uint_as_float(hi[3])};
+    float r1[8], r2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        r1[j] = f[j] - trunc_bf16(f[j]);
+        r2[j] = r1[j] - trunc_bf16(r1[j]);
+    }
+    const uint4 uh = {pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7])};
+    const uint4 um = {pack2(r1[0], r1[1]), pack2(r1[2], r1[3]), pack2(r1[4], r1[5]), pack2(r1[6], r1[7])};
+    const uint4 ul = {pack2(r2[0], r2[1]), pack2(r2[2], r2[3]), pack2(r2[4], r2[5]), pack2(r2[6], r2[7])};
+    t[0] = __builtin_bit_cast(bf16x8_t, uh); t[1] = __builtin_bit_cast(bf16x8_t, um); t[2] = __builtin_bit_cast(bf16x8_t, ul);
+}
+
+__global__ __launch_bounds__(NTH3, 4) void cheb3_bwd_rowblock_kernel(const Bwd3vArgs P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* wimg = lds;                                              // [3 planes][3 terms][32 f][128 B]
+    unsigned char* g2 = wimg + W3_BYTES;                                    // [max_n2][GS] G_2 on the 2-ring
+    unsigned char* g1 = g2 + (size_t)P.max_n2 * GS;                         // [max_n1][GS] G_1, then H_1, on the 1-ring
+    unsigned char* g0 = g1 + (size_t)P.max_n1 * GS;                         // [64][GS]     G_0' on the tile
+    float* ell_val = reinterpret_cast<float*>(g0 + 64 * GS);                // [max_n1][W]
+    unsigned char* ell_idx = reinterpret_cast<unsigned char*>(ell_val + (size_t)P.max_n1 * P.ell_w);   // [max_n1][W] u8
+    int* rows = reinterpret_cast<int*>(ell_idx + (((size_t)P.max_n1 * P.ell_w + 3) & ~(size_t)3));   // [max_n2] global row ids
+    int* tile_w = rows + ((P.max_n2 + 3) & ~3);
+
+    const long nwg = gridDim.x, orig = blockIdx.x;                          // XCD-aware order (see dsw_spmm2.hip)
+    const long q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const long wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int tile = (int)(wg / P.n_chunks);
+    const int chunk = (int)(wg - (long)tile * P.n_chunks);
+    const int b_begin = chunk * P.spc;
+    const int b_end = min(P.B, b_begin + P.spc);
+    const int* meta = P.tile_meta + (size_t)tile * 6;
+    const int s2_off = meta[0], n1 = meta[1], n2 = meta[2], nnz_off = meta[3], rp_off = meta[4];
+    const int rt = P.explicit_tiles ? meta[5] : min(64, P.V - tile * 64);   // tile rows = the first rt list entries
+    const int tid = threadIdx.x;
+    const int W = P.ell_w;
+    const size_t y_sample = (size_t)P.V * YB, x_sample = (size_t)P.V * XB;
+
+    int* lrp = reinterpret_cast<int*>(g1);           // local row pointers, parked in g1 until the ELL is built
+    if (tid == 0) *tile_w = 2;
+    for (int i = tid; i < n2; i += NTH3) rows[i] = P.s2_rows[s2_off + i];
+    for (int i = tid; i <= n1; i += NTH3) lrp[i] = P.lrowptr[rp_off + i];
+    __syncthreads();
+
+    // matrix role: wave w owns row block w (list rows 16 w .. 16 w + 15); lane (n = l & 15, kg = l >> 4)
+    const int wave = tid >> 6, lane = tid & 63;
+    const unsigned l15 = (unsigned)(lane & 15), kc = (unsigned)(lane >> 4);
+    const int p0 = 16 * wave;
+    const bool has2 = p0 < n2, has1 = p0 < n1, has0 = p0 < rt;            // uniform per wave
+    const unsigned yoff = (unsigned)rows[min(p0 + (int)l15, n2 - 1)] * (unsigned)YB + kc * 32u;   // + 128 for the second k-step
+    u32x4 py[4];
+    if (has2 && b_begin < b_end) {
+        const char* src = P.dY + (size_t)b_begin * y_sample + yoff;
+        py[0] = *reinterpret_cast<const u32x4*>(src); py[1] = *reinterpret_cast<const u32x4*>(src + 16);
+        py[2] = *reinterpret_cast<const u32x4*>(src + 128); py[3] = *reinterpret_cast<const u32x4*>(src + 144);
+    }
+    // CSR -> ELL of the tile + 1-ring rows (as dsw_fwd3.hip)
+    const int tile_nnz = lrp[n1];
+    for (int t = tid; t < n1 * W; t += NTH3) {
+        const int i = t / W, j = t - i * W;
+        const int q0 = lrp[i], q1 = lrp[i + 1];
+        unsigned col = 0;
+        float val = 0.f;
+        if (tile_nnz > 0) {
+            const int p = max(0, min(q0 + j, tile_nnz - 1));
+            col = P.lcol[nnz_off + p];
+            val = P.lval[nnz_off + p];
+        }
+        if (j == 0 && q1 - q0 > 2) atomicMax(tile_w, q1 - q0);
+        const bool live = q0 + j < q1;
+        ell_idx[t] = (unsigned char)(live ? col : (unsigned)i);
+        ell_val[t] = live ? val : 0.f;
+    }
+    // split image of the weights: plane 0 = W_0 - W_2 (the subtraction of the raw plane K-1 at the top of the adjoint
+    // recurrence, folded into the weights), planes 1, 2 = W_1, W_2; image row = dX channel f, columns = dY channels o
+    for (int e = tid; e < 3 * 32 * 16; e += NTH3) {
+        const int p = e / (32 * 16), f = (e / 16) & 31;
+        const unsigned q = (unsigned)(e & 15);
+        const float4 w = *reinterpret_cast<const float4*>(P.W + ((size_t)f * 3 + p) * 64 + 4 * q);
+        float v[4] = {w.x, w.y, w.z, w.w};
+        if (p == 0) {
+            const float4 w2 = *reinterpret_cast<const float4*>(P.W + ((size_t)f * 3 + 2) * 64 + 4 * q);
+            v[0] -= w2.x; v[1] -= w2.y; v[2] -= w2.z; v[3] -= w2.w;
+        }
+        split_store4(wimg + (size_t)p * W3_PLANE, 32 * 128, (unsigned)f, q, v);
+    }
+    __syncthreads();   // ELL and weight image complete (lrp in g1 dead)
+    const int Wt = *tile_w;
+
+    // A-fragment offsets in a plane of the weight image: dX channel blocks fb = 0 / 1, k-steps 0 / 1
+    const unsigned a00 = img_off(l15, kc), a01 = img_off(l15, 4u + kc), a10 = img_off(16u + l15, kc), a11 = img_off(16u + l15, 4u + kc);
+    const unsigned grow_ = (unsigned)(p0 + (int)l15);
+    const unsigned gcol = 4u * kc * 4u;                  // 16 bytes of a G row: dX channels 16 fb + 4 kc .. + 3
+
+    // gather role (hops): list position grp, 16-byte chunk of the 128-byte row
+    const int grp = tid >> 3;
+    const unsigned gcb = (unsigned)(tid & 7) * 16u;
+
+    for (int b = b_begin; b < b_end; ++b) {
+        if (has2) {
+            bf16x8_t b0[3], b1[3];
+            split8(py[0], py[1], b0);
+            split8(py[2], py[3], b1);
+            {   // next sample's rows of this block: in flight under the matrix work and the hops
+                const char* src = P.dY + (size_t)(b + 1 < b_end ? b + 1 : b) * y_sample + yoff;
+                py[0] = *reinterpret_cast<const u32x4*>(src); py[1] = *reinterpret_cast<const u32x4*>(src + 16);
+                py[2] = *reinterpret_cast<const u32x4*>(src + 128); py[3] = *reinterpret_cast<const u32x4*>(src + 144);
+            }
+#pragma unroll
+            for (int pi = 0; pi < 3; ++pi) {             // plane 2 (two-ring), plane 1 (one-ring), plane 0' (tile)
+                const int plane = 2 - pi;
+                const bool need = plane == 2 ? true : plane == 1 ? has1 : has0;
+                if (need) {
+                    const unsigned char* wp = wimg + (size_t)plane * W3_PLANE;
+                    f32x4_t c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+                    {
+                        bf16x8_t a0[3], a1[3];
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) {
+                            a0[t] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * (32 * 128) + a00);
+                            a1[t] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * (32 * 128) + a10);
+                        }
+                        mfma6x2(a0, a1, b0, c0, c1);
+                    }
+                    {
+                        bf16x8_t a0[3], a1[3];
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) {
+                            a0[t] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * (32 * 128) + a01);
+                            a1[t] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * (32 * 128) + a11);
+                        }
+                        mfma6x2(a0, a1, b1, c0, c1);
+                    }
+                    unsigned char* gd = (plane == 2 ? g2 : plane == 1 ? g1 : g0) + grow_ * GS + gcol;
+                    if ((int)grow_ < (plane == 2 ? n2 : plane == 1 ? n1 : 64)) {
+                        *reinterpret_cast<f32x4_t*>(gd) = c0;
+                        *reinterpret_cast<f32x4_t*>(gd + 64) = c1;
+                    }
+                }
+            }
+        }
+        __syncthreads();   // G_2, G_1, G_0' complete
+        // ---- hop 1: H_1 = G_1 + 2 L^T G_2 on the tile + 1-ring rows, in place
+        if (grp < n1) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            gather_ell<GS>(ell_idx + (size_t)grp * W, ell_val + (size_t)grp * W, Wt, g2 + gcb, acc);
+            float4* hp = reinterpret_cast<float4*>(g1 + (size_t)grp * GS + gcb);
+            const float4 g = *hp;
+            *hp = make_float4(fmaf(2.f, acc[0], g.x), fmaf(2.f, acc[1], g.y), fmaf(2.f, acc[2], g.z), fmaf(2.f, acc[3], g.w));
+        }
+        __syncthreads();
+        // ---- hop 2: dX = G_0' + L^T H_1 on the tile rows -> HBM
+        if (grp < rt) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            gather_ell<GS>(ell_idx + (size_t)grp * W, ell_val + (size_t)grp * W, Wt, g1 + gcb, acc);
+            const float4 g = *reinterpret_cast<const float4*>(g0 + (size_t)grp * GS + gcb);
+            const float4 o = make_float4(g.x + acc[0], g.y + acc[1], g.z + acc[2], g.w + acc[3]);
+            st16_nt(P.dX + (size_t)b * x_sample + (size_t)rows[grp] * XB + gcb, o);
+        }
+        __syncthreads();   // the next sample's matrix phase overwrites the G buffers
+    }
+}
+
+size_t bwd3v_lds_bytes(const dsw_hop2_plan* plan) {
+    const int ell_w = (plan->reserved + 3) & ~3;
+    size_t s = (size_t)W3_BYTES + ((size_t)plan->max_n2 + plan->max_n1 + 64) * GS;
+    s += (size_t)plan->max_n1 * ell_w * 4 + (((size_t)plan->max_n1 * ell_w + 3) & ~(size_t)3);   // fp32 values + u8 positions
+    s += (size_t)((plan->max_n2 + 3) & ~3) * 4 + 16;
+    return (s + 15) & ~(size_t)15;
+}
+
 size_t bwd3_lds_bytes(const dsw_hop2_plan* plan) {
     const int ell_w = (plan->reserved + 3) & ~3;
     size_t s = (size_t)IMG_BYTES + (size_t)plan->max_n2 * GS + ((size_t)plan->max_n1 + 64) * GS1;
@@ -384,8 +604,12 @@ int dsw_cheb3_bwd_fused_eligible(const dsw_hop2_plan* plan_t, int64_t Fin, int64
     if (env && env[0] == '0') return 0;
     if (dtype != DSW_F32 || K != 3 || Fin != 32 || Fout != 64) return 0;
     if (!plan_t || plan_t->hops == 1 || plan_t->tile_rows != 64 || !dsw_spmm2_supported(plan_t, Fin, dtype)) return 0;
-    if (plan_t->max_n2 > 255 || plan_t->max_n1 > 128) return 0;     // u8 list positions; hop 1 in two passes of the 512 threads
-    if (bwd3_lds_bytes(plan_t) > 80 * 1024) return 0;               // two workgroups per CU or not at all
+    if (plan_t->max_n2 > 255 || plan_t->max_n1 > 128) return 0;     // u8 list positions, 16 row blocks for 16 waves; hop 1 in one pass
+#ifdef DSW_BWD3_V2
+    if (bwd3_lds_bytes(plan_t) > 80 * 1024) return 0;               // (second build: two workgroups per CU or not at all)
+#else
+    if (bwd3v_lds_bytes(plan_t) > 160 * 1024) return 0;
+#endif
     return 1;
 }
 
@@ -396,24 +620,36 @@ int dsw_cheb3_bwd_fused_try(const dsw_hop2_plan* plan_t, int64_t V, const void* 
                             int64_t ws_bytes) {
     if (!dsw_cheb3_bwd_fused_eligible(plan_t, Fin, Fout, K, dtype)) return 0;
     if (!dsw_aligned16(dY) || !dsw_aligned16(dX) || !dsw_aligned16(W)) return 0;
+#ifdef DSW_BWD3_V2
     if (ws == nullptr || !dsw_aligned16(ws) || ws_bytes < WFRAG_BYTES) return 0;      // scratch for the split W fragments
+#else
+    (void)ws; (void)ws_bytes;
+#endif
     if ((unsigned long long)V * YB >= (1ull << 32)) return 0;           // 32-bit row offsets inside a sample
     if (V <= 0 || B <= 0) { *rc = DSW_OK; return 1; }
+#ifdef DSW_BWD3_V2
     Bwd3Args A;
+    A.wfrag = static_cast<const unsigned char*>(ws);
+    const long per_cu = 2;
+#else
+    Bwd3vArgs A;
+    A.W = static_cast<const float*>(W);
+    const long per_cu = 1;
+#endif
     A.tile_meta = plan_t->tile_meta; A.s2_rows = plan_t->s2_rows; A.lrowptr = plan_t->lrowptr;
     A.lcol = plan_t->lcol; A.lval = plan_t->lval;
-    A.dY = static_cast<const char*>(dY); A.dX = static_cast<char*>(dX); A.wfrag = static_cast<const unsigned char*>(ws);
+    A.dY = static_cast<const char*>(dY); A.dX = static_cast<char*>(dX);
     A.V = (int)V; A.n_tiles = plan_t->n_tiles; A.max_n1 = plan_t->max_n1; A.max_n2 = plan_t->max_n2;
     A.B = (int)B; A.ell_w = (plan_t->reserved + 3) & ~3; A.explicit_tiles = plan_t->explicit_tiles;
-    // batch chunks: two workgroups per CU; rounds x (plan staging, about 1.5 samples' worth, + samples per chunk)
-    const long slots = 2 * dsw_device_cus();
+    // batch chunks: rounds over the resident slots x (plan + weight staging, about 2 samples' worth, + samples per chunk)
+    const long slots = per_cu * dsw_device_cus();
     long chunks = 1;
     {
         double best = -1.0;
         const long cmax = B > 1 ? (B + 1) / 2 : 1;
         for (long c = 1; c <= cmax && c <= 16; ++c) {
             const long rounds = (plan_t->n_tiles * c + slots - 1) / slots;
-            const double cost = (double)rounds * (1.5 + (double)((B + c - 1) / c));
+            const double cost = (double)rounds * (2.0 + (double)((B + c - 1) / c));
             if (best < 0 || cost < best - 1e-9) { best = cost; chunks = c; }
         }
     }
@@ -421,9 +657,19 @@ int dsw_cheb3_bwd_fused_try(const dsw_hop2_plan* plan_t, int64_t V, const void* 
     A.n_chunks = (int)((B + A.spc - 1) / A.spc);
     const long nwg = (long)plan_t->n_tiles * A.n_chunks;
     if (nwg > 2147483647L) return 0;
+#ifdef DSW_BWD3_V2
     const size_t lds = bwd3_lds_bytes(plan_t);
     DSW_LAUNCH(bwd3_wprep_kernel, dim3(3), dim3(256), 0, stream, static_cast<const float*>(W), static_cast<unsigned char*>(ws));
     if ((*rc = dsw_check_launch()) != DSW_OK) return 1;
     *rc = launch_bwd3(A, nwg, lds, stream);
+#else
+    const size_t lds = bwd3v_lds_bytes(plan_t);
+    if (hipFuncSetAttribute((const void*)cheb3_bwd_rowblock_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        *rc = DSW_ERR_LAUNCH;
+        return 1;
+    }
+    DSW_LAUNCH(cheb3_bwd_rowblock_kernel, dim3((unsigned)nwg), dim3(NTH3), lds, stream, A);
+    *rc = dsw_check_launch();
+#endif
     return 1;
 }
