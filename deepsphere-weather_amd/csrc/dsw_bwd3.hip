@@ -18,16 +18,18 @@
 // image of W (3 planes x 3 terms x 32 rows: 36 KB) is built once per workgroup; every dY row is split once, by the
 // thread that loaded it.
 //
-// 512 threads, two workgroups per CU (79 KB of LDS at nside 64, <= 128 registers): the phases of a sample use one unit each
-// (vector ALU for the split, matrix cores, the LDS pipe for the hops) and only a second, independent workgroup overlaps
-// them - a first version with ONE 1024-thread workgroup per CU (W image in LDS, 141 KB) ran its 16 waves in lockstep
-// through five barriers per sample: 216 us against the 157 us of the launches it replaces.  What fits two workgroups:
-//   * the chunk image is single-buffered (two barriers per chunk step);
-//   * the W fragments live in REGISTERS: waves 0-3 hold plane 2 (needed on every row block), waves 4-7 plane 1 (1-ring) - 24
-//     registers - and fetch plane 0' (tile rows: one chunk step per sample) when they need it; the MFMA work of the two groups
-//     is balanced (60 / 66 per wave and sample); the fragments come ready-made from a 36 KB image in the caller's workspace
-//     (bwd3_wprep_kernel: split once per call);
-//   * dY rows are prefetched two chunk steps ahead through a ring of two register slots.
+// One workgroup of 16 waves per CU (147 KB of LDS at nside 64), SPECIALISED: waves 0-7 are the matrix waves, waves 8-15 the
+// hop waves, and they work on DIFFERENT samples - while the hop waves run the two L^T hops of sample b out of one set of G
+// buffers, the matrix waves fill the other set for sample b + 1.  A matrix wave owns two row blocks (16 list rows each) of the
+// tile's two-ring for the whole batch: it loads the dY rows of a block straight into the B-fragment layout of the MFMA (lane
+// (n, kg): 8 consecutive dY channels of row n), splits them in registers and multiplies them with the W fragments of the planes
+// the rows need, read from a split image of the weights in LDS, both dX channel blocks interleaved (two accumulation chains).
+// Two workgroup barriers per sample (between the hops / at the end), which the matrix waves pass between their two row blocks.
+//
+// How it got here: one 1024-thread workgroup staging dY through an LDS image in 64-row chunks, all waves in
+// lockstep through five barriers per sample: 216 us; two 512-thread workgroups per CU with the W fragments in registers: 203 us
+// (seven barriers, phases that do not overlap: the ablation's parts add up); no dY image, a row block per wave, three barriers:
+// 168 us; the specialised form: see DESIGN.md.  The launches it replaces cost 157 us.
 #include <cstdlib>
 #include "dsw_common.h"
 #include "../../include/dsw_hip.h"
@@ -41,32 +43,12 @@ static __device__ __forceinline__ void st16_nt(char* p, const T4& v) {
     __builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, v), reinterpret_cast<u32x4_nt*>(p));
 }
 
-constexpr int NTH = 512;
 constexpr int XB = 128;          // bytes of a dX / G row in HBM (32 fp32 channels)
 constexpr int YB = 256;          // bytes of a dY row (64 fp32 channels)
-constexpr int GS = 144;          // LDS stride of a G_2 row: 128 + 16 (the 16 rows of an accumulator store hit distinct banks)
-constexpr int GS1 = 128;         // ... of a G_1 / G_0' row: dense (the fattest nside-64 tile - 175 / 115 rows - must fit 80 KB;
-                                 // their accumulator stores take the 4-way conflict: 22 wave stores per sample)
-constexpr int IMG_TERM = 64 * 128;           // one term of a 64-row chunk image
-constexpr int IMG_BYTES = 3 * IMG_TERM;      // 24 KB
-constexpr int WFRAG_BYTES = 3 * 2 * 2 * 3 * 64 * 16;   // [plane][fb][ks][term][lane] x 16 B: the W fragments, 36 KB (workspace)
+constexpr int GS = 144;          // LDS stride of a G row: 128 + 16 (the 16 rows of an accumulator store hit distinct banks)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-
-struct Bwd3Args {
-    const int* tile_meta;
-    const int* s2_rows;
-    const int* lrowptr;
-    const unsigned short* lcol;
-    const float* lval;
-    const char* dY;
-    char* dX;
-    const unsigned char* wfrag;   // pre-split W fragments (bwd3_wprep_kernel)
-    int V, n_tiles, max_n1, max_n2;
-    int B, n_chunks, spc, ell_w;
-    int explicit_tiles;
-};
 
 static __device__ __forceinline__ float trunc_bf16(float f) { return __uint_as_float(__float_as_uint(f) & 0xffff0000u); }
 static __device__ __forceinline__ unsigned pack2(float lo, float hi) {
@@ -125,21 +107,7 @@ static __device__ __forceinline__ void gather_ell(const unsigned char* __restric
     }
 }
 
-// six leading terms of the split product, smallest first: acc += A (3 terms) x B (3 terms)
-static __device__ __forceinline__ f32x4_t mfma6(const bf16x8_t (&a)[3], const bf16x8_t (&b)[3], f32x4_t acc) {
-#ifdef DSW_ABL_B3_NOMFMA
-    acc[0] += __builtin_bit_cast(f32x4_t, a[0])[0] + __builtin_bit_cast(f32x4_t, b[0])[0]; return acc;
-#endif
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
-    return acc;
-}
-
-// the same six terms for TWO products that share the B operand (the two dX channel blocks of a row block), interleaved: two
+// six leading terms of the split product (smallest first), for TWO products that share the B operand (the two dX channel blocks of a row block), interleaved: two
 // independent accumulation chains keep the matrix pipe issuing while a result is still in flight
 static __device__ __forceinline__ void mfma6x2(const bf16x8_t (&a0)[3], const bf16x8_t (&a1)[3], const bf16x8_t (&b)[3],
                                                f32x4_t& c0, f32x4_t& c1) {
@@ -161,239 +129,11 @@ static __device__ __forceinline__ void mfma6x2(const bf16x8_t (&a0)[3], const bf
     c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[0], b[0], c1, 0, 0, 0);
 }
 
-// W [32][3][64] -> fragment image [plane 0' = W_0 - W_2, W_1, W_2][fb][ks][term][lane]: lane l of the wave that owns dX channel
-// block fb gets, for k-step ks, the 8 dY channels o = 32 ks + 8 (l >> 4) .. + 7 of dX channel f = 16 fb + (l & 15), split
-// into its three bf16 terms.  (The subtraction of the raw plane K-1 at the top of the adjoint recurrence is folded into the
-// weights of plane 0.)
-__global__ __launch_bounds__(256) void bwd3_wprep_kernel(const float* __restrict__ W, unsigned char* __restrict__ out) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= 3 * 2 * 2 * 64) return;
-    const int lane = e & 63, ks = (e >> 6) & 1, fb = (e >> 7) & 1, plane = e >> 8;
-    const int f = 16 * fb + (lane & 15), o0 = 32 * ks + 8 * (lane >> 4);
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        v[j] = W[((size_t)f * 3 + plane) * 64 + o0 + j];
-        if (plane == 0) v[j] -= W[((size_t)f * 3 + 2) * 64 + o0 + j];
-    }
-    float r1[8], r2[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        r1[j] = v[j] - trunc_bf16(v[j]);
-        r2[j] = r1[j] - trunc_bf16(r1[j]);
-    }
-    uint4* dst = reinterpret_cast<uint4*>(out + ((size_t)((plane * 2 + fb) * 2 + ks) * 3) * 1024 + (size_t)lane * 16);
-    dst[0] = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
-    dst[64] = make_uint4(pack2(r1[0], r1[1]), pack2(r1[2], r1[3]), pack2(r1[4], r1[5]), pack2(r1[6], r1[7]));
-    dst[128] = make_uint4(pack2(r2[0], r2[1]), pack2(r2[2], r2[3]), pack2(r2[4], r2[5]), pack2(r2[6], r2[7]));
-}
-
-__global__ __launch_bounds__(NTH, 4) void cheb3_bwd_fused_kernel(const Bwd3Args P) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned char* img = lds;                                               // [3 terms][64 rows][128 B]
-    unsigned char* g2 = img + IMG_BYTES;                                    // [max_n2][GS] G_2 on the 2-ring
-    unsigned char* g1 = g2 + (size_t)P.max_n2 * GS;                         // [max_n1][GS] G_1, then H_1, on the 1-ring
-    unsigned char* g0 = g1 + (size_t)P.max_n1 * GS1;                        // [64][GS1]    G_0' on the tile
-    float* ell_val = reinterpret_cast<float*>(g0 + 64 * GS1);               // [max_n1][W]
-    unsigned char* ell_idx = reinterpret_cast<unsigned char*>(ell_val + (size_t)P.max_n1 * P.ell_w);   // [max_n1][W] u8
-    int* rows = reinterpret_cast<int*>(ell_idx + (((size_t)P.max_n1 * P.ell_w + 3) & ~(size_t)3));   // [max_n2] global row ids
-    int* tile_w = rows + ((P.max_n2 + 3) & ~3);
-
-    const long nwg = gridDim.x, orig = blockIdx.x;                          // XCD-aware order (see dsw_spmm2.hip)
-    const long q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
-    const long wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int tile = (int)(wg / P.n_chunks);
-    const int chunk = (int)(wg - (long)tile * P.n_chunks);
-    const int b_begin = chunk * P.spc;
-    const int b_end = min(P.B, b_begin + P.spc);
-    const int* meta = P.tile_meta + (size_t)tile * 6;
-    const int s2_off = meta[0], n1 = meta[1], n2 = meta[2], nnz_off = meta[3], rp_off = meta[4];
-    const int rt = P.explicit_tiles ? meta[5] : min(64, P.V - tile * 64);   // tile rows = the first rt list entries
-    const int tid = threadIdx.x;
-    const int W = P.ell_w;
-    const size_t y_sample = (size_t)P.V * YB, x_sample = (size_t)P.V * XB;
-    const int nch = (n2 + 63) >> 6;                  // chunk steps per sample of THIS tile
-    const int total = (b_end - b_begin) * nch;       // chunk steps of this workgroup
-
-    int* lrp = reinterpret_cast<int*>(g1);           // local row pointers, parked in g1 until the ELL is built
-    if (tid == 0) *tile_w = 2;
-    for (int i = tid; i < n2; i += NTH) rows[i] = P.s2_rows[s2_off + i];
-    for (int i = tid; i <= n1; i += NTH) lrp[i] = P.lrowptr[rp_off + i];
-    __syncthreads();
-
-    // staging role: two slots per chunk - list positions 64 c + srow and 64 c + srow + 32, 16-byte lane sq (dY channels 4 sq ..)
-    const int srow = tid >> 4;
-    const unsigned sq = (unsigned)(tid & 15);
-    auto load_step = [&](const int b, const int c, u32x4 (&dst)[2]) __attribute__((always_inline)) {
-        const char* base = P.dY + (size_t)b * y_sample + sq * 16u;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#ifdef DSW_ABL_B3_NOLOAD
-            dst[j] = u32x4{(unsigned)c, (unsigned)b, 0u, 0u};
-#else
-            dst[j] = *reinterpret_cast<const u32x4*>(base + (size_t)((unsigned)rows[min(64 * c + srow + 32 * j, n2 - 1)] * (unsigned)YB));
-#endif
-    };
-    // ring of two register slots: chunk step t lives in slot t & 1 and is requested two steps ahead
-    u32x4 ring0[2], ring1[2];
-    int pb = b_begin, pc = 0;                        // (sample, chunk) of the next step to request
-    auto advance_req = [&]() __attribute__((always_inline)) {
-        const int wrap = pc + 1 == nch ? 1 : 0;
-        pb += wrap;
-        pc = wrap ? 0 : pc + 1;
-    };
-    if (total > 0) { load_step(pb, pc, ring0); advance_req(); }
-    if (total > 1) { load_step(pb, pc, ring1); advance_req(); }
-
-    // CSR -> ELL of the tile + 1-ring rows (as dsw_fwd3.hip)
-    const int tile_nnz = lrp[n1];
-    for (int t = tid; t < n1 * W; t += NTH) {
-        const int i = t / W, j = t - i * W;
-        const int p0 = lrp[i], p1 = lrp[i + 1];
-        unsigned col = 0;
-        float val = 0.f;
-        if (tile_nnz > 0) {
-            const int p = max(0, min(p0 + j, tile_nnz - 1));
-            col = P.lcol[nnz_off + p];
-            val = P.lval[nnz_off + p];
-        }
-        if (j == 0 && p1 - p0 > 2) atomicMax(tile_w, p1 - p0);
-        const bool live = p0 + j < p1;
-        ell_idx[t] = (unsigned char)(live ? col : (unsigned)i);
-        ell_val[t] = live ? val : 0.f;
-    }
-
-    // MFMA role of this wave: plane group pg (0: plane 2, needed on the whole 2-ring; 1: plane 1 on the 1-ring and plane 0' on
-    // the tile), dX channel block fb, row blocks 2 rbh and 2 rbh + 1 of every chunk
-    const int wave = tid >> 6, lane = tid & 63;
-    const int pg = wave >> 2, fb = wave & 1, rbh = (wave >> 1) & 1;
-    const unsigned l15 = (unsigned)(lane & 15), kc = (unsigned)(lane >> 4);
-    bf16x8_t wa[2][3];                               // [k-step][term] of plane 2 (pg 0) / plane 1 (pg 1): resident
-    const unsigned char* wf_lane = P.wfrag + (size_t)lane * 16;
-    {
-        const int plane = pg == 0 ? 2 : 1;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-                wa[ks][t] = *reinterpret_cast<const bf16x8_t*>(wf_lane + ((size_t)(((plane * 2 + fb) * 2 + ks) * 3 + t)) * 1024);
-    }
-    __syncthreads();   // ELL complete (lrp in g1 dead)
-    const int Wt = *tile_w;
-
-    // gather role (hops): list position grp (+ 64 in the second pass of hop 1), 16-byte chunk of the 128-byte row
-    const int grp = tid >> 3;
-    const unsigned gcb = (unsigned)(tid & 7) * 16u;
-
-    int cb = b_begin, cc = 0;                        // (sample, chunk) of the current step
-    auto step = [&](u32x4 (&slot)[2], const int t) __attribute__((always_inline)) {
-        // ---- this step's rows -> split image; the slot then takes the step two ahead
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float f4[4] = {__uint_as_float(slot[j][0]), __uint_as_float(slot[j][1]), __uint_as_float(slot[j][2]),
-                                 __uint_as_float(slot[j][3])};
-            split_store4(img, IMG_TERM, (unsigned)(srow + 32 * j), sq, f4);
-        }
-        const int c = cc;
-        const bool tile_rows = pg == 1 && c == 0;    // plane 0' as well: on the tile rows, i.e. in the first chunk of a sample
-        // plane 0' fragments (tile rows only: one chunk step in nch) are fetched per use from the image in the workspace (L1 / L2
-        // hits, issued here, needed behind the barrier): resident they cost the 24 registers that decide between 128 and spills
-        bf16x8_t w0[2][3];
-        if (tile_rows) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int tt = 0; tt < 3; ++tt)
-                    w0[ks][tt] = *reinterpret_cast<const bf16x8_t*>(wf_lane + ((size_t)(((0 * 2 + fb) * 2 + ks) * 3 + tt)) * 1024);
-        }
-        // the slot takes the step two ahead - UNCONDITIONALLY (past the end: the last step again) and BEHIND the fragment loads:
-        // the loads retire in order, so the wait for the fragments leaves these two in flight (s_waitcnt vmcnt(2)); issued
-        // under a condition, or in front, the compiler must drain the queue at every step (a first build did: vmcnt(0) in
-        // front of the second k-step, i.e. an HBM round trip per chunk step, 210 us)
-        load_step(pb, pc, slot);
-        if (t + 3 < total) advance_req();
-        __syncthreads();   // image complete; everybody is past the hops of the previous sample
-#pragma unroll 1
-        for (int h = 0; h < 2; ++h) {
-            const int rb = 2 * rbh + h;
-            const int p0 = 64 * c + 16 * rb;                 // first list position of the row block
-            const bool need = pg == 0 ? p0 < n2 : p0 < n1;   // uniform per wave
-            if (need) {
-                f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, acc0 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {             // one k-step of B fragments live at a time (registers)
-                    bf16x8_t bf[3];
-                    const unsigned o = img_off(16u * rb + l15, 4u * ks + kc);
-#ifdef DSW_ABL_B3_NOFRAG
-#pragma unroll
-                    for (int tt = 0; tt < 3; ++tt) bf[tt] = wa[ks][tt];
-                    (void)o;
-#else
-#pragma unroll
-                    for (int tt = 0; tt < 3; ++tt) bf[tt] = *reinterpret_cast<const bf16x8_t*>(img + (size_t)tt * IMG_TERM + o);
-#endif
-                    acc = mfma6(wa[ks], bf, acc);
-                    if (tile_rows) acc0 = mfma6(w0[ks], bf, acc0);
-                }
-                const unsigned gcol = (16u * fb + 4u * kc) * 4u;                                  // 16 bytes of a G row
-                const unsigned grow_ = (unsigned)(p0 + (int)l15);
-                if (pg == 0) {
-                    if ((int)grow_ < n2) *reinterpret_cast<f32x4_t*>(g2 + grow_ * GS + gcol) = acc;
-                } else {
-                    if ((int)grow_ < n1) *reinterpret_cast<f32x4_t*>(g1 + grow_ * GS1 + gcol) = acc;
-                    if (tile_rows) *reinterpret_cast<f32x4_t*>(g0 + grow_ * GS1 + gcol) = acc0;
-                }
-            }
-        }
-        __syncthreads();   // the image may be overwritten; after the last chunk: G_2, G_1, G_0' complete
-        if (c == nch - 1) {
-            // ---- hop 1: H_1 = G_1 + 2 L^T G_2 on the tile + 1-ring rows, in place
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int i = grp + 64 * k;
-                if (i < n1) {
-                    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                    gather_ell<GS>(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, g2 + gcb, acc);
-                    float4* hp = reinterpret_cast<float4*>(g1 + (size_t)i * GS1 + gcb);
-                    const float4 g = *hp;
-                    *hp = make_float4(fmaf(2.f, acc[0], g.x), fmaf(2.f, acc[1], g.y), fmaf(2.f, acc[2], g.z), fmaf(2.f, acc[3], g.w));
-                }
-            }
-            __syncthreads();
-            // ---- hop 2: dX = G_0' + L^T H_1 on the tile rows -> HBM
-            if (grp < rt) {
-                float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                gather_ell<GS1>(ell_idx + (size_t)grp * W, ell_val + (size_t)grp * W, Wt, g1 + gcb, acc);
-                const float4 g = *reinterpret_cast<const float4*>(g0 + (size_t)grp * GS1 + gcb);
-                const float4 o = make_float4(g.x + acc[0], g.y + acc[1], g.z + acc[2], g.w + acc[3]);
-                st16_nt(P.dX + (size_t)cb * x_sample + (size_t)rows[grp] * XB + gcb, o);
-            }
-            // (no barrier: the next step has one between its split-store and the first write to a G buffer)
-        }
-        const int last = c == nch - 1 ? 1 : 0;
-        cb += last;
-        cc = last ? 0 : c + 1;
-    };
-    int t = 0;
-    for (; t + 1 < total; t += 2) {    // (both steps unconditional inside the loop: the compiler can then count the loads of the
-        step(ring0, t);                //  other slot as younger than the ones it waits for - s_waitcnt vmcnt(2), not vmcnt(0))
-        step(ring1, t + 1);
-    }
-    if (t < total) step(ring0, t);
-}
-
-// ---- third build: ONE workgroup of 16 waves per CU, the weights in LDS, NO image of dY ----------------------------------------
-// A wave owns one row block (16 list rows) of the tile's two-ring for the whole batch: it loads the dY rows of its block
-// straight into the B-fragment layout of the MFMA (lane (n, kg): 8 consecutive dY channels of row n - two 16-byte loads per
-// k-step), splits them in registers and multiplies them with the W fragments of the planes its rows need (plane 2 on the
-// two-ring, plane 1 on the one-ring, plane 0' on the tile), read from a split image of the weights in LDS, both dX channel
-// blocks interleaved (two independent accumulation chains).  No staging of dY through LDS, no chunk steps: three barriers per
-// sample (G complete / hop 1 done / hop 2 done), as in the forward kernel.
 constexpr int NTH3 = 1024;
 constexpr int W3_PLANE = 3 * 32 * 128;       // [term][32 f][64 o bf16], 16-byte chunks swizzled by the row (img_off)
 constexpr int W3_BYTES = 3 * W3_PLANE;       // 36 KB
 
-struct Bwd3vArgs {
+struct Bwd3Args {
     const int* tile_meta;
     const int* s2_rows;
     const int* lrowptr;
@@ -410,6 +150,11 @@ struct Bwd3vArgs {
 static __device__ __forceinline__ void split8(const u32x4 lo, const u32x4 hi, bf16x8_t (&t)[3]) {
     const float f[8] = {__uint_as_float(lo[0]), __uint_as_float(lo[1]), __uint_as_float(lo[2]), __uint_as_float(lo[3]),
                         __uint_as_float(hi[0]), __uint_as_float(hi[1]), __uint_as_float(hi[2]), __uint_as_float(hi[3])};
+#ifdef DSW_ABL_B3_NOSPLIT
+    const uint4 u0 = {pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7])};
+    t[0] = t[1] = t[2] = __builtin_bit_cast(bf16x8_t, u0);
+    return;
+#endif
     float r1[8], r2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -422,13 +167,12 @@ static __device__ __forceinline__ void split8(const u32x4 lo, const u32x4 hi, bf
     t[0] = __builtin_bit_cast(bf16x8_t, uh); t[1] = __builtin_bit_cast(bf16x8_t, um); t[2] = __builtin_bit_cast(bf16x8_t, ul);
 }
 
-__global__ __launch_bounds__(NTH3, 4) void cheb3_bwd_rowblock_kernel(const Bwd3vArgs P) {
+__global__ __launch_bounds__(NTH3, 4) void cheb3_bwd_fused_kernel(const Bwd3Args P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* wimg = lds;                                              // [3 planes][3 terms][32 f][128 B]
-    unsigned char* g2 = wimg + W3_BYTES;                                    // [max_n2][GS] G_2 on the 2-ring
-    unsigned char* g1 = g2 + (size_t)P.max_n2 * GS;                         // [max_n1][GS] G_1, then H_1, on the 1-ring
-    unsigned char* g0 = g1 + (size_t)P.max_n1 * GS;                         // [64][GS]     G_0' on the tile
-    float* ell_val = reinterpret_cast<float*>(g0 + 64 * GS);                // [max_n1][W]
+    const size_t gset = ((size_t)P.max_n2 + P.max_n1 + 64) * GS;           // one set of G buffers: G_2 | G_1 (H_1) | G_0'
+    unsigned char* gbuf = wimg + W3_BYTES;                                  // [2 sets]
+    float* ell_val = reinterpret_cast<float*>(gbuf + 2 * gset);             // [max_n1][W]
     unsigned char* ell_idx = reinterpret_cast<unsigned char*>(ell_val + (size_t)P.max_n1 * P.ell_w);   // [max_n1][W] u8
     int* rows = reinterpret_cast<int*>(ell_idx + (((size_t)P.max_n1 * P.ell_w + 3) & ~(size_t)3));   // [max_n2] global row ids
     int* tile_w = rows + ((P.max_n2 + 3) & ~3);
@@ -447,23 +191,33 @@ __global__ __launch_bounds__(NTH3, 4) void cheb3_bwd_rowblock_kernel(const Bwd3v
     const int W = P.ell_w;
     const size_t y_sample = (size_t)P.V * YB, x_sample = (size_t)P.V * XB;
 
-    int* lrp = reinterpret_cast<int*>(g1);           // local row pointers, parked in g1 until the ELL is built
+    int* lrp = reinterpret_cast<int*>(gbuf);         // local row pointers, parked in the G buffers until the ELL is built
     if (tid == 0) *tile_w = 2;
     for (int i = tid; i < n2; i += NTH3) rows[i] = P.s2_rows[s2_off + i];
     for (int i = tid; i <= n1; i += NTH3) lrp[i] = P.lrowptr[rp_off + i];
     __syncthreads();
 
-    // matrix role: wave w owns row block w (list rows 16 w .. 16 w + 15); lane (n = l & 15, kg = l >> 4)
     const int wave = tid >> 6, lane = tid & 63;
+    const bool matrix = wave < 8;                    // uniform per wave: waves 0-7 form the G planes, waves 8-15 run the hops
+    // ---- matrix role: row blocks wave and wave + 8 (list rows 16 rb .. 16 rb + 15); lane (n = l & 15, kg = l >> 4)
     const unsigned l15 = (unsigned)(lane & 15), kc = (unsigned)(lane >> 4);
-    const int p0 = 16 * wave;
-    const bool has2 = p0 < n2, has1 = p0 < n1, has0 = p0 < rt;            // uniform per wave
-    const unsigned yoff = (unsigned)rows[min(p0 + (int)l15, n2 - 1)] * (unsigned)YB + kc * 32u;   // + 128 for the second k-step
-    u32x4 py[4];
-    if (has2 && b_begin < b_end) {
-        const char* src = P.dY + (size_t)b_begin * y_sample + yoff;
+    const int pA = 16 * (wave & 7), pB = pA + 128;
+    const bool hasA = matrix && pA < n2, hasB = matrix && pB < n2;
+    const unsigned yoffA = (unsigned)rows[min(pA + (int)l15, n2 - 1)] * (unsigned)YB + kc * 32u;   // (+ 128: the second k-step)
+    const unsigned yoffB = (unsigned)rows[min(pB + (int)l15, n2 - 1)] * (unsigned)YB + kc * 32u;
+    u32x4 pyA[4], pyB[4];
+    auto load4 = [&](const int b, const unsigned yoff, u32x4 (&py)[4]) __attribute__((always_inline)) {
+#ifdef DSW_ABL_B3_NOLOAD
+        py[0] = py[1] = py[2] = py[3] = u32x4{(unsigned)b, yoff, 0u, 0u};
+#else
+        const char* src = P.dY + (size_t)b * y_sample + yoff;
         py[0] = *reinterpret_cast<const u32x4*>(src); py[1] = *reinterpret_cast<const u32x4*>(src + 16);
         py[2] = *reinterpret_cast<const u32x4*>(src + 128); py[3] = *reinterpret_cast<const u32x4*>(src + 144);
+#endif
+    };
+    if (b_begin < b_end) {
+        if (hasA) load4(b_begin, yoffA, pyA);
+        if (hasB) load4(b_begin, yoffB, pyB);
     }
     // CSR -> ELL of the tile + 1-ring rows (as dsw_fwd3.hip)
     const int tile_nnz = lrp[n1];
@@ -495,105 +249,116 @@ __global__ __launch_bounds__(NTH3, 4) void cheb3_bwd_rowblock_kernel(const Bwd3v
         }
         split_store4(wimg + (size_t)p * W3_PLANE, 32 * 128, (unsigned)f, q, v);
     }
-    __syncthreads();   // ELL and weight image complete (lrp in g1 dead)
+    __syncthreads();   // ELL and weight image complete (lrp in the G buffers dead)
     const int Wt = *tile_w;
 
     // A-fragment offsets in a plane of the weight image: dX channel blocks fb = 0 / 1, k-steps 0 / 1
     const unsigned a00 = img_off(l15, kc), a01 = img_off(l15, 4u + kc), a10 = img_off(16u + l15, kc), a11 = img_off(16u + l15, 4u + kc);
-    const unsigned grow_ = (unsigned)(p0 + (int)l15);
-    const unsigned gcol = 4u * kc * 4u;                  // 16 bytes of a G row: dX channels 16 fb + 4 kc .. + 3
+    const unsigned gcol = 4u * kc * 4u;              // 16 bytes of a G row: dX channels 16 fb + 4 kc .. + 3
 
-    // gather role (hops): list position grp, 16-byte chunk of the 128-byte row
-    const int grp = tid >> 3;
-    const unsigned gcb = (unsigned)(tid & 7) * 16u;
-
-    for (int b = b_begin; b < b_end; ++b) {
-        if (has2) {
-            bf16x8_t b0[3], b1[3];
-            split8(py[0], py[1], b0);
-            split8(py[2], py[3], b1);
-            {   // next sample's rows of this block: in flight under the matrix work and the hops
-                const char* src = P.dY + (size_t)(b + 1 < b_end ? b + 1 : b) * y_sample + yoff;
-                py[0] = *reinterpret_cast<const u32x4*>(src); py[1] = *reinterpret_cast<const u32x4*>(src + 16);
-                py[2] = *reinterpret_cast<const u32x4*>(src + 128); py[3] = *reinterpret_cast<const u32x4*>(src + 144);
-            }
+    // G planes of one row block (first list row p0) of the sample held in py -> set gs; py then takes sample b_next
+    auto form = [&](const int p0, const unsigned yoff, u32x4 (&py)[4], unsigned char* gs, const int b_next) __attribute__((always_inline)) {
+        bf16x8_t b0[3], b1[3];
+        split8(py[0], py[1], b0);
+        split8(py[2], py[3], b1);
+        load4(b_next, yoff, py);                     // in flight under the matrix work and the hops of a whole sample
+        unsigned char* s2 = gs;
+        unsigned char* s1 = gs + (size_t)P.max_n2 * GS;
+        unsigned char* s0 = s1 + (size_t)P.max_n1 * GS;
+        const unsigned grow_ = (unsigned)(p0 + (int)l15);
 #pragma unroll
-            for (int pi = 0; pi < 3; ++pi) {             // plane 2 (two-ring), plane 1 (one-ring), plane 0' (tile)
-                const int plane = 2 - pi;
-                const bool need = plane == 2 ? true : plane == 1 ? has1 : has0;
-                if (need) {
-                    const unsigned char* wp = wimg + (size_t)plane * W3_PLANE;
-                    f32x4_t c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-                    {
-                        bf16x8_t a0[3], a1[3];
+        for (int pi = 0; pi < 3; ++pi) {             // plane 2 (two-ring), plane 1 (one-ring), plane 0' (tile)
+            const int plane = 2 - pi;
+            const bool need = plane == 2 ? true : plane == 1 ? p0 < n1 : p0 < rt;
+            if (need) {
+                const unsigned char* wp = wimg + (size_t)plane * W3_PLANE;
+                f32x4_t c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+                {
+                    bf16x8_t a0[3], a1[3];
 #pragma unroll
-                        for (int t = 0; t < 3; ++t) {
-                            a0[t] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * (32 * 128) + a00);
-                            a1[t] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * (32 * 128) + a10);
-                        }
-                        mfma6x2(a0, a1, b0, c0, c1);
+                    for (int t = 0; t < 3; ++t) {
+                        a0[t] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * (32 * 128) + a00);
+                        a1[t] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * (32 * 128) + a10);
                     }
-                    {
-                        bf16x8_t a0[3], a1[3];
+                    mfma6x2(a0, a1, b0, c0, c1);
+                }
+                {
+                    bf16x8_t a0[3], a1[3];
 #pragma unroll
-                        for (int t = 0; t < 3; ++t) {
-                            a0[t] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * (32 * 128) + a01);
-                            a1[t] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * (32 * 128) + a11);
-                        }
-                        mfma6x2(a0, a1, b1, c0, c1);
+                    for (int t = 0; t < 3; ++t) {
+                        a0[t] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * (32 * 128) + a01);
+                        a1[t] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)t * (32 * 128) + a11);
                     }
-                    unsigned char* gd = (plane == 2 ? g2 : plane == 1 ? g1 : g0) + grow_ * GS + gcol;
-                    if ((int)grow_ < (plane == 2 ? n2 : plane == 1 ? n1 : 64)) {
-                        *reinterpret_cast<f32x4_t*>(gd) = c0;
-                        *reinterpret_cast<f32x4_t*>(gd + 64) = c1;
-                    }
+                    mfma6x2(a0, a1, b1, c0, c1);
+                }
+                unsigned char* gd = (plane == 2 ? s2 : plane == 1 ? s1 : s0) + grow_ * GS + gcol;
+                if ((int)grow_ < (plane == 2 ? n2 : plane == 1 ? n1 : 64)) {
+                    *reinterpret_cast<f32x4_t*>(gd) = c0;
+                    *reinterpret_cast<f32x4_t*>(gd + 64) = c1;
                 }
             }
         }
-        __syncthreads();   // G_2, G_1, G_0' complete
-        // ---- hop 1: H_1 = G_1 + 2 L^T G_2 on the tile + 1-ring rows, in place
-        if (grp < n1) {
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            gather_ell<GS>(ell_idx + (size_t)grp * W, ell_val + (size_t)grp * W, Wt, g2 + gcb, acc);
-            float4* hp = reinterpret_cast<float4*>(g1 + (size_t)grp * GS + gcb);
-            const float4 g = *hp;
-            *hp = make_float4(fmaf(2.f, acc[0], g.x), fmaf(2.f, acc[1], g.y), fmaf(2.f, acc[2], g.z), fmaf(2.f, acc[3], g.w));
-        }
-        __syncthreads();
-        // ---- hop 2: dX = G_0' + L^T H_1 on the tile rows -> HBM
-        if (grp < rt) {
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            gather_ell<GS>(ell_idx + (size_t)grp * W, ell_val + (size_t)grp * W, Wt, g1 + gcb, acc);
-            const float4 g = *reinterpret_cast<const float4*>(g0 + (size_t)grp * GS + gcb);
-            const float4 o = make_float4(g.x + acc[0], g.y + acc[1], g.z + acc[2], g.w + acc[3]);
-            st16_nt(P.dX + (size_t)b * x_sample + (size_t)rows[grp] * XB + gcb, o);
-        }
-        __syncthreads();   // the next sample's matrix phase overwrites the G buffers
-    }
-}
+    };
 
-size_t bwd3v_lds_bytes(const dsw_hop2_plan* plan) {
-    const int ell_w = (plan->reserved + 3) & ~3;
-    size_t s = (size_t)W3_BYTES + ((size_t)plan->max_n2 + plan->max_n1 + 64) * GS;
-    s += (size_t)plan->max_n1 * ell_w * 4 + (((size_t)plan->max_n1 * ell_w + 3) & ~(size_t)3);   // fp32 values + u8 positions
-    s += (size_t)((plan->max_n2 + 3) & ~3) * 4 + 16;
-    return (s + 15) & ~(size_t)15;
+    // ---- hop role (waves 8-15): list positions hg and hg + 64, 16-byte chunk of the 128-byte row
+    const int hg = (tid & 511) >> 3;
+    const unsigned gcb = (unsigned)(tid & 7) * 16u;
+
+    // pipeline prologue: the G planes of the first sample
+    if (b_begin < b_end) {
+        const int bn = b_begin + 1 < b_end ? b_begin + 1 : b_begin;
+        if (hasA) form(pA, yoffA, pyA, gbuf, bn);
+        if (hasB) form(pB, yoffB, pyB, gbuf, bn);
+    }
+    __syncthreads();
+    for (int b = b_begin; b < b_end; ++b) {
+        unsigned char* gs = gbuf + (size_t)((b - b_begin) & 1) * gset;          // set of sample b (read by the hops)
+        unsigned char* gn = gbuf + (size_t)((b - b_begin + 1) & 1) * gset;      // set of sample b + 1 (written by the matrix waves)
+        const bool more = b + 1 < b_end;
+        const int bn = b + 2 < b_end ? b + 2 : b_end - 1;
+        if (matrix) {
+            if (more && hasA) form(pA, yoffA, pyA, gn, bn);
+        } else {
+            // ---- hop 1: H_1 = G_1 + 2 L^T G_2 on the tile + 1-ring rows, in place
+            unsigned char* s2 = gs;
+            unsigned char* s1 = gs + (size_t)P.max_n2 * GS;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = hg + 64 * k;
+                if (i < n1) {
+                    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                    gather_ell<GS>(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, s2 + gcb, acc);
+                    float4* hp = reinterpret_cast<float4*>(s1 + (size_t)i * GS + gcb);
+                    const float4 g = *hp;
+                    *hp = make_float4(fmaf(2.f, acc[0], g.x), fmaf(2.f, acc[1], g.y), fmaf(2.f, acc[2], g.z), fmaf(2.f, acc[3], g.w));
+                }
+            }
+        }
+        __syncthreads();   // H_1 of sample b complete (the matrix waves pass here between their two row blocks)
+        if (matrix) {
+            if (more && hasB) form(pB, yoffB, pyB, gn, bn);
+        } else {
+            // ---- hop 2: dX = G_0' + L^T H_1 on the tile rows -> HBM
+            unsigned char* s1 = gs + (size_t)P.max_n2 * GS;
+            unsigned char* s0 = s1 + (size_t)P.max_n1 * GS;
+            if (hg < rt) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                gather_ell<GS>(ell_idx + (size_t)hg * W, ell_val + (size_t)hg * W, Wt, s1 + gcb, acc);
+                const float4 g = *reinterpret_cast<const float4*>(s0 + (size_t)hg * GS + gcb);
+                const float4 o = make_float4(g.x + acc[0], g.y + acc[1], g.z + acc[2], g.w + acc[3]);
+                st16_nt(P.dX + (size_t)b * x_sample + (size_t)rows[hg] * XB + gcb, o);
+            }
+        }
+        __syncthreads();   // set of sample b free, set of sample b + 1 complete
+    }
 }
 
 size_t bwd3_lds_bytes(const dsw_hop2_plan* plan) {
     const int ell_w = (plan->reserved + 3) & ~3;
-    size_t s = (size_t)IMG_BYTES + (size_t)plan->max_n2 * GS + ((size_t)plan->max_n1 + 64) * GS1;
+    size_t s = (size_t)W3_BYTES + 2 * ((size_t)plan->max_n2 + plan->max_n1 + 64) * GS;
     s += (size_t)plan->max_n1 * ell_w * 4 + (((size_t)plan->max_n1 * ell_w + 3) & ~(size_t)3);   // fp32 values + u8 positions
     s += (size_t)((plan->max_n2 + 3) & ~3) * 4 + 16;
     return (s + 15) & ~(size_t)15;
-}
-
-int launch_bwd3(const Bwd3Args& A, long nwg, size_t lds, hipStream_t stream) {
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)cheb3_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return DSW_ERR_LAUNCH;
-    DSW_LAUNCH(cheb3_bwd_fused_kernel, dim3((unsigned)nwg), dim3(NTH), lds, stream, A);
-    return dsw_check_launch();
 }
 
 }  // namespace
@@ -604,52 +369,36 @@ int dsw_cheb3_bwd_fused_eligible(const dsw_hop2_plan* plan_t, int64_t Fin, int64
     if (env && env[0] == '0') return 0;
     if (dtype != DSW_F32 || K != 3 || Fin != 32 || Fout != 64) return 0;
     if (!plan_t || plan_t->hops == 1 || plan_t->tile_rows != 64 || !dsw_spmm2_supported(plan_t, Fin, dtype)) return 0;
-    if (plan_t->max_n2 > 255 || plan_t->max_n1 > 128) return 0;     // u8 list positions, 16 row blocks for 16 waves; hop 1 in one pass
-#ifdef DSW_BWD3_V2
-    if (bwd3_lds_bytes(plan_t) > 80 * 1024) return 0;               // (second build: two workgroups per CU or not at all)
-#else
-    if (bwd3v_lds_bytes(plan_t) > 160 * 1024) return 0;
-#endif
+    if (plan_t->max_n2 > 255 || plan_t->max_n1 > 128) return 0;     // u8 list positions, 16 row blocks on 8 matrix waves; hop 1 in two passes
+    if (bwd3_lds_bytes(plan_t) > 160 * 1024) return 0;
     return 1;
 }
 
 // dX from dY in one launch if the shape / plan allow it.  Returns 1 if it took the call (*rc = status), 0 if the caller
-// must use the generic sequence (dgrad planes + adjoint recurrence).
+// must use the generic sequence (dgrad planes + adjoint recurrence).  (ws: unused since the weights image moved to LDS.)
 int dsw_cheb3_bwd_fused_try(const dsw_hop2_plan* plan_t, int64_t V, const void* dY, const void* W, void* dX, int64_t B,
                             int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int* rc, void* ws,
                             int64_t ws_bytes) {
+    (void)ws; (void)ws_bytes;
     if (!dsw_cheb3_bwd_fused_eligible(plan_t, Fin, Fout, K, dtype)) return 0;
     if (!dsw_aligned16(dY) || !dsw_aligned16(dX) || !dsw_aligned16(W)) return 0;
-#ifdef DSW_BWD3_V2
-    if (ws == nullptr || !dsw_aligned16(ws) || ws_bytes < WFRAG_BYTES) return 0;      // scratch for the split W fragments
-#else
-    (void)ws; (void)ws_bytes;
-#endif
     if ((unsigned long long)V * YB >= (1ull << 32)) return 0;           // 32-bit row offsets inside a sample
     if (V <= 0 || B <= 0) { *rc = DSW_OK; return 1; }
-#ifdef DSW_BWD3_V2
     Bwd3Args A;
-    A.wfrag = static_cast<const unsigned char*>(ws);
-    const long per_cu = 2;
-#else
-    Bwd3vArgs A;
-    A.W = static_cast<const float*>(W);
-    const long per_cu = 1;
-#endif
     A.tile_meta = plan_t->tile_meta; A.s2_rows = plan_t->s2_rows; A.lrowptr = plan_t->lrowptr;
     A.lcol = plan_t->lcol; A.lval = plan_t->lval;
-    A.dY = static_cast<const char*>(dY); A.dX = static_cast<char*>(dX);
+    A.dY = static_cast<const char*>(dY); A.dX = static_cast<char*>(dX); A.W = static_cast<const float*>(W);
     A.V = (int)V; A.n_tiles = plan_t->n_tiles; A.max_n1 = plan_t->max_n1; A.max_n2 = plan_t->max_n2;
     A.B = (int)B; A.ell_w = (plan_t->reserved + 3) & ~3; A.explicit_tiles = plan_t->explicit_tiles;
-    // batch chunks: rounds over the resident slots x (plan + weight staging, about 2 samples' worth, + samples per chunk)
-    const long slots = per_cu * dsw_device_cus();
+    // batch chunks: one workgroup per CU; rounds x (plan + weight staging + pipeline fill, about 3 samples' worth, + samples per chunk)
+    const long slots = dsw_device_cus();
     long chunks = 1;
     {
         double best = -1.0;
         const long cmax = B > 1 ? (B + 1) / 2 : 1;
         for (long c = 1; c <= cmax && c <= 16; ++c) {
             const long rounds = (plan_t->n_tiles * c + slots - 1) / slots;
-            const double cost = (double)rounds * (2.0 + (double)((B + c - 1) / c));
+            const double cost = (double)rounds * (3.0 + (double)((B + c - 1) / c));
             if (best < 0 || cost < best - 1e-9) { best = cost; chunks = c; }
         }
     }
@@ -657,19 +406,12 @@ int dsw_cheb3_bwd_fused_try(const dsw_hop2_plan* plan_t, int64_t V, const void* 
     A.n_chunks = (int)((B + A.spc - 1) / A.spc);
     const long nwg = (long)plan_t->n_tiles * A.n_chunks;
     if (nwg > 2147483647L) return 0;
-#ifdef DSW_BWD3_V2
     const size_t lds = bwd3_lds_bytes(plan_t);
-    DSW_LAUNCH(bwd3_wprep_kernel, dim3(3), dim3(256), 0, stream, static_cast<const float*>(W), static_cast<unsigned char*>(ws));
-    if ((*rc = dsw_check_launch()) != DSW_OK) return 1;
-    *rc = launch_bwd3(A, nwg, lds, stream);
-#else
-    const size_t lds = bwd3v_lds_bytes(plan_t);
-    if (hipFuncSetAttribute((const void*)cheb3_bwd_rowblock_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)cheb3_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         *rc = DSW_ERR_LAUNCH;
         return 1;
     }
-    DSW_LAUNCH(cheb3_bwd_rowblock_kernel, dim3((unsigned)nwg), dim3(NTH3), lds, stream, A);
+    DSW_LAUNCH(cheb3_bwd_fused_kernel, dim3((unsigned)nwg), dim3(NTH3), lds, stream, A);
     *rc = dsw_check_launch();
-#endif
     return 1;
 }
