@@ -146,6 +146,11 @@ int dsw_cheb3_hop2mix_eligible(const dsw_hop2_plan* plan, int64_t Fin, int64_t F
 int dsw_cheb3_hop2mix_try(const dsw_hop2_plan* plan, int64_t V, const void* X, const void* W, const void* bias, void* Y,
                           void* T, int64_t B, int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int* rc,
                           int relu, void (*after_hop1)(void*), void* ctx);
+int dsw_cheb3_bwd_dual_eligible(const dsw_hop2_plan* plan_t, int64_t V, int64_t Fin, int64_t Fout, int64_t K, int dtype);
+int64_t dsw_cheb3_bwd_dual_ws_bytes(void);
+int dsw_cheb3_bwd_dual_try(const dsw_hop2_plan* plan_t, int64_t V, const void* X, const void* dY, const void* W, void* dX,
+                           void* dW, void* db, float* partial, int64_t B, int64_t Fin, int64_t Fout, int64_t K, int dtype,
+                           hipStream_t stream, int* rc, int accumulate);
 int dsw_cheb3_bwd_fused_try(const dsw_hop2_plan* plan_t, int64_t V, const void* dY, const void* W, void* dX, int64_t B,
                             int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int* rc, void* ws,
                             int64_t ws_bytes);
@@ -478,6 +483,13 @@ int dsw_cheb_dx_one_launch(const dsw_hop2_plan* plan_t, int64_t V, const void* d
     return took ? rc : DSW_ERR_ALIGN;
 }
 
+int dsw_cheb_bwd_needs_basis(const dsw_hop2_plan* plan_t, int64_t V, int64_t Fin, int64_t Fout, int64_t K, int dtype) {
+    if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
+    if (Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
+    if (K == 1 || mix_first(Fin, Fout, K)) return 0;
+    return dsw_cheb3_bwd_dual_eligible(plan_t, V, Fin, Fout, K, dtype) ? 0 : 1;
+}
+
 int dsw_cheb_fwd_path(const dsw_hop2_plan* plan, int64_t Fin, int64_t Fout, int64_t K, int dtype) {
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     if (Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
@@ -638,7 +650,13 @@ int64_t dsw_cheb_bwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t 
     const int64_t S = dsw_wgrad_slabs(N, Fin, Fout, K);
     const int64_t p = round_up((S > 0 ? S : 1) * (K * Fin + 1) * Fout * 4, 256);
     const int64_t wf = round_up(w_image_bytes(Fin, Fout, K, dtype), 256);   // pre-split / folded image of the weights for the dgrad GEMM
-    return g + p + wf + 256;
+    int64_t total = g + p + wf + 256;
+    // the one-launch dual backward (dsw_bwd3d.hip) parks one slab of dW / db partials per persistent workgroup at the base
+    if (dtype == DSW_F32 && K == 3 && Fin == 32 && Fout == 64 && V % 64 == 0) {
+        const int64_t d = round_up(dsw_cheb3_bwd_dual_ws_bytes(), 256) + 256;
+        if (d > total) total = d;
+    }
+    return total;
 }
 
 static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t, int64_t V,
@@ -656,7 +674,7 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
     const bool mf = mix_first(Fin, Fout, K);
     const int64_t N = B * V;
     hipStream_t s = (hipStream_t)stream;
-    if (N > 0 && (!dY || !X || !W || (K > 1 && !T && !mf))) return DSW_ERR_BAD_ARG;
+    if (N > 0 && (!dY || !X || !W)) return DSW_ERR_BAD_ARG;
     if (N == 0) {   // an empty batch shard (B < world size): the parameter gradients are exactly zero, not "unwritten"
         if (dW && hipMemsetAsync(dW, 0, (size_t)(Fin * K * Fout * elem_size(dtype)), s) != hipSuccess) return DSW_ERR_LAUNCH;
         if (db && hipMemsetAsync(db, 0, (size_t)(Fout * elem_size(dtype)), s) != hipSuccess) return DSW_ERR_LAUNCH;
@@ -687,6 +705,17 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
         }
         return rcm;
     }
+    if (!extras && (dX != nullptr || dW != nullptr)) {
+        // K = 3, 32 -> 64, fp32, two-hop plan of L^T: the whole backward in ONE launch in the dual form (dsw_bwd3d.hip) - the
+        // Chebyshev basis of dY under L^T on chip, dX = sum_k U_k W_k^T and dW_k = X^T U_k from it: neither T nor dgrad planes
+        int rcd = DSW_OK;
+        if (dsw_cheb3_bwd_dual_try(plan_t, V, X, dY, W, dX, dW, db, reinterpret_cast<float*>(ws), B, Fin, Fout, K, dtype, s, &rcd,
+                                   accumulate)) {
+            trace_mark(stream, DSW_ROLE_BWD_DUAL, V, Fin, Fout);
+            return rcd;
+        }
+    }
+    if (K > 1 && !T) return DSW_ERR_BAD_ARG;         // every other route reads the forward's basis planes
     const int64_t plane = N * Fin * elem_size(dtype);
     char* G = ws;                                                    // G_1 .. G_{K-1}
     char* spare = G + (K - 1) * plane;

@@ -109,6 +109,7 @@ int dsw_build_flags(void);
 #define DSW_ROLE_CLENSHAW_FWD 12   /* mix-first forward: Clenshaw recurrence on the output channels */
 #define DSW_ROLE_ELEMENTWISE 13    /* relu mask (kind 1), ReZero residual forward (2) / backward (3), ReZero parameter gradients (4) */
 #define DSW_ROLE_BWD_FUSED 14      /* dgrad + adjoint recurrence in one launch (dY -> dX) */
+#define DSW_ROLE_BWD_DUAL 15       /* whole backward in one launch in the dual form (X, dY -> dX, dW, db) + the partial reduce */
 #define DSW_ROLE_FWD_HOP2_MIX 16     /* hop 2 + channel mix + bias of the forward in one launch (one-hop plans) */
 #define DSW_ROLE_BASIS_DUAL 15     /* mix-first backward: Chebyshev basis of dY under L^T (on the output channels) */
 int dsw_trace_begin(int capacity);
@@ -309,6 +310,14 @@ int dsw_cheb_fwd_ws(const int32_t* rowptr, const int32_t* colind, const float* v
 /* Backward of that activation (autograd of F.relu, what the reference's ConvBlock records):
  *     dYm[i] = Y[i] > 0 ? dY[i] : 0          (Y = the layer's activated output; n elements; dYm may alias dY) */
 int dsw_relu_bwd(const void* dY, const void* Y, void* dYm, int64_t n, int dtype, dsw_stream_t stream);
+
+/* 0 if dsw_cheb_bwd of this layer shape works WITHOUT the forward's basis planes (T = NULL): mix-first layers, K = 1, and
+ * layers whose whole backward runs in one launch in the dual form (dsw_bwd3d.hip: fp32, K = 3, 32 -> 64, two-hop plan of
+ * L^T, V % 64 == 0):
+ *     U_k = T_k(L^T) dY on chip,   dX = sum_k U_k W_k^T,   dW_k = X^T U_k,   db = 1^T dY
+ * - X and dY in, dX out, no T_1 / T_2 and no dgrad planes.  The forward of such a layer may then be called with T = NULL
+ * (dsw_cheb_fwd: "inference" form, the basis is not stored).  1: T is required.  plan_t: the plan dsw_cheb_bwd will get. */
+int dsw_cheb_bwd_needs_basis(const dsw_hop2_plan* plan_t, int64_t V, int64_t Fin, int64_t Fout, int64_t K, int dtype);
 
 /* Scratch bytes dsw_cheb_bwd needs for this problem size. */
 int64_t dsw_cheb_bwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t Fout, int64_t K,
