@@ -426,7 +426,8 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
     t_dgrad, t_wgrad = tr("bwd_dgrad", V, C, Fout), tr("bwd_wgrad", V, C, Fout)
     t_adj = tr("basis_adj", V, C, K)
     t_bwdf = tr("bwd_fused", V, C, Fout)
-    have_trace = t_adj is not None or t_bwdf is not None or mf
+    t_dual = tr("bwd_dual", V, C, Fout)                # whole backward in one launch in the dual form (dsw_bwd3d.hip)
+    have_trace = t_adj is not None or t_bwdf is not None or t_dual is not None or mf
 
     # forward recurrence alone: in the step where the step launches it, otherwise an isolated leg (north-star gate)
     fwd_s_iso = timed(fwd)
@@ -434,7 +435,7 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
     adj_s_iso = None
     if t_adj is not None:
         adj_s = t_adj["avg_us"] * 1e-6
-    elif t_bwdf is not None:
+    elif t_bwdf is not None or t_dual is not None:
         adj_s = None                 # the adjoint recurrence lives inside the one-launch backward: no launch of its own
     else:
         adj_s = adj_s_iso = timed(adj)
@@ -442,7 +443,8 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
 
     yb_bytes = N * Fout * es
     wf_bytes = fwd_b + (K * E + yb_bytes)
-    compulsory_fwd = int(E + (K - 1) * E + yb_bytes)
+    # (a backward in the dual form needs no basis planes: the forward then stores Y only)
+    compulsory_fwd = int(E + yb_bytes) if t_dual is not None else int(E + (K - 1) * E + yb_bytes)
 
     def entry(role, kernels, sec, nbytes, calls, extra=None):
         d = {"role": role, "kernels": kernels, "avg_us": round(sec * 1e6, 2), "calls_per_step": calls,
@@ -497,6 +499,16 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
                              t_bwdf["avg_us"] * 1e-6, yb_bytes + K * E + bwd_b, t_bwdf["calls_per_step"],
                              {"compulsory_bytes": int(yb_bytes + E),
                               "bytes_note": "algorithmic = the dgrad GEMM (dY in, K planes out) + the adjoint recurrence it replaces"}))
+    dual_bytes = (K * E + yb_bytes + K * E) + bwd_b      # what the dual launch replaces: fused wgrad + dgrad pass + adjoint recurrence
+    if t_dual is not None:
+        in_step.append(entry("whole backward in ONE launch in the dual form (X, dY -> dX, dW, db; + the partial reduce)",
+                             "cheb3_bwd_dual + cheb_wgrad_reduce", t_dual["avg_us"] * 1e-6, dual_bytes, t_dual["calls_per_step"],
+                             {"compulsory_bytes": int(E + yb_bytes + E), "flops": gemm_flops,
+                              "TFLOPs": round(gemm_flops / (t_dual["avg_us"] * 1e-6) / 1e12, 1),
+                              "frac_compulsory": round((E + yb_bytes + E) / (t_dual["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                              "bytes_note": "algorithmic = the launches it replaces (SURVEY 8d: K basis planes + dY in, K dgrad planes "
+                                            "out; adjoint recurrence 7E + 2Lb); it MOVES X, dY in and dX out (compulsory_bytes): the "
+                                            "Chebyshev basis of dY under L^T lives in LDS only"}))
     if t_adj is not None:
         in_step.append(entry("adjoint recurrence (dsw_cheb_bwd: basis_adj launches)", "spmm_csr x%d" % (K - 1) if ppt is None else
                              "spmm1_dma / spmm1_staged x%d" % (K - 1) if _k2.hops == 1 else "spmm2_fused adjoint pair(s)",
@@ -509,15 +521,17 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
     # the adjoint recurrence always (inside cheb3_bwd_fused where the step takes that launch); the forward recurrence only
     # where the step launches it (not at the north-star shape, whose forward is ONE launch with the hops inside)
     legs = []
-    if t_bwdf is None:
+    if t_bwdf is None and t_dual is None:
         legs.append(("adj", n_adj, adj_s, bwd_b))
     if fwd_rec_in_step:
         legs.append(("fwd", n_fwd, fwd_s, fwd_b))
     elif t_h2m is not None and t_bfwd is not None:     # hop 1 is a launch of its own; hop 2 lives in the fused launch (in_step)
         legs.append(("fwd1", 1, t_bfwd["avg_us"] * 1e-6, spmm_algorithmic_bytes(E, Lb, 2)[0]))
-    fused_bwd = t_bwdf is not None
-    if fused_bwd:      # the adjoint recurrence lives inside the fused backward launch: that launch against the bytes it replaces
+    fused_bwd = t_bwdf is not None or t_dual is not None
+    if t_bwdf is not None:   # the adjoint recurrence lives inside the fused backward launch: that launch against the bytes it replaces
         legs.append(("bwdf", 1, t_bwdf["avg_us"] * 1e-6, yb_bytes + K * E + bwd_b))
+    if t_dual is not None:   # ... or inside the dual launch, together with the wgrad + dgrad pass
+        legs.append(("bwdd", 1, t_dual["avg_us"] * 1e-6, dual_bytes))
     n_in = sum(l[1] for l in legs)
     t_in = sum(l[2] for l in legs)
     b_in = sum(l[3] for l in legs)
@@ -541,7 +555,8 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
     out = {
         "bound": "hbm",
         "kernel": ("SpMM recurrence launches of a timed step: " +
-                   ("cheb3_bwd_fused (dgrad GEMM + adjoint recurrence in one launch)" if fused_bwd else
+                   ("cheb3_bwd_dual (the WHOLE backward in one launch: L^T recurrence on dY in LDS, dX and dW from it)" if t_dual is not None else
+                    "cheb3_bwd_fused (dgrad GEMM + adjoint recurrence in one launch)" if fused_bwd else
                     "adjoint recurrence (%s)" % kname(_k2, True)) +
                    ((" + forward recurrence (%s)" % kname(_k1, False)) if fwd_rec_in_step else "") +
                    "; forward path of this layer: %s" % path_names.get(fwd_path)),
@@ -570,6 +585,9 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
         "in_step_sum_us": round(step_sum_us, 2),
         "mfma": out_mfma,
     }
+    if t_dual is not None:   # the fused launch moves far fewer bytes than the 8(d) count of what it replaces: say both
+        out["compulsory_bytes"] = int(E + yb_bytes + E)
+        out["frac_compulsory"] = round((E + yb_bytes + E) / (t_dual["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
     if ms_per_step is not None and in_step:
         out["in_step_sum_vs_ms_per_step"] = round(step_sum_us / (ms_per_step * 1e3), 4)
     return out

@@ -162,7 +162,9 @@ static __device__ __forceinline__ void gather_ell(const unsigned char* __restric
 // registers) and RBW = NCB / 2 of the four 16-row blocks of the tile.
 // FULL: every tile has 64 rows (V % 64 == 0) and the basis is kept (T != NULL): no store of the loop sits under a
 // condition, so the compiler can count the VMEM operations behind the prefetch loads (s_waitcnt vmcnt(n), n > 0).
-template <int NST, int NS1, int NCB, bool FULL>
+// KEEP: the basis planes T1 / T2 are stored (training with a backward that reads them); !KEEP with FULL: no T store at all
+// (inference, or a backward in the dual form - dsw_bwd3d.hip - which needs X and dY only).
+template <int NST, int NS1, int NCB, bool FULL, bool KEEP = true>
 __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3Args P) {
     constexpr int RBW = NCB / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
                 *reinterpret_cast<uint4*>(bufT + (size_t)i * RB + cb) = packed;
                 if (k == 0) {
                     // uniform 64-bit base + 32-bit lane offset: the store takes its address from an SGPR pair + one VGPR
-                    if constexpr (FULL) st16(P.T1 + sample + tile_off, packed);
+                    if constexpr (FULL) { if constexpr (KEEP) st16(P.T1 + sample + tile_off, packed); }
                     else if (P.T1 != nullptr && i < rt) st16(P.T1 + sample + tile_off, packed);
                     split_store(simg, 1, i, c4, acc);
                     const float4 xr = *reinterpret_cast<const float4*>(bufX + (size_t)i * RB + cb);
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
                 gather_ell(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, bufT + cb, acc);
                 const float4 u = *reinterpret_cast<const float4*>(bufX + (size_t)i * RB + cb);
                 const float t2[4] = {fmaf(2.f, acc[0], -u.x), fmaf(2.f, acc[1], -u.y), fmaf(2.f, acc[2], -u.z), fmaf(2.f, acc[3], -u.w)};
-                if (FULL || P.T2 != nullptr)
+                if ((FULL && KEEP) || (!FULL && P.T2 != nullptr))
                     st16(P.T2 + sample + tile_off,
                          make_uint4(__float_as_uint(t2[0]), __float_as_uint(t2[1]), __float_as_uint(t2[2]), __float_as_uint(t2[3])));
                 split_store(simg, 2, i, c4, t2);
@@ -576,14 +578,14 @@ size_t fwd3_lds_bytes(const dsw_hop2_plan* plan) {
     return (s + 15) & ~(size_t)15;
 }
 
-template <int NST, int NS1, bool FULL>
+template <int NST, int NS1, bool FULL, bool KEEP = true>
 int launch_ncb(const Fwd3Args& A, long nwg, size_t lds, hipStream_t stream) {
 #define DSW_F3(N_)                                                                                                      \
     case N_: {                                                                                                          \
-        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)cheb3_fwd_fused_kernel<NST, NS1, N_, FULL>,             \
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)cheb3_fwd_fused_kernel<NST, NS1, N_, FULL, KEEP>,       \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
             return DSW_ERR_LAUNCH;                                                                                      \
-        DSW_LAUNCH((cheb3_fwd_fused_kernel<NST, NS1, N_, FULL>), dim3((unsigned)nwg), dim3(NTHREADS), lds, stream, A); \
+        DSW_LAUNCH((cheb3_fwd_fused_kernel<NST, NS1, N_, FULL, KEEP>), dim3((unsigned)nwg), dim3(NTHREADS), lds, stream, A); \
         break;                                                                                                          \
     }
     switch (A.Fout / 16) {
@@ -650,11 +652,16 @@ int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X,
     const long nwg = (long)plan->n_tiles * A.n_chunks;
     if (nwg > 2147483647L) return 0;
     int r;
-    const bool full = (V % 64 == 0) && T != nullptr && !plan->explicit_tiles;
-    if (nst == 3 && ns1 == 2) r = full ? launch_ncb<3, 2, true>(A, nwg, lds, stream) : launch_ncb<3, 2, false>(A, nwg, lds, stream);
-    else if (nst == 2 && ns1 <= 2) r = full ? launch_ncb<2, 2, true>(A, nwg, lds, stream) : launch_ncb<2, 2, false>(A, nwg, lds, stream);
-    else if (nst == 3) r = full ? launch_ncb<3, 3, true>(A, nwg, lds, stream) : launch_ncb<3, 3, false>(A, nwg, lds, stream);
-    else r = full ? launch_ncb<4, 4, true>(A, nwg, lds, stream) : launch_ncb<4, 4, false>(A, nwg, lds, stream);
+    const bool full = (V % 64 == 0) && !plan->explicit_tiles;
+    const bool keep = T != nullptr;
+#define DSW_F3_PICK(A_, B_)                                                                           \
+    r = !full ? launch_ncb<A_, B_, false>(A, nwg, lds, stream)                                        \
+              : keep ? launch_ncb<A_, B_, true, true>(A, nwg, lds, stream) : launch_ncb<A_, B_, true, false>(A, nwg, lds, stream)
+    if (nst == 3 && ns1 == 2) DSW_F3_PICK(3, 2);
+    else if (nst == 2 && ns1 <= 2) DSW_F3_PICK(2, 2);
+    else if (nst == 3) DSW_F3_PICK(3, 3);
+    else DSW_F3_PICK(4, 4);
+#undef DSW_F3_PICK
     *rc = r;
     return 1;
 }

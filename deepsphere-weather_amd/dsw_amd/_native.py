@@ -147,7 +147,7 @@ def load():
 
 ROLE_NAMES = {1: "spmm", 2: "spmm2", 3: "spmm_staged", 4: "basis_fwd", 5: "basis_adj", 6: "mix_fwd", 7: "fwd_one_launch",
               8: "bwd_gemm_fused", 9: "bwd_dgrad", 10: "bwd_wgrad", 11: "zmix", 12: "clenshaw_fwd", 13: "elementwise",
-              14: "bwd_fused", 15: "basis_dual", 16: "fwd_hop2_mix"}
+              14: "bwd_fused", 15: "basis_dual", 16: "fwd_hop2_mix", 17: "bwd_dual"}
 
 
 class LaunchTrace:

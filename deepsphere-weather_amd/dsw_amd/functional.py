@@ -404,17 +404,25 @@ class _HipBackend:
             _native.check(rc, "dsw_cheb_basis_fwd")
         return T
 
-    def cheb_fwd(self, op, x, w, bias, relu=False):
+    def cheb_fwd(self, op, x, w, bias, relu=False, keep_basis=True):
+        """``keep_basis=False``: the caller's backward is plain ``cheb_bwd`` / ``cheb_bwd_res`` without scale / dx_add - where
+        that backward runs in the dual form (``dsw_cheb_bwd_needs_basis`` == 0: X and dY only) AND the forward is the
+        one-launch kernel, the basis planes are neither allocated nor stored and ``T`` comes back as None."""
         lib = _native.load()
         B, V, Fin = x.shape
         _, K, Fout = w.shape
         y = torch.empty((B, V, Fout), dtype=x.dtype, device=x.device)
-        T = torch.empty((K - 1, B, V, Fin), dtype=x.dtype, device=x.device) if K > 1 else None
         # mix-first layers (channel-shrinking, see dsw_cheb_mix_first) run their hops on Fout channels, use T as
         # scratch only and need nothing but x for backward
         mix_first = bool(lib.dsw_cheb_mix_first(Fin, Fout, K))
         pp, _keep = (_plan_ptr(op, x, Fout if mix_first else Fin)
                      if (K > 1 and (_FWD_FUSED or mix_first)) else (None, None))
+        drop = False
+        if not keep_basis and K > 1 and not mix_first and pp is not None and op is not None \
+                and lib.dsw_cheb_fwd_path(pp, Fin, Fout, K, _DTYPES[x.dtype]) == 3:      # DSW_FWD_ONE_LAUNCH takes T = NULL
+            ppt, _keep_t = _plan_ptr(op.transpose(), x, Fin)
+            drop = ppt is not None and lib.dsw_cheb_bwd_needs_basis(ppt, V, Fin, Fout, K, _DTYPES[x.dtype]) == 0
+        T = torch.empty((K - 1, B, V, Fin), dtype=x.dtype, device=x.device) if (K > 1 and not drop) else None
         csr = (None, None, None, V, 0) if op is None else (
             op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz)
         ws, nws = self._fwd_workspace(lib, x, Fin, Fout, K)
@@ -452,7 +460,7 @@ class _HipBackend:
             _native.check(nbytes, "dsw_cheb_bwd_workspace_bytes")
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
         mix_first = bool(lib.dsw_cheb_mix_first(Fin, Fout, K))
-        need_hops = K > 1 and (need_dx or (mix_first and want_w))
+        need_hops = K > 1 and (need_dx or (mix_first and want_w) or T is None)    # (T is None: the dual form runs its hops on dY)
         opt = op.transpose() if need_hops else op
         pp, _keep = _plan_ptr(opt, x, Fout if mix_first else Fin) if (need_hops and K > 1) else (None, None)
         csr = (None, None, None, V, 0) if opt is None else (
@@ -510,7 +518,7 @@ class _HipBackend:
             _native.check(nbytes, "dsw_cheb_bwd_workspace_bytes")
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
         mix_first = bool(lib.dsw_cheb_mix_first(Fin, Fout, K))
-        need_hops = K > 1 and (need_dx or (mix_first and need_dw))
+        need_hops = K > 1 and (need_dx or (mix_first and need_dw) or T is None)
         opt = op.transpose() if need_hops else op
         pp, _keep = _plan_ptr(opt, x, Fout if mix_first else Fin) if (need_hops and K > 1) else (None, None)
         csr = (None, None, None, V, 0) if opt is None else (
@@ -724,7 +732,11 @@ class _ChebConvFn(torch.autograd.Function):
             xc = x.contiguous()
             wc = weight.contiguous()
         bc = None if bias is None else bias.contiguous()
-        y, T = be.cheb_fwd(op, xc, wc, bc, relu) if relu else be.cheb_fwd(op, xc, wc, bc)
+        if getattr(be, "name", "") == "hip":
+            # this Function's backward is the plain closed form: the basis planes are dropped where it runs in the dual form
+            y, T = be.cheb_fwd(op, xc, wc, bc, relu, keep_basis=False)
+        else:
+            y, T = be.cheb_fwd(op, xc, wc, bc, relu) if relu else be.cheb_fwd(op, xc, wc, bc)
         # the plain output is NOT saved: callers modify it in place (layers.py:375, my_models_graph.py:213).  With the
         # fused activation the output IS the ReLU result, whose sign pattern backward needs (as F.relu saves its result);
         # an in-place edit by the caller then trips autograd's version check instead of corrupting gradients.

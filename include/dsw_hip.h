@@ -109,9 +109,9 @@ int dsw_build_flags(void);
 #define DSW_ROLE_CLENSHAW_FWD 12   /* mix-first forward: Clenshaw recurrence on the output channels */
 #define DSW_ROLE_ELEMENTWISE 13    /* relu mask (kind 1), ReZero residual forward (2) / backward (3), ReZero parameter gradients (4) */
 #define DSW_ROLE_BWD_FUSED 14      /* dgrad + adjoint recurrence in one launch (dY -> dX) */
-#define DSW_ROLE_BWD_DUAL 15       /* whole backward in one launch in the dual form (X, dY -> dX, dW, db) + the partial reduce */
 #define DSW_ROLE_FWD_HOP2_MIX 16     /* hop 2 + channel mix + bias of the forward in one launch (one-hop plans) */
 #define DSW_ROLE_BASIS_DUAL 15     /* mix-first backward: Chebyshev basis of dY under L^T (on the output channels) */
+#define DSW_ROLE_BWD_DUAL 17       /* whole backward in one launch in the dual form (X, dY -> dX, dW, db), + the partial reduce */
 int dsw_trace_begin(int capacity);
 int dsw_trace_end(int32_t* call, int32_t* roles, int32_t* aux0, int32_t* aux1, int32_t* aux2, float* us, char* names,
                   int name_stride, int cap);

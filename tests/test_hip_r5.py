@@ -43,7 +43,7 @@ def test_launch_trace_reports_the_roles_of_a_step():
         assert {(r[0], r[1], r[2]) for r in roles["spmm"]} == {(768, 3072, 64), (3072, 768, 64)}
         fwd = roles.get("fwd_one_launch") or roles.get("basis_fwd")
         assert fwd and len(fwd) == 3
-        assert "basis_adj" in roles or "bwd_fused" in roles
+        assert "basis_adj" in roles or "bwd_fused" in roles or "bwd_dual" in roles
         for rs in roles.values():
             for _a0, _a1, _a2, us in rs:
                 assert 0.5 < us < 5000.0, rs
