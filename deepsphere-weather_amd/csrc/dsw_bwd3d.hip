@@ -29,7 +29,7 @@
 // next chunk's rows can only be written once everybody has left the matrix phase.
 #include <cstdlib>
 #if defined(DSW_ABL_D3_NODW) || defined(DSW_ABL_D3_NODX) || defined(DSW_ABL_D3_NOGATHER) || defined(DSW_ABL_D3_NOSPLIT) || \
-    defined(DSW_ABL_D3_NOD) || defined(DSW_ABL_D3_NOLOAD) || defined(DSW_ABL_D3_NOTR)
+    defined(DSW_ABL_D3_NOD) || defined(DSW_ABL_D3_NOLOAD) || defined(DSW_D3_TIMELINE)
 #define DSW_ABLATION 1   // timing experiments (tools/build_variant1.sh): wrong results by design, refused by _native.load()
 #endif
 #include "dsw_common.h"
@@ -173,6 +173,12 @@ static __device__ __forceinline__ bf16x8_t read_tr(const unsigned char* p) {
         acc_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah_, bh_, acc_, 0, 0, 0);         \
     } while (0)
 
+#ifdef DSW_D3_TIMELINE   // diagnostics build: cycle stamps of waves 0 and 4 of workgroup 0 (third sample of its first item) behind the scratch slots
+#define DSW_STAMP(i_) do { if (blockIdx.x == 0 && b == b_begin + 2 && orig == blockIdx.x && (tid == 0 || tid == 256)) \
+        reinterpret_cast<long long*>(P.pscr + (size_t)gridDim.x * 8192)[(tid >> 8) * 32 + c * 16 + (i_)] = clock64(); } while (0)
+#else
+#define DSW_STAMP(i_) do { } while (0)
+#endif
 // NST / NS1: register-stage slots per thread for the gather list (ceil(max_n2 / 64)) and for the one-ring (ceil(max_n1 / 64)).
 // Every tile is FULL (64 rows: V % 64 == 0, tiles of consecutive rows) - a condition of eligibility.
 template <int NST, int NS1>
@@ -278,7 +284,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_bwd_dual_kernel(const DualA
         for (int b = b_begin; b < b_end; ++b) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
+                DSW_STAMP(0);
                 __syncthreads();   // A: the rows of (b, c) are complete in bufX
+                DSW_STAMP(1);
                 {   // next chunk's rows (and, in chunk phase 1, the next sample's X tile row): in flight under phases 1, 2 and 3
                     const int bn = c == 0 ? b : (b + 1 < b_end ? b + 1 : b);
                     const char* src = P.dY + (size_t)bn * y_sample + (c == 0 ? RB : 0);
@@ -308,7 +316,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_bwd_dual_kernel(const DualA
                         }
                     }
                 }
+                DSW_STAMP(2);
                 __syncthreads();   // B: U_1 complete; bufX is dead (the U_2 image takes its place)
+                DSW_STAMP(3);
                 // ---- phase 2: U_2 = 2 L^T U_1 - U_0 on the tile rows -> split image; chunk phase 0: the X tile rows -> split image
                 {
                     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -323,7 +333,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_bwd_dual_kernel(const DualA
                         xq = *reinterpret_cast<const u32x4*>(P.X + (size_t)bn * x_sample + ((unsigned)rows[grp] * (unsigned)RB + cb));
                     }
                 }
+                DSW_STAMP(4);
                 __syncthreads();   // C: images complete; nobody reads bufT of this chunk any more
+                DSW_STAMP(5);
                 // ---- phase 3: matrix cores
                 int tv = tid;
                 asm volatile("" : "+v"(tv));          // opaque: everything below is recomputed here, not kept across the phases
@@ -422,9 +434,11 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_bwd_dual_kernel(const DualA
                         *reinterpret_cast<f32x4_t*>(d) = o + dba;
                     }
                 }
+                DSW_STAMP(6);
 #ifndef DSW_ABL_D3_NOD
                 __syncthreads();   // D: everybody has left the matrix phase: images, bufX, handoff slot readable / writable
 #endif
+                DSW_STAMP(7);
                 {   // next chunk's rows -> the (single) input buffer; the next barrier A publishes them
                     const unsigned sto = (unsigned)tv * 16u;          // = grp * RB + cb
 #pragma unroll

@@ -89,6 +89,22 @@ if "--eager-only" in sys.argv:     # for counter collection (rocprofv3 --pmc doe
         bwd(pt, o1, basis=False)
     torch.cuda.synchronize()
     sys.exit(0)
+if "--timeline" in sys.argv:    # -DDSW_D3_TIMELINE build: cycle stamps of waves 0 and 4 of workgroup 0 around the barriers of one sample
+    o1 = outs()
+    fwd()
+    for _ in range(3):
+        bwd(pt, o1, basis=False)
+    torch.cuda.synchronize()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    base = (-ws.data_ptr()) % 256
+    off = base + (2 * cus + 8) * (97 * 64) * 4 + 512 * 8192
+    st = ws[off:off + 64 * 8].view(torch.int64).cpu().tolist()
+    names = ["->A", "A", "ph1 end", "B", "ph2 end", "C", "mfma end", "D"]
+    for wv in (0, 1):
+        t = st[wv * 32:(wv + 1) * 32]
+        t0 = t[0]
+        print("wave %d:" % (4 * wv), " | ".join("c%d %s %d" % (i // 16, names[i % 16], t[i] - t0) for i in list(range(8)) + list(range(16, 24))))
+    sys.exit(0)
 if "--time-only" in sys.argv:
     o1 = outs()
     fwd()
