@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--global-batch", type=int, default=None,
                     help="STRONG scaling: this many samples in total, sharded over the ranks with dsw_amd.parallel.shard_batch "
                          "(ragged and empty shards allowed); default: the workload's batch PER GPU (weak scaling)")
-    ap.add_argument("--pmc-leg", default=None, choices=["fwd", "adj", "pool"],
+    ap.add_argument("--pmc-leg", default=None, choices=["fwd", "adj", "pool", "bwdd", "fwd1l"],
                     help="profiling aid (tools/pmc_traffic.sh): run ONLY that leg of the roofline measurement - the forward "
                          "recurrence, the adjoint recurrence or the pooling products of the workload - and exit; every "
                          "dispatch of the run then belongs to the leg")
@@ -164,6 +164,14 @@ def _native_lib():
     from dsw_amd import _native
 
     return _native.load()
+
+
+def _moved(traffic_key, leg, sec):
+    """HBM bytes the counters saw for a one-launch leg (profiles/spmm_traffic.json) and the fraction of 8 TB/s they are in `sec`."""
+    m = _traffic(traffic_key, leg) if leg else None
+    if m is None:
+        return {}
+    return {"bytes_moved": int(m["hbm_bytes_per_call"]), "frac_counter": round(m["hbm_bytes_per_call"] / sec / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 def _traffic(traffic_key, leg):
@@ -370,8 +378,25 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
                                     G0.data_ptr(), Gr.data_ptr(), B, C, K, dcode, st, ppt, spare.data_ptr())
         assert rc == 0
 
-    if pmc_leg in ("fwd", "adj"):     # profiling aid: this leg only
-        fn = fwd if pmc_leg == "fwd" else adj
+    def bwdd():  # the whole backward as the step runs it where it is ONE launch in the dual form (no basis planes, T = NULL)
+        Fo = layer.out_channels
+        nb = int(lib.dsw_cheb_bwd_workspace_bytes(B, V, C, Fo, K, dcode))
+        if not hasattr(bwdd, "t"):
+            bwdd.t = (torch.empty(nb, dtype=torch.uint8, device=x.device), torch.randn(B, V, Fo, dtype=x.dtype, device=x.device),
+                      torch.empty_like(x), torch.empty_like(layer.weight), torch.empty(Fo, dtype=x.dtype, device=x.device))
+        ws, dy, dx, dw, db = bwdd.t
+        rc = lib.dsw_cheb_bwd(opt.rowptr.data_ptr(), opt.colind.data_ptr(), opt.values.data_ptr(), V, opt.nnz, x.data_ptr(), None,
+                              layer.weight.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nb,
+                              B, C, Fo, K, dcode, st, ppt)
+        assert rc == 0, rc
+
+    def fwd1l():  # the forward of such a layer: one launch, no basis stores
+        from dsw_amd import functional as F2
+
+        F2._backend_for(x).cheb_fwd(op, x, layer.weight.detach(), None if layer.bias is None else layer.bias.detach(), keep_basis=False)
+
+    if pmc_leg in ("fwd", "adj", "bwdd", "fwd1l"):     # profiling aid: this leg only
+        fn = {"fwd": fwd, "adj": adj, "bwdd": bwdd, "fwd1l": fwd1l}[pmc_leg]
         for _ in range(steps):
             fn()
         torch.cuda.synchronize()
@@ -456,7 +481,9 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
     in_step = []
     if t_one is not None:
         in_step.append(entry("forward (dsw_cheb_fwd)", "cheb3_fwd_fused: hops + channel mix + bias in ONE launch",
-                             t_one["avg_us"] * 1e-6, wf_bytes, t_one["calls_per_step"], {"compulsory_bytes": compulsory_fwd}))
+                             t_one["avg_us"] * 1e-6, wf_bytes, t_one["calls_per_step"],
+                             dict({"compulsory_bytes": compulsory_fwd}, **_moved(traffic_key, "fwd1l" if t_dual is not None else None,
+                                                                               t_one["avg_us"] * 1e-6))))
     elif t_h2m is not None:
         hop1_b = spmm_algorithmic_bytes(E, Lb, 2)[0]
         if t_bfwd is not None:
@@ -506,6 +533,7 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
                              {"compulsory_bytes": int(E + yb_bytes + E), "flops": gemm_flops,
                               "TFLOPs": round(gemm_flops / (t_dual["avg_us"] * 1e-6) / 1e12, 1),
                               "frac_compulsory": round((E + yb_bytes + E) / (t_dual["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                              **_moved(traffic_key, "bwdd", t_dual["avg_us"] * 1e-6),
                               "bytes_note": "algorithmic = the launches it replaces (SURVEY 8d: K basis planes + dY in, K dgrad planes "
                                             "out; adjoint recurrence 7E + 2Lb); it MOVES X, dY in and dX out (compulsory_bytes): the "
                                             "Chebyshev basis of dY under L^T lives in LDS only"}))

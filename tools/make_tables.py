@@ -82,14 +82,20 @@ if ns and (ns.get("roofline") or {}).get("in_step"):
       "`ms_per_step`) next to rocprofv3 `--stats` of the same command (`profiles/%s_default_kernel_stats.csv`):" % (
           ns["roofline"].get("in_step_sum_vs_ms_per_step") or float("nan"), tag))
     w("")
-    w("| role | in-graph us (bench.py) | algorithmic MB -> fraction of 8 TB/s | rocprofv3 kernel (avg us, % of GPU time) |")
-    w("|---|---|---|---|")
-    match = {"forward": "cheb3_fwd_fused_kernel", "backward GEMM": "cheb_wgrad_x3_kernel", "adjoint": "spmm2_fused_kernel<false, 3, true, true"}
+    w("| role | in-graph us (bench.py) | algorithmic MB -> fraction of 8 TB/s | compulsory MB -> fraction | counter MB -> fraction | rocprofv3 kernel (avg us, % of GPU time) |")
+    w("|---|---|---|---|---|---|")
+    match = {"forward": "cheb3_fwd_fused_kernel", "backward GEMM": "cheb_wgrad_x3_kernel", "adjoint": "spmm2_fused_kernel<false, 3, true, true",
+             "whole backward": "cheb3_bwd_dual_kernel"}
     for e in ns["roofline"]["in_step"]:
         pat = next((v for k, v in match.items() if e["role"].startswith(k)), None)
-        kn = next((r_ for r_ in st if pat and r_[0].startswith(pat)), None)
+        kn = next((r_ for r_ in sorted(st, key=lambda r_: -r_[1]) if pat and r_[0].startswith(pat)), None)
         prof = "`%s` %.1f us, %.1f %%" % (kn[0][:52], kn[2], kn[3]) if kn else "-"
-        w("| %s | %.1f | %.0f -> %.2f | %s |" % (e["role"], e["avg_us"], e["algorithmic_bytes"] / 1e6, e["frac"], prof))
+        cb_, mv = e.get("compulsory_bytes"), e.get("bytes_moved")
+        sec = e["avg_us"] * 1e-6
+        w("| %s | %.1f | %.0f -> %.2f | %s | %s | %s |" % (
+            e["role"], e["avg_us"], e["algorithmic_bytes"] / 1e6, e["frac"],
+            "%.0f -> %.2f" % (cb_ / 1e6, cb_ / sec / 8e12) if cb_ else "-",
+            "%.0f -> %.2f" % (mv / 1e6, mv / sec / 8e12) if mv else "-", prof))
     w("")
 for key, fn in (("ns_default", "default"), ("ns_k20", "k20"), ("c3", "c3"), ("unet", "unet"), ("c5", "c5")):
     rows = stats("%s_%s_kernel_stats.csv" % (tag, fn))

@@ -18,15 +18,16 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_path = os.path.join(ROOT, "profiles", "spmm_traffic.json")
 CALLS = 20
-KERNEL = re.compile(r"(spmm1_dma_kernel<[^>]*>|spmm1_staged_kernel<[^>]*>|spmm2_fused_kernel<[^>]*>|spmm_csr_rowsplit<[^>]*>|remap_\w+_kernel<[^>]*>|spmm_long_rows\w*<[^>]*>)")
+LEGS = ("fwd", "adj", "pool", "bwdd", "fwd1l")
+KERNEL = re.compile(r"(spmm1_dma_kernel<[^>]*>|spmm1_staged_kernel<[^>]*>|spmm2_fused_kernel<[^>]*>|spmm_csr_rowsplit<[^>]*>|remap_\w+_kernel<[^>]*>|spmm_long_rows\w*<[^>]*>|cheb3_bwd_dual_kernel<[^>]*>|cheb3_fwd_fused_kernel<[^>]*>|cheb_wgrad_reduce_kernel<[^>]*>)")
 tag, keys = sys.argv[1], sys.argv[2:]
 result = {}
 if os.path.exists(out_path):
     old = json.load(open(out_path))
-    result = {k: v for k, v in old.items() if isinstance(v, dict) and any(leg in v for leg in ("fwd", "adj", "pool"))}
+    result = {k: v for k, v in old.items() if isinstance(v, dict) and any(leg in v for leg in LEGS)}
 for key in keys:
     entry = {}
-    for leg in ("fwd", "adj", "pool"):
+    for leg in LEGS:
         vals = collections.defaultdict(lambda: collections.defaultdict(list))
         for f in glob.glob(f"{ROOT}/gpurun_out/pmct_{tag}_{key}_{leg}_[AB]/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):

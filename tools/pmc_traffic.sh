@@ -12,6 +12,7 @@ for wl in $wls; do
     ns) wargs="";; ns_k20) wargs="--knn 20";; c3) wargs="--workload c3";; unet) wargs="--workload unet";; c5) wargs="--workload c5";;
   esac
   legs="fwd adj"; if [ $wl = unet ] || [ $wl = c5 ]; then legs="fwd adj pool"; fi
+  if [ $wl = ns ]; then legs="fwd adj bwdd fwd1l"; fi     # (the step's backward / forward are ONE launch each there)
   for leg in $legs; do
     for pass in "A FETCH_SIZE" "B WRITE_SIZE"; do
       set -- $pass; p=$1; shift
