@@ -187,6 +187,62 @@ static __device__ __forceinline__ void gather_ell8(const unsigned char* __restri
         }
 }
 
+// ... and for EIGHT channels per lane (four lanes per 128-byte row): the positions / values of a row are read and decoded once
+// per 8 channels instead of once per 4 - half the index arithmetic and half the stencil reads of the 8-lane form - and a
+// 512-thread pass covers 128 list rows (the whole one-ring of a tile).  bufc = buffer + 32 q (this lane's 32 bytes of a row).
+static __device__ __forceinline__ void gather_ell8w(const unsigned char* __restrict__ row_idx, const float* __restrict__ row_val,
+                                                    const int W, const unsigned char* __restrict__ bufc, float (&acc)[8]) {
+#ifdef DSW_ABL_D3_NOGATHER
+    acc[0] = row_val[0]; return;
+#endif
+    const unsigned w0 = *reinterpret_cast<const unsigned*>(row_idx), w1 = *reinterpret_cast<const unsigned*>(row_idx + 4);
+    const unsigned w2 = *reinterpret_cast<const unsigned*>(row_idx + 8);
+    const float4 v0 = *reinterpret_cast<const float4*>(row_val), v1 = *reinterpret_cast<const float4*>(row_val + 4);
+    const float4 v2 = *reinterpret_cast<const float4*>(row_val + 8);
+    auto four = [&](const unsigned w, const float4 v) __attribute__((always_inline)) {
+        const unsigned ix[4] = {(w & 0xffu) << 7, ((w >> 8) & 0xffu) << 7, ((w >> 16) & 0xffu) << 7, (w >> 24) << 7};
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        float4 d[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            d[t][0] = *reinterpret_cast<const float4*>(bufc + ix[t]);
+            d[t][1] = *reinterpret_cast<const float4*>(bufc + ix[t] + 16);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc[0] = fmaf(vv[t], d[t][0].x, acc[0]); acc[1] = fmaf(vv[t], d[t][0].y, acc[1]);
+            acc[2] = fmaf(vv[t], d[t][0].z, acc[2]); acc[3] = fmaf(vv[t], d[t][0].w, acc[3]);
+            acc[4] = fmaf(vv[t], d[t][1].x, acc[4]); acc[5] = fmaf(vv[t], d[t][1].y, acc[5]);
+            acc[6] = fmaf(vv[t], d[t][1].z, acc[6]); acc[7] = fmaf(vv[t], d[t][1].w, acc[7]);
+        }
+    };
+    four(w0, v0);
+    four(w1, v1);
+    const float v2a[4] = {v2.x, v2.y, v2.z, v2.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (8 + t < W) {
+            const unsigned off = ((w2 >> (8 * t)) & 0xffu) << 7;
+            const float4 d0 = *reinterpret_cast<const float4*>(bufc + off), d1 = *reinterpret_cast<const float4*>(bufc + off + 16);
+            acc[0] = fmaf(v2a[t], d0.x, acc[0]); acc[1] = fmaf(v2a[t], d0.y, acc[1]);
+            acc[2] = fmaf(v2a[t], d0.z, acc[2]); acc[3] = fmaf(v2a[t], d0.w, acc[3]);
+            acc[4] = fmaf(v2a[t], d1.x, acc[4]); acc[5] = fmaf(v2a[t], d1.y, acc[5]);
+            acc[6] = fmaf(v2a[t], d1.z, acc[6]); acc[7] = fmaf(v2a[t], d1.w, acc[7]);
+        }
+}
+// the three bf16 terms of 8 consecutive channels (16-byte chunk q of 4) of image row `row` -> LDS, one 16-byte write per term
+static __device__ __forceinline__ void split_store8(unsigned char* __restrict__ img, const int row, const unsigned q, const float (&f)[8]) {
+#ifdef DSW_ABL_D3_NOSPLIT
+    if (row >= 0) return;
+#endif
+    bf16x8_t h, m, l;
+    split3x8(f, h, m, l);
+    unsigned char* base = img + (unsigned)row * 64u + ((q ^ (((unsigned)row >> 2) & 2u)) << 4);
+    *reinterpret_cast<bf16x8_t*>(base) = h;
+    *reinterpret_cast<bf16x8_t*>(base + IMG_TERM) = m;
+    *reinterpret_cast<bf16x8_t*>(base + 2 * IMG_TERM) = l;
+}
+
 // 8 consecutive ROWS of one channel column of a row-major image: two transposing reads (rows +0..3 at p, +4..7 at p + 256)
 static __device__ __forceinline__ bf16x8_t read_tr(const unsigned char* p) {
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -558,19 +614,25 @@ __global__ __launch_bounds__(NT16, 4) void cheb3_bwd_dual16_kernel(const DualArg
             for (int i = tid; i < n2; i += 512) rows[i] = P.s2_rows[s2_off + i];
             for (int i = tid; i <= n1; i += 512) lrp[i] = P.lrowptr[rp_off + i];
             __syncthreads();   // P1
-            const unsigned tile_off = (unsigned)rows[grp] * (unsigned)RB + cb;     // this thread's tile row in X, sample-relative
             auto offU = [&](const int k) __attribute__((always_inline)) {
                 return (unsigned)rows[min(grp + k * RPP, n2 - 1)] * (unsigned)YB + cb;
             };
             // rows travel TWO chunk steps ahead of their use (a step is too short for an HBM round trip): register set s0 carries
             // the rows of chunk 0 of the next sample, s1 those of chunk 1
             u32x4 s0[NST], s1[NST];
-            u32x4 xq = {0u, 0u, 0u, 0u};
+            // hops: FOUR lanes per row, 8 channels per lane (gather_ell8w): thread -> (list row tid >> 2, 32-byte piece tid & 3)
+            const int row4 = tid >> 2;
+            const unsigned q4 = (unsigned)(tid & 3);
+            const unsigned x_off = (unsigned)rows[row4 & 63] * (unsigned)RB + q4 * 32u;    // waves 4-7: X tile row (row4 - 64), its 32 bytes
+            u32x4 xq[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
 #pragma unroll
             for (int k = 0; k < NST; ++k) s0[k] = *reinterpret_cast<const u32x4*>(P.dY + (size_t)b_begin * y_sample + offU(k));
 #pragma unroll
             for (int k = 0; k < NST; ++k) s1[k] = *reinterpret_cast<const u32x4*>(P.dY + (size_t)b_begin * y_sample + RB + offU(k));
-            xq = *reinterpret_cast<const u32x4*>(P.X + (size_t)b_begin * x_sample + tile_off);
+            if (row4 >= 64) {
+                xq[0] = *reinterpret_cast<const u32x4*>(P.X + (size_t)b_begin * x_sample + x_off);
+                xq[1] = *reinterpret_cast<const u32x4*>(P.X + (size_t)b_begin * x_sample + x_off + 16);
+            }
             const int tile_nnz = lrp[n1];
             for (int t = tid; t < n1 * W; t += 512) {
                 const int i = t / W, j = t - i * W;
@@ -601,7 +663,7 @@ __global__ __launch_bounds__(NT16, 4) void cheb3_bwd_dual16_kernel(const DualArg
                 __syncthreads();   // A: rows of this step complete; the matrix waves have left image set c (read one step ago)
                 DSW_ST16(0, b == b_begin + 2 && live, c * 8 + 1);
                 unsigned char* img = simg + (size_t)c * (3 * IMG_PLANE);
-                float u0[4] = {0.f, 0.f, 0.f, 0.f};
+                float u0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 if (live) {
                     {   // the rows of the same chunk of the NEXT sample: two steps of flight
                         const int bn = b + 1 < b_end ? b + 1 : b;
@@ -609,39 +671,44 @@ __global__ __launch_bounds__(NT16, 4) void cheb3_bwd_dual16_kernel(const DualArg
 #pragma unroll
                         for (int k = 0; k < NST; ++k) fill[k] = *reinterpret_cast<const u32x4*>(src + offU(k));
                     }
-                    // ---- hop 1: U_1 = L^T U_0 on the one-ring; the tile rows (slot 0) also leave the split images of U_0 and U_1
-#pragma unroll
-                    for (int k = 0; k < NS1; ++k) {
-                        const int i = grp + k * RPP;
-                        if (k == 0 || i < n1) {
-                            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                            gather_ell8(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, bufX + cb, acc);
-                            *reinterpret_cast<uint4*>(bufT + (size_t)i * RB + cb) =
-                                make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3]));
-                            if (k == 0) {
-                                split_store(img + IMG_PLANE, i, c4, acc);
-                                const float4 xr = *reinterpret_cast<const float4*>(bufX + (size_t)i * RB + cb);
-                                u0[0] = xr.x; u0[1] = xr.y; u0[2] = xr.z; u0[3] = xr.w;
-                                split_store(img, i, c4, u0);
-                            }
+                    // ---- hop 1: U_1 = L^T U_0 on the one-ring, ONE pass (128 list rows x 4 lanes); the tile rows (waves 0-3) also leave
+                    // the split images of U_0 and U_1 and keep their U_0 values for hop 2
+                    if (row4 < n1) {
+                        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        gather_ell8w(ell_idx + (size_t)row4 * W, ell_val + (size_t)row4 * W, Wt, bufX + q4 * 32u, acc);
+                        unsigned char* tp_ = bufT + (size_t)row4 * RB + q4 * 32u;
+                        *reinterpret_cast<float4*>(tp_) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                        *reinterpret_cast<float4*>(tp_ + 16) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+                        if (row4 < 64) {
+                            split_store8(img + IMG_PLANE, row4, q4, acc);
+                            const float4 xa = *reinterpret_cast<const float4*>(bufX + (size_t)row4 * RB + q4 * 32u);
+                            const float4 xb = *reinterpret_cast<const float4*>(bufX + (size_t)row4 * RB + q4 * 32u + 16);
+                            u0[0] = xa.x; u0[1] = xa.y; u0[2] = xa.z; u0[3] = xa.w; u0[4] = xb.x; u0[5] = xb.y; u0[6] = xb.z; u0[7] = xb.w;
+                            split_store8(img, row4, q4, u0);
                         }
                     }
                 }
                 DSW_ST16(0, b == b_begin + 2 && live, c * 8 + 2);
-                __syncthreads();   // B: U_1 complete; bufX is dead (this thread keeps its own U_0 row)
+                __syncthreads();   // B: U_1 complete; bufX is dead (the tile-row threads keep their U_0 values)
                 DSW_ST16(0, b == b_begin + 2 && live, c * 8 + 3);
                 if (live) {
-                    // ---- hop 2: U_2 = 2 L^T U_1 - U_0 on the tile rows -> split image; chunk 0: the X tile rows -> split image
-                    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                    gather_ell8(ell_idx + (size_t)grp * W, ell_val + (size_t)grp * W, Wt, bufT + cb, acc);
-                    const float t2[4] = {fmaf(2.f, acc[0], -u0[0]), fmaf(2.f, acc[1], -u0[1]), fmaf(2.f, acc[2], -u0[2]), fmaf(2.f, acc[3], -u0[3])};
-                    split_store(img + 2 * IMG_PLANE, grp, c4, t2);
-                    if (c == 0) {
-                        const float xf[4] = {__uint_as_float(xq[0]), __uint_as_float(xq[1]), __uint_as_float(xq[2]), __uint_as_float(xq[3])};
-                        split_store(ximg + (size_t)((b - b_begin) & 1) * IMG_PLANE, grp, c4, xf);
+                    if (row4 < 64) {
+                        // ---- hop 2 (waves 0-3): U_2 = 2 L^T U_1 - U_0 on the tile rows -> split image
+                        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        gather_ell8w(ell_idx + (size_t)row4 * W, ell_val + (size_t)row4 * W, Wt, bufT + q4 * 32u, acc);
+                        float t2[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) t2[j] = fmaf(2.f, acc[j], -u0[j]);
+                        split_store8(img + 2 * IMG_PLANE, row4, q4, t2);
+                    } else if (c == 0) {
+                        // ---- waves 4-7, chunk 0: the X tile rows of this sample -> split image
+                        const float xf[8] = {__uint_as_float(xq[0][0]), __uint_as_float(xq[0][1]), __uint_as_float(xq[0][2]), __uint_as_float(xq[0][3]),
+                                             __uint_as_float(xq[1][0]), __uint_as_float(xq[1][1]), __uint_as_float(xq[1][2]), __uint_as_float(xq[1][3])};
+                        split_store8(ximg + (size_t)((b - b_begin) & 1) * IMG_PLANE, row4 - 64, q4, xf);
                     } else {
                         const int bn = b + 1 < b_end ? b + 1 : b;
-                        xq = *reinterpret_cast<const u32x4*>(P.X + (size_t)bn * x_sample + tile_off);
+                        xq[0] = *reinterpret_cast<const u32x4*>(P.X + (size_t)bn * x_sample + x_off);
+                        xq[1] = *reinterpret_cast<const u32x4*>(P.X + (size_t)bn * x_sample + x_off + 16);
                     }
                     // the NEXT step's rows -> the (single) input buffer: nobody reads it between barrier B and the next barrier A
 #pragma unroll
@@ -872,7 +939,7 @@ bool dual16_wanted(const dsw_hop2_plan* plan) {
 #endif
     static const char* env = dsw_diag_env("DSW_BWD_DUAL16");   // "1": the 16-wave form (diagnostics builds only: measured equal, not taken)
     if (!env || env[0] != '1') return false;
-    if (((plan->reserved + 3) & ~3) > 12) return false;          // gather_ell8 walks at most 12 entries per row
+    if (((plan->reserved + 3) & ~3) > 12 || plan->max_n1 > 128) return false;   // at most 12 entries per row; hop 1 is ONE pass of 128 list rows
     return dual16_lds_bytes(plan) <= 160 * 1024;
 }
 
