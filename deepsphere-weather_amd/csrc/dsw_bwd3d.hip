@@ -153,96 +153,6 @@ static __device__ __forceinline__ void gather_ell(const unsigned char* __restric
     }
 }
 
-// The same sum with the whole stencil requested up front (gather waves of the 16-wave form, which have the registers): the
-// positions and values of the first 12 entries in one round of reads, then the first 8 rows in flight together, then the
-// rest one by one - three dependent LDS round trips for the usual 9-entry row instead of six.  (W <= 12 storage is a condition
-// of that form; entries behind a row's length are {own row, 0}.)
-static __device__ __forceinline__ void gather_ell8(const unsigned char* __restrict__ row_idx, const float* __restrict__ row_val,
-                                                   const int W, const unsigned char* __restrict__ bufc, float (&acc)[4]) {
-#ifdef DSW_ABL_D3_NOGATHER
-    acc[0] = row_val[0]; return;
-#endif
-    const uint2 w01 = {*reinterpret_cast<const unsigned*>(row_idx), *reinterpret_cast<const unsigned*>(row_idx + 4)};   // (rows are W bytes apart: 4-byte aligned)
-    const unsigned w2 = *reinterpret_cast<const unsigned*>(row_idx + 8);
-    const float4 v0 = *reinterpret_cast<const float4*>(row_val), v1 = *reinterpret_cast<const float4*>(row_val + 4);
-    const float4 v2 = *reinterpret_cast<const float4*>(row_val + 8);
-    const unsigned ix[8] = {(w01.x & 0xffu) << 7, ((w01.x >> 8) & 0xffu) << 7, ((w01.x >> 16) & 0xffu) << 7, (w01.x >> 24) << 7,
-                            (w01.y & 0xffu) << 7, ((w01.y >> 8) & 0xffu) << 7, ((w01.y >> 16) & 0xffu) << 7, (w01.y >> 24) << 7};
-    const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    float4 d[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) d[t] = *reinterpret_cast<const float4*>(bufc + ix[t]);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        acc[0] = fmaf(vv[t], d[t].x, acc[0]); acc[1] = fmaf(vv[t], d[t].y, acc[1]);
-        acc[2] = fmaf(vv[t], d[t].z, acc[2]); acc[3] = fmaf(vv[t], d[t].w, acc[3]);
-    }
-    const float v2a[4] = {v2.x, v2.y, v2.z, v2.w};
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-        if (8 + t < W) {
-            const float4 d0 = *reinterpret_cast<const float4*>(bufc + (((w2 >> (8 * t)) & 0xffu) << 7));
-            acc[0] = fmaf(v2a[t], d0.x, acc[0]); acc[1] = fmaf(v2a[t], d0.y, acc[1]);
-            acc[2] = fmaf(v2a[t], d0.z, acc[2]); acc[3] = fmaf(v2a[t], d0.w, acc[3]);
-        }
-}
-
-// ... and for EIGHT channels per lane (four lanes per 128-byte row): the positions / values of a row are read and decoded once
-// per 8 channels instead of once per 4 - half the index arithmetic and half the stencil reads of the 8-lane form - and a
-// 512-thread pass covers 128 list rows (the whole one-ring of a tile).  bufc = buffer + 32 q (this lane's 32 bytes of a row).
-static __device__ __forceinline__ void gather_ell8w(const unsigned char* __restrict__ row_idx, const float* __restrict__ row_val,
-                                                    const int W, const unsigned char* __restrict__ bufc, float (&acc)[8]) {
-#ifdef DSW_ABL_D3_NOGATHER
-    acc[0] = row_val[0]; return;
-#endif
-    const unsigned w0 = *reinterpret_cast<const unsigned*>(row_idx), w1 = *reinterpret_cast<const unsigned*>(row_idx + 4);
-    const unsigned w2 = *reinterpret_cast<const unsigned*>(row_idx + 8);
-    const float4 v0 = *reinterpret_cast<const float4*>(row_val), v1 = *reinterpret_cast<const float4*>(row_val + 4);
-    const float4 v2 = *reinterpret_cast<const float4*>(row_val + 8);
-    auto four = [&](const unsigned w, const float4 v) __attribute__((always_inline)) {
-        const unsigned ix[4] = {(w & 0xffu) << 7, ((w >> 8) & 0xffu) << 7, ((w >> 16) & 0xffu) << 7, (w >> 24) << 7};
-        const float vv[4] = {v.x, v.y, v.z, v.w};
-        float4 d[4][2];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            d[t][0] = *reinterpret_cast<const float4*>(bufc + ix[t]);
-            d[t][1] = *reinterpret_cast<const float4*>(bufc + ix[t] + 16);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            acc[0] = fmaf(vv[t], d[t][0].x, acc[0]); acc[1] = fmaf(vv[t], d[t][0].y, acc[1]);
-            acc[2] = fmaf(vv[t], d[t][0].z, acc[2]); acc[3] = fmaf(vv[t], d[t][0].w, acc[3]);
-            acc[4] = fmaf(vv[t], d[t][1].x, acc[4]); acc[5] = fmaf(vv[t], d[t][1].y, acc[5]);
-            acc[6] = fmaf(vv[t], d[t][1].z, acc[6]); acc[7] = fmaf(vv[t], d[t][1].w, acc[7]);
-        }
-    };
-    four(w0, v0);
-    four(w1, v1);
-    const float v2a[4] = {v2.x, v2.y, v2.z, v2.w};
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-        if (8 + t < W) {
-            const unsigned off = ((w2 >> (8 * t)) & 0xffu) << 7;
-            const float4 d0 = *reinterpret_cast<const float4*>(bufc + off), d1 = *reinterpret_cast<const float4*>(bufc + off + 16);
-            acc[0] = fmaf(v2a[t], d0.x, acc[0]); acc[1] = fmaf(v2a[t], d0.y, acc[1]);
-            acc[2] = fmaf(v2a[t], d0.z, acc[2]); acc[3] = fmaf(v2a[t], d0.w, acc[3]);
-            acc[4] = fmaf(v2a[t], d1.x, acc[4]); acc[5] = fmaf(v2a[t], d1.y, acc[5]);
-            acc[6] = fmaf(v2a[t], d1.z, acc[6]); acc[7] = fmaf(v2a[t], d1.w, acc[7]);
-        }
-}
-// the three bf16 terms of 8 consecutive channels (16-byte chunk q of 4) of image row `row` -> LDS, one 16-byte write per term
-static __device__ __forceinline__ void split_store8(unsigned char* __restrict__ img, const int row, const unsigned q, const float (&f)[8]) {
-#ifdef DSW_ABL_D3_NOSPLIT
-    if (row >= 0) return;
-#endif
-    bf16x8_t h, m, l;
-    split3x8(f, h, m, l);
-    unsigned char* base = img + (unsigned)row * 64u + ((q ^ (((unsigned)row >> 2) & 2u)) << 4);
-    *reinterpret_cast<bf16x8_t*>(base) = h;
-    *reinterpret_cast<bf16x8_t*>(base + IMG_TERM) = m;
-    *reinterpret_cast<bf16x8_t*>(base + 2 * IMG_TERM) = l;
-}
-
 // 8 consecutive ROWS of one channel column of a row-major image: two transposing reads (rows +0..3 at p, +4..7 at p + 256)
 static __device__ __forceinline__ bf16x8_t read_tr(const unsigned char* p) {
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -551,361 +461,6 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_bwd_dual_kernel(const DualA
     }
 }
 
-// ---- the same backward as ONE 16-wave workgroup per CU with three SPECIALISED wave groups working on different chunk steps ----
-// (a chunk step t = one 32-channel chunk of one sample).  Waves 0-7 are the GATHER waves: they stage the rows of step t, run
-// the two L^T hops and leave the split images of U_0..U_2 (and, once per sample, of the X tile rows) in image set t & 1.
-// Waves 8-11 run the dX products and waves 12-15 the dW products of step t - 1 out of the OTHER image set, at the same time.
-// What the two-workgroup form above cannot have: the matrix waves never run a gather, so the dX waves hold the W fragments of
-// BOTH chunks (72 registers) - the reduction over (k, o) is no longer cut, no partial travels anywhere - and the gather waves
-// hold neither weights nor accumulators; the images are double-buffered (143 KB of LDS), hop 1 -> hop 2 is the only dependency
-// inside a step: TWO workgroup barriers per chunk step instead of four, which the matrix waves pass in the middle of their
-// products.  Every wave executes the same number of barriers; the three roles are three separate loops (separate register
-// allocations: the W fragments are not live in the gather code).
-constexpr int NT16 = 1024;
-#ifdef DSW_D3_TIMELINE
-#define DSW_ST16(r_, cond_, i_) do { if (blockIdx.x == 0 && orig == blockIdx.x && (cond_) && lane == 0 && wave == (r_ == 0 ? 0 : r_ == 1 ? 8 : 12)) \
-        reinterpret_cast<long long*>(P.pscr + (size_t)512 * 8192)[(r_) * 16 + (i_)] = clock64(); } while (0)
-#else
-#define DSW_ST16(r_, cond_, i_) do { } while (0)
-#endif
-
-template <int NST, int NS1>
-__global__ __launch_bounds__(NT16, 4) void cheb3_bwd_dual16_kernel(const DualArgs P) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned char* bufX = lds;                                              // [max_n2][128] dY chunk rows of the 2-ring
-    unsigned char* bufT = bufX + (size_t)P.max_n2 * RB;                     // [max_n1][128] U_1 on the 1-ring
-    unsigned char* simg = bufT + (size_t)P.max_n1 * RB;                     // [2 sets][3 planes]: split images of U_0, U_1, U_2 (tile rows)
-    unsigned char* ximg = simg + 6 * IMG_PLANE;                             // [2 sets]: split image of the X tile rows (per sample)
-    float* ell_val = reinterpret_cast<float*>(ximg + 2 * IMG_PLANE);        // [max_n1][W]
-    unsigned char* ell_idx = reinterpret_cast<unsigned char*>(ell_val + (size_t)P.max_n1 * P.ell_w);     // [max_n1][W] u8
-    int* rows = reinterpret_cast<int*>(ell_idx + (((size_t)P.max_n1 * P.ell_w + 3) & ~(size_t)3));   // [max_n2] global row ids
-    int* tile_w = rows + ((P.max_n2 + 3) & ~3);
-    float* dbs = reinterpret_cast<float*>(tile_w + 4);                      // [64] db of this workgroup (LDS accumulator)
-
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int W = P.ell_w;
-    const size_t y_sample = (size_t)P.V * YB, x_sample = (size_t)P.V * RB;
-    const long n_items = (long)P.n_tiles * P.n_chunks;
-    const long q8 = n_items >> 3, r8 = n_items & 7;
-    if (tid < 64) dbs[tid] = 0.f;                    // (published by the first barrier of the item loop)
-    auto item_of = [&](const long orig, int& tile, int& b_begin, int& b_end) __attribute__((always_inline)) {
-        const long xcd = orig & 7;                   // XCD-aware order (gridDim.x is a multiple of 8)
-        const long wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-        tile = (int)(wg / P.n_chunks);
-        const int chunk = (int)(wg - (long)tile * P.n_chunks);
-        b_begin = chunk * P.spc;
-        b_end = min(P.B, b_begin + P.spc);
-    };
-
-    if (wave < 8) {
-        // =============================== gather waves: staging, hops, split images ===============================
-        const int grp = tid >> 3;                       // row of a 64-row pass
-        const unsigned c4 = (unsigned)(tid & 7);        // 16-byte chunk (4 channels) of this lane inside a staged row
-        const unsigned cb = c4 * 16;
-        for (long orig = blockIdx.x; orig < n_items; orig += gridDim.x) {
-            int tile, b_begin, b_end;
-            item_of(orig, tile, b_begin, b_end);
-            const int* meta = P.tile_meta + (size_t)tile * 6;
-            const int s2_off = meta[0], n1 = meta[1], n2 = meta[2], nnz_off = meta[3], rp_off = meta[4];
-            __syncthreads();   // P0: the previous item is over for everybody
-            int* lrp = reinterpret_cast<int*>(bufT);
-            if (tid == 0) *tile_w = 2;
-            for (int i = tid; i < n2; i += 512) rows[i] = P.s2_rows[s2_off + i];
-            for (int i = tid; i <= n1; i += 512) lrp[i] = P.lrowptr[rp_off + i];
-            __syncthreads();   // P1
-            auto offU = [&](const int k) __attribute__((always_inline)) {
-                return (unsigned)rows[min(grp + k * RPP, n2 - 1)] * (unsigned)YB + cb;
-            };
-            // rows travel TWO chunk steps ahead of their use (a step is too short for an HBM round trip): register set s0 carries
-            // the rows of chunk 0 of the next sample, s1 those of chunk 1
-            u32x4 s0[NST], s1[NST];
-            // hops: FOUR lanes per row, 8 channels per lane (gather_ell8w): thread -> (list row tid >> 2, 32-byte piece tid & 3)
-            const int row4 = tid >> 2;
-            const unsigned q4 = (unsigned)(tid & 3);
-            const unsigned x_off = (unsigned)rows[row4 & 63] * (unsigned)RB + q4 * 32u;    // waves 4-7: X tile row (row4 - 64), its 32 bytes
-            u32x4 xq[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-#pragma unroll
-            for (int k = 0; k < NST; ++k) s0[k] = *reinterpret_cast<const u32x4*>(P.dY + (size_t)b_begin * y_sample + offU(k));
-#pragma unroll
-            for (int k = 0; k < NST; ++k) s1[k] = *reinterpret_cast<const u32x4*>(P.dY + (size_t)b_begin * y_sample + RB + offU(k));
-            if (row4 >= 64) {
-                xq[0] = *reinterpret_cast<const u32x4*>(P.X + (size_t)b_begin * x_sample + x_off);
-                xq[1] = *reinterpret_cast<const u32x4*>(P.X + (size_t)b_begin * x_sample + x_off + 16);
-            }
-            const int tile_nnz = lrp[n1];
-            for (int t = tid; t < n1 * W; t += 512) {
-                const int i = t / W, j = t - i * W;
-                const int p0 = lrp[i], p1 = lrp[i + 1];
-                unsigned col = 0;
-                float val = 0.f;
-                if (tile_nnz > 0) {
-                    const int p = max(0, min(p0 + j, tile_nnz - 1));
-                    col = P.lcol[nnz_off + p];
-                    val = P.lval[nnz_off + p];
-                }
-                if (j == 0 && p1 - p0 > 2) atomicMax(tile_w, p1 - p0);
-                const bool live = p0 + j < p1;
-                ell_idx[t] = (unsigned char)(live ? col : (unsigned)i);
-                ell_val[t] = live ? val : 0.f;
-            }
-            __syncthreads();   // P2: ELL complete (and lrp in bufT dead)
-            const int Wt = *tile_w;
-#pragma unroll
-            for (int k = 0; k < NST; ++k) {
-                const int i = grp + k * RPP;
-                if (i < n2) *reinterpret_cast<u32x4*>(bufX + (size_t)i * RB + cb) = s0[k];
-            }
-            const int S = b_end - b_begin;
-            // one chunk step of the gather waves; `c` is a compile-time constant at both call sites
-            auto step = [&](const int b, const int c, const bool live, u32x4 (&fill)[NST], const u32x4 (&drain)[NST]) __attribute__((always_inline)) {
-                DSW_ST16(0, b == b_begin + 2 && live, c * 8 + 0);
-                __syncthreads();   // A: rows of this step complete; the matrix waves have left image set c (read one step ago)
-                DSW_ST16(0, b == b_begin + 2 && live, c * 8 + 1);
-                unsigned char* img = simg + (size_t)c * (3 * IMG_PLANE);
-                float u0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (live) {
-                    {   // the rows of the same chunk of the NEXT sample: two steps of flight
-                        const int bn = b + 1 < b_end ? b + 1 : b;
-                        const char* src = P.dY + (size_t)bn * y_sample + (c == 0 ? 0 : RB);
-#pragma unroll
-                        for (int k = 0; k < NST; ++k) fill[k] = *reinterpret_cast<const u32x4*>(src + offU(k));
-                    }
-                    // ---- hop 1: U_1 = L^T U_0 on the one-ring, ONE pass (128 list rows x 4 lanes); the tile rows (waves 0-3) also leave
-                    // the split images of U_0 and U_1 and keep their U_0 values for hop 2
-                    if (row4 < n1) {
-                        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        gather_ell8w(ell_idx + (size_t)row4 * W, ell_val + (size_t)row4 * W, Wt, bufX + q4 * 32u, acc);
-                        unsigned char* tp_ = bufT + (size_t)row4 * RB + q4 * 32u;
-                        *reinterpret_cast<float4*>(tp_) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                        *reinterpret_cast<float4*>(tp_ + 16) = make_float4(acc[4], acc[5], acc[6], acc[7]);
-                        if (row4 < 64) {
-                            split_store8(img + IMG_PLANE, row4, q4, acc);
-                            const float4 xa = *reinterpret_cast<const float4*>(bufX + (size_t)row4 * RB + q4 * 32u);
-                            const float4 xb = *reinterpret_cast<const float4*>(bufX + (size_t)row4 * RB + q4 * 32u + 16);
-                            u0[0] = xa.x; u0[1] = xa.y; u0[2] = xa.z; u0[3] = xa.w; u0[4] = xb.x; u0[5] = xb.y; u0[6] = xb.z; u0[7] = xb.w;
-                            split_store8(img, row4, q4, u0);
-                        }
-                    }
-                }
-                DSW_ST16(0, b == b_begin + 2 && live, c * 8 + 2);
-                __syncthreads();   // B: U_1 complete; bufX is dead (the tile-row threads keep their U_0 values)
-                DSW_ST16(0, b == b_begin + 2 && live, c * 8 + 3);
-                if (live) {
-                    if (row4 < 64) {
-                        // ---- hop 2 (waves 0-3): U_2 = 2 L^T U_1 - U_0 on the tile rows -> split image
-                        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        gather_ell8w(ell_idx + (size_t)row4 * W, ell_val + (size_t)row4 * W, Wt, bufT + q4 * 32u, acc);
-                        float t2[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) t2[j] = fmaf(2.f, acc[j], -u0[j]);
-                        split_store8(img + 2 * IMG_PLANE, row4, q4, t2);
-                    } else if (c == 0) {
-                        // ---- waves 4-7, chunk 0: the X tile rows of this sample -> split image
-                        const float xf[8] = {__uint_as_float(xq[0][0]), __uint_as_float(xq[0][1]), __uint_as_float(xq[0][2]), __uint_as_float(xq[0][3]),
-                                             __uint_as_float(xq[1][0]), __uint_as_float(xq[1][1]), __uint_as_float(xq[1][2]), __uint_as_float(xq[1][3])};
-                        split_store8(ximg + (size_t)((b - b_begin) & 1) * IMG_PLANE, row4 - 64, q4, xf);
-                    } else {
-                        const int bn = b + 1 < b_end ? b + 1 : b;
-                        xq[0] = *reinterpret_cast<const u32x4*>(P.X + (size_t)bn * x_sample + x_off);
-                        xq[1] = *reinterpret_cast<const u32x4*>(P.X + (size_t)bn * x_sample + x_off + 16);
-                    }
-                    // the NEXT step's rows -> the (single) input buffer: nobody reads it between barrier B and the next barrier A
-#pragma unroll
-                    for (int k = 0; k < NST; ++k) {
-                        const int i = grp + k * RPP;
-                        if (i < n2) *reinterpret_cast<u32x4*>(bufX + (size_t)i * RB + cb) = drain[k];
-                    }
-                }
-                DSW_ST16(0, b == b_begin + 2 && live, c * 8 + 4);
-            };
-            for (int bi = 0; bi <= S; ++bi) {
-                const int b = b_begin + (bi < S ? bi : S - 1);
-                step(b, 0, bi < S, s0, s1);      // chunk 0: requests chunk 0 of sample b + 1 (s0), hands chunk 1 of sample b (s1) to LDS
-                if (bi == S) break;
-                step(b, 1, true, s1, s0);        // chunk 1: requests chunk 1 of sample b + 1 (s1), hands chunk 0 of sample b + 1 (s0) to LDS
-            }
-        }
-    } else if (wave < 12) {
-        // =============================== dX waves: dX = sum_k U_k W_k^T, both chunks ===============================
-        const int l15 = lane & 15, kc = lane >> 4, jw = wave & 3;
-        const int cbk = jw & 1;                       // 16-channel block of dX; row blocks 2 (jw >> 1), + 1 of the tile
-        bf16x8_t wh[2][3], wm[2][3], wl[2][3];        // A fragments: lane holds W[f = 16 cbk + l15][s][o = 32 c + 8 kc + j]
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                float f[8];
-                const float* src = P.W + ((size_t)(16 * cbk + l15) * 3 + s) * 64 + 32 * c + 8 * kc;
-                const float4 a = *reinterpret_cast<const float4*>(src), b4 = *reinterpret_cast<const float4*>(src + 4);
-                f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b4.x; f[5] = b4.y; f[6] = b4.z; f[7] = b4.w;
-                split3x8(f, wh[c][s], wm[c][s], wl[c][s]);
-            }
-        unsigned fro[2];                              // B fragment (row 16 (rb0 + r) + l15, chunk kc) inside a term of an image
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const unsigned row = 16u * ((jw >> 1) * 2 + r) + l15;
-            fro[r] = row * 64u + (((unsigned)kc ^ ((row >> 2) & 2u)) << 4);
-        }
-        f32x4_t pacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        // the products of one plane of one chunk step out of image set `set`
-        auto plane = [&](const int c, const int s, const int set) __attribute__((always_inline)) {
-            const unsigned char* pb = simg + (size_t)set * (3 * IMG_PLANE) + (size_t)s * IMG_PLANE;
-            bf16x8_t th[2], tm[2], tl[2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                th[r] = *reinterpret_cast<const bf16x8_t*>(pb + fro[r]);
-                tm[r] = *reinterpret_cast<const bf16x8_t*>(pb + IMG_TERM + fro[r]);
-                tl[r] = *reinterpret_cast<const bf16x8_t*>(pb + 2 * IMG_TERM + fro[r]);
-            }
-#pragma unroll
-            for (int r = 0; r < 2; ++r) pacc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[c][s], th[r], pacc[r], 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 2; ++r) pacc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[c][s], tl[r], pacc[r], 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 2; ++r) pacc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[c][s], tm[r], pacc[r], 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 2; ++r) pacc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[c][s], th[r], pacc[r], 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 2; ++r) pacc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[c][s], tm[r], pacc[r], 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 2; ++r) pacc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[c][s], th[r], pacc[r], 0, 0, 0);
-        };
-        for (long orig = blockIdx.x; orig < n_items; orig += gridDim.x) {
-            int tile, b_begin, b_end;
-            item_of(orig, tile, b_begin, b_end);
-            __syncthreads();   // P0
-            __syncthreads();   // P1
-            __syncthreads();   // P2
-            const int S = b_end - b_begin;
-            const unsigned col = (16u * (unsigned)cbk + 4u * (unsigned)kc) * 4u, r0 = 32u * (unsigned)(jw >> 1) + (unsigned)l15;
-            for (int tp = 0; tp <= S; ++tp) {
-                // step t = 2 tp: the images of step t - 1 = chunk 1 of sample tp - 1 (set 1) -> finishes that sample's dX
-                DSW_ST16(1, tp == 3, 0);
-                __syncthreads();   // A
-                DSW_ST16(1, tp == 3, 1);
-                if (tp > 0) { plane(1, 0, 1); plane(1, 1, 1); }
-                DSW_ST16(1, tp == 3, 2);
-                __syncthreads();   // B
-                DSW_ST16(1, tp == 3, 3);
-                if (tp > 0) {
-                    plane(1, 2, 1);
-                    if (P.dX != nullptr) {
-                        char* dst = P.dX + (size_t)(b_begin + tp - 1) * x_sample;      // uniform base + 32-bit lane offsets
-                        st16_nt(dst + ((unsigned)rows[r0] * (unsigned)RB + col), pacc[0]);
-                        st16_nt(dst + ((unsigned)rows[r0 + 16] * (unsigned)RB + col), pacc[1]);
-                    }
-                }
-                DSW_ST16(1, tp == 3, 4);
-                if (tp == S) break;
-                // step t = 2 tp + 1: the images of chunk 0 of sample tp (set 0)
-                __syncthreads();   // A
-                DSW_ST16(1, tp == 3, 5);
-                pacc[0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                pacc[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                plane(0, 0, 0); plane(0, 1, 0);
-                __syncthreads();   // B
-                plane(0, 2, 0);
-            }
-        }
-    } else {
-        // =============================== dW waves: dW_k = X^T U_k (both chunks), db ===============================
-        const unsigned l15 = (unsigned)(lane & 15), kc = (unsigned)(lane >> 4), jw = (unsigned)(wave & 3);
-        const unsigned fb = jw & 1u, ob = jw >> 1;    // 16-channel block of X, 16-channel block of the dY chunk
-        // transposing reads: a 16-lane group kc addresses rows 8 kc + (i >> 2) (+ 4: second read; + 32: second k-step) and the
-        // 8-byte pieces (i & 3) of the 16-channel block; it receives column i = l15 of those rows
-        const unsigned trrow = (8u * kc + (l15 >> 2)) * 64u + ((l15 & 1u) << 3);
-        const unsigned trkey = 2u * (kc & 1u), trhalf = (l15 & 3u) >> 1;
-        const unsigned xoff = trrow + (((2u * fb + trhalf) ^ trkey) << 4);
-        const unsigned uoff = trrow + (((2u * ob + trhalf) ^ trkey) << 4);
-        f32x4_t dwa[2][3];
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int s = 0; s < 3; ++s) dwa[c][s] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        f32x4_t dba = {0.f, 0.f, 0.f, 0.f};
-        // one k-step (32 tile rows) of the products of chunk c out of image set `set`, X image `xs`
-        auto kstep = [&](const int c, const int ks, const int set, const int xs) __attribute__((always_inline)) {
-            const uint4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-            const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_u);
-            const unsigned char* xp = ximg + (size_t)xs * IMG_PLANE + xoff + 2048 * ks;
-            const bf16x8_t xh = read_tr(xp), xm = read_tr(xp + IMG_TERM), xl = read_tr(xp + 2 * IMG_TERM);
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const unsigned char* up = simg + (size_t)set * (3 * IMG_PLANE) + (size_t)s * IMG_PLANE + uoff + 2048 * ks;
-                const bf16x8_t uh = read_tr(up), um = read_tr(up + IMG_TERM), ul = read_tr(up + 2 * IMG_TERM);
-                DSW_MFMA6(dwa[c][s], uh, um, ul, xh, xm, xl);
-                if (s == 0 && fb == 0) {
-                    dba = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ul, ones, dba, 0, 0, 0);
-                    dba = __builtin_amdgcn_mfma_f32_16x16x32_bf16(um, ones, dba, 0, 0, 0);
-                    dba = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uh, ones, dba, 0, 0, 0);
-                }
-            }
-        };
-        auto db_out = [&](const int c) __attribute__((always_inline)) {    // one wave per 16-channel block owns these sums: fixed order
-            if (fb == 0 && l15 == 0) {
-                float* d = dbs + 32 * c + 16 * ob + 4 * kc;
-                const f32x4_t o = *reinterpret_cast<const f32x4_t*>(d);
-                *reinterpret_cast<f32x4_t*>(d) = o + dba;
-            }
-            dba = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        };
-        for (long orig = blockIdx.x; orig < n_items; orig += gridDim.x) {
-            int tile, b_begin, b_end;
-            item_of(orig, tile, b_begin, b_end);
-            __syncthreads();   // P0
-            __syncthreads();   // P1
-            __syncthreads();   // P2
-            const int S = b_end - b_begin;
-            for (int tp = 0; tp <= S; ++tp) {
-                DSW_ST16(2, tp == 3, 0);
-                __syncthreads();   // A (step 2 tp): chunk 1 of sample tp - 1 in set 1, its X image in set (tp - 1) & 1
-                DSW_ST16(2, tp == 3, 1);
-                if (tp > 0) kstep(1, 0, 1, (tp - 1) & 1);
-                DSW_ST16(2, tp == 3, 2);
-                __syncthreads();   // B
-                DSW_ST16(2, tp == 3, 3);
-                if (tp > 0) { kstep(1, 1, 1, (tp - 1) & 1); db_out(1); }
-                DSW_ST16(2, tp == 3, 4);
-                if (tp == S) break;
-                __syncthreads();   // A (step 2 tp + 1): chunk 0 of sample tp in set 0
-                DSW_ST16(2, tp == 3, 5);
-                kstep(0, 0, 0, tp & 1);
-                __syncthreads();   // B
-                kstep(0, 1, 0, tp & 1);
-                db_out(0);
-            }
-        }
-        if (P.partial != nullptr) {
-            float* slab = P.partial + (size_t)blockIdx.x * SLAB;
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int s = 0; s < 3; ++s)
-                    *reinterpret_cast<f32x4_t*>(slab + (size_t)(s * 32 + 16 * fb + l15) * 64 + 32 * c + 16 * ob + 4 * kc) = dwa[c][s];
-        }
-    }
-    // ---- the db row of the workgroup's slab
-    __syncthreads();
-    if (P.partial != nullptr && tid < 64) P.partial[(size_t)blockIdx.x * SLAB + (size_t)96 * 64 + tid] = dbs[tid];
-}
-
-size_t dual16_lds_bytes(const dsw_hop2_plan* plan) {
-    const int ell_w = (plan->reserved + 3) & ~3;
-    size_t s = (size_t)(plan->max_n2 + (size_t)plan->max_n1) * RB + 8 * IMG_PLANE;
-    s += (size_t)plan->max_n1 * ell_w * 4 + (((size_t)plan->max_n1 * ell_w + 3) & ~(size_t)3);   // fp32 values + u8 positions
-    s += (size_t)((plan->max_n2 + 3) & ~3) * 4 + 16 + 64 * 4;
-    return (s + 15) & ~(size_t)15;
-}
-
-template <int NST, int NS1>
-int launch_dual16(const DualArgs& A, long nwg, size_t lds, hipStream_t stream) {
-    if (hipFuncSetAttribute((const void*)cheb3_bwd_dual16_kernel<NST, NS1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return DSW_ERR_LAUNCH;
-    DSW_LAUNCH((cheb3_bwd_dual16_kernel<NST, NS1>), dim3((unsigned)nwg), dim3(NT16), lds, stream, A);
-    return dsw_check_launch();
-}
-
 size_t dual_lds_bytes(const dsw_hop2_plan* plan) {
     const int ell_w = (plan->reserved + 3) & ~3;
     const int bufx_rows = plan->max_n2 > 96 ? plan->max_n2 : 96;           // the U_2 image (12 KB) lives there after hop 1
@@ -930,17 +485,6 @@ long dual_grid(long n_items) {
     g -= g % 8;
     if (g < 8) g = 8;
     return n_items < g ? n_items : g;
-}
-
-// the specialised 16-wave form where its double-buffered images fit the CU's LDS
-bool dual16_wanted(const dsw_hop2_plan* plan) {
-#ifdef DSW_DUAL16_OFF
-    return false;
-#endif
-    static const char* env = dsw_diag_env("DSW_BWD_DUAL16");   // "1": the 16-wave form (diagnostics builds only: measured equal, not taken)
-    if (!env || env[0] != '1') return false;
-    if (((plan->reserved + 3) & ~3) > 12 || plan->max_n1 > 128) return false;   // at most 12 entries per row; hop 1 is ONE pass of 128 list rows
-    return dual16_lds_bytes(plan) <= 160 * 1024;
 }
 
 }  // namespace
@@ -991,44 +535,16 @@ int dsw_cheb3_bwd_dual_try(const dsw_hop2_plan* plan_t, int64_t V, const void* X
             if (best < 0 || cost < best - 1e-9) { best = cost; chunks = c; }
         }
     }
+    A.spc = (int)((B + chunks - 1) / chunks);
+    A.n_chunks = (int)((B + A.spc - 1) / A.spc);
+    const long nwg = dual_grid((long)plan_t->n_tiles * A.n_chunks);
+    const size_t lds = dual_lds_bytes(plan_t);
     const int nst = (plan_t->max_n2 + RPP - 1) / RPP, ns1 = (plan_t->max_n1 + RPP - 1) / RPP;
     int r;
-    long nwg;
-    if (dual16_wanted(plan_t)) {
-        // one 16-wave workgroup per CU (specialised wave groups): items = tiles x chunks over the CUs; a chunk of S samples
-        // costs 2 S + 1 chunk steps + the tile prologue (~2 steps)
-        long g16 = dsw_device_cus();
-        g16 -= g16 % 8;
-        if (g16 < 8) g16 = 8;
-        long chunks16 = 1;
-        double best = -1.0;
-        const long cmax = B > 1 ? (B + 1) / 2 : 1;
-        for (long c = 1; c <= cmax && c <= 16; ++c) {
-            const long items = (long)plan_t->n_tiles * c;
-            const long g = items < g16 ? items : g16;
-            const long rounds = (items + g - 1) / g;
-            const double cost = (double)rounds * (3.0 + 2.0 * (double)((B + c - 1) / c));
-            if (best < 0 || cost < best - 1e-9) { best = cost; chunks16 = c; }
-        }
-        A.spc = (int)((B + chunks16 - 1) / chunks16);
-        A.n_chunks = (int)((B + A.spc - 1) / A.spc);
-        const long items = (long)plan_t->n_tiles * A.n_chunks;
-        nwg = items < g16 ? items : g16;
-        const size_t lds = dual16_lds_bytes(plan_t);
-        if (nst == 3 && ns1 == 2) r = launch_dual16<3, 2>(A, nwg, lds, stream);
-        else if (nst == 2 && ns1 <= 2) r = launch_dual16<2, 2>(A, nwg, lds, stream);
-        else if (nst == 3) r = launch_dual16<3, 3>(A, nwg, lds, stream);
-        else r = launch_dual16<4, 4>(A, nwg, lds, stream);
-    } else {
-        A.spc = (int)((B + chunks - 1) / chunks);
-        A.n_chunks = (int)((B + A.spc - 1) / A.spc);
-        nwg = dual_grid((long)plan_t->n_tiles * A.n_chunks);
-        const size_t lds = dual_lds_bytes(plan_t);
-        if (nst == 3 && ns1 == 2) r = launch_dual<3, 2>(A, nwg, lds, stream);
-        else if (nst == 2 && ns1 <= 2) r = launch_dual<2, 2>(A, nwg, lds, stream);
-        else if (nst == 3) r = launch_dual<3, 3>(A, nwg, lds, stream);
-        else r = launch_dual<4, 4>(A, nwg, lds, stream);
-    }
+    if (nst == 3 && ns1 == 2) r = launch_dual<3, 2>(A, nwg, lds, stream);
+    else if (nst == 2 && ns1 <= 2) r = launch_dual<2, 2>(A, nwg, lds, stream);
+    else if (nst == 3) r = launch_dual<3, 3>(A, nwg, lds, stream);
+    else r = launch_dual<4, 4>(A, nwg, lds, stream);
     if (r == DSW_OK && dW != nullptr)
         r = dsw_wgrad_reduce_launch(partial, nwg, Fin, Fout, K, dW, db, K, 0, 1 << 30, dtype, stream, accumulate);
     *rc = r;

@@ -99,14 +99,6 @@ if "--timeline" in sys.argv:    # -DDSW_D3_TIMELINE build: cycle stamps of waves
     base = (-ws.data_ptr()) % 256
     off = base + (2 * cus + 8) * (97 * 64) * 4 + 512 * 8192
     st = ws[off:off + 64 * 8].view(torch.int64).cpu().tolist()
-    if "--t16" in sys.argv:      # the 16-wave form: gather wave 0 (both chunks of sample 2), dX wave 8, dW wave 12 around step 6
-        st = ws[off:off + 48 * 8].view(torch.int64).cpu().tolist()
-        t0 = st[0]
-        print("gather c0: ->A 0 | A %d | hop1 end %d | B %d | hop2+stage end %d" % tuple(v - t0 for v in st[1:5]))
-        print("gather c1: ->A %d | A %d | hop1 end %d | B %d | hop2+stage end %d" % tuple(v - t0 for v in st[8:13]))
-        print("dX: ->A %d | A %d | part1 end %d | B %d | part2 end %d | next A %d" % tuple(v - t0 for v in st[16:22]))
-        print("dW: ->A %d | A %d | part1 end %d | B %d | part2 end %d | next A %d" % tuple(v - t0 for v in st[32:38]))
-        sys.exit(0)
     names = ["->A", "A", "ph1 end", "B", "ph2 end", "C", "mfma end", "D"]
     for wv in (0, 1):
         t = st[wv * 32:(wv + 1) * 32]
