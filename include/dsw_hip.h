@@ -327,6 +327,8 @@ int64_t dsw_cheb_bwd_workspace_bytes(int64_t B, int64_t V, int64_t Fin, int64_t 
  *     dW[f,k,o] = sum_n T_k[n,f] dY[n,o];  db[o] = sum_n dY[n,o];
  *     G_k = dY W[:,k,:]^T;  for j=K-1..1: G_{j-1} += (j>1 ? 2 : 1) L^T G_j - G_{j+1};  dX = G_0
  * rowptr_t/colind_t/vals_t describe the CSR of L^T (for a symmetric L pass L itself).
+ * T may be NULL where dsw_cheb_bwd_needs_basis() == 0 (mix-first layers; the one-launch dual form, which is taken whenever the
+ * shape and plan_t allow it - with or without T - and for which plan_t is then REQUIRED).
  * dX / dW / db may be NULL to skip them (db is only produced together with dW).
  * plan_t: optional two-hop plan of L^T (NULL = one launch per adjoint step).
  * B * V == 0 (an empty batch shard) writes dW = 0 and db = 0. */
