@@ -260,7 +260,12 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
         {   // next sample's input rows: in flight under phases 1 and 2
             const size_t sb = (size_t)(b + 1 < b_end ? b + 1 : b) * sample_bytes;
 #pragma unroll
-            for (int k = 0; k < NST; ++k) su[k] = *reinterpret_cast<const u32x4*>(P.X + sb + offU(k));
+            for (int k = 0; k < NST; ++k)
+#ifdef DSW_ABL_F3_NOLOAD
+                su[k] = u32x4{(unsigned)sb, offU(k), 0u, 0u};
+#else
+                su[k] = *reinterpret_cast<const u32x4*>(P.X + sb + offU(k));
+#endif
         }
         // ---- phase 1: T1 = L X on S1; the tile rows (slot 0) also leave their split images of X and T1
 #pragma unroll

@@ -105,6 +105,10 @@ if "--timeline" in sys.argv:    # -DDSW_D3_TIMELINE build: cycle stamps of waves
         t0 = t[0]
         print("wave %d:" % (4 * wv), " | ".join("c%d %s %d" % (i // 16, names[i % 16], t[i] - t0) for i in list(range(8)) + list(range(16, 24))))
     sys.exit(0)
+if "--fwd-only" in sys.argv:
+    print("%s: forward with basis stores %.1f us | without %.1f us" % (os.environ.get("DSW_HIP_LIB", "product").split("/")[-1],
+                                                                        graphed_us(lambda: fwd(True)), graphed_us(lambda: fwd(False))), flush=True)
+    sys.exit(0)
 if "--time-only" in sys.argv:
     o1 = outs()
     fwd()
