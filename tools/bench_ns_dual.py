@@ -112,7 +112,9 @@ if "--fwd-only" in sys.argv:
 if "--time-only" in sys.argv:
     o1 = outs()
     fwd()
-    print("%s: dual backward %.1f us" % (os.environ.get("DSW_HIP_LIB", "product").split("/")[-1], graphed_us_later(lambda: bwd(pt, o1, basis=False))), flush=True)
+    nb_ = int(lib.dsw_cheb_bwd_needs_basis(pt, V, fin, fout, K, 0)) != 0     # (a diagnostics build with DSW_BWD_DUAL=0: the route on the basis planes)
+    print("%s: %s backward %.1f us" % (os.environ.get("DSW_HIP_LIB", "product").split("/")[-1], "basis-route" if nb_ else "dual",
+                                        graphed_us_later(lambda: bwd(pt, o1, basis=nb_))), flush=True)
     sys.exit(0)
 fwd()
 ref, new = outs(), outs()
