@@ -22,7 +22,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{root}/gpurun_out/pmc_{tag}_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         import re
-        m = re.search(r"(ts_gemm_x3s?_kernel<[^>]*>|ts_gemm_kernel<[^>]*>|cheb_wgrad\w*_kernel<[^>]*>|spmm_csr_rowsplit<[^>]*>|remap_\w+_kernel<[^>]*>|cheb3_bwd_fused_kernel|spmm2_fused_kernel<[^>]*>|spmm1_dma_kernel<[^>]*>|spmm1_staged_kernel<[^>]*>|cheb3_fwd_fused_kernel<[^>]*>|cheb_wgrad_reduce)", r["Kernel_Name"])
+        m = re.search(r"(ts_gemm_x3s?_kernel<[^>]*>|ts_gemm_kernel<[^>]*>|cheb_wgrad\w*_kernel<[^>]*>|spmm_csr_rowsplit<[^>]*>|remap_\w+_kernel<[^>]*>|cheb3_bwd_fused_kernel|cheb3_bwd_dual_kernel<[^>]*>|cheb3_hop2mix_kernel<[^>]*>|spmm2_fused_kernel<[^>]*>|spmm1_dma_kernel<[^>]*>|spmm1_staged_kernel<[^>]*>|cheb3_fwd_fused_kernel<[^>]*>|cheb_wgrad_reduce)", r["Kernel_Name"])
         if not m:
             continue
         name = m.group(1)
