@@ -71,6 +71,8 @@ struct Fwd3Args {
     int Fout;
     int relu;            // ReLU after the bias (ConvBlock)
     int explicit_tiles;  // the plan's tiles are explicit row sets (see dsw_hop2_plan)
+    const unsigned char* ell2;   // per-tile ELL image in the LDS layout (dsw_hop2_plan::ell2) or null
+    long ell2_stride;
 };
 
 static __device__ __forceinline__ float trunc_bf16(float f) { return __uint_as_float(__float_as_uint(f) & 0xffff0000u); }
@@ -191,9 +193,19 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
     const size_t sample_bytes = (size_t)P.V * RB;
 
     int* lrp = reinterpret_cast<int*>(bufT);
-    if (tid == 0) *tile_w = 2;
+    constexpr bool image = FULL;                    // FULL launches carry the tile's ELL as an LDS image of the plan: ONE round of loads, one barrier
+    if (tid == 0) *tile_w = image ? meta[5] : 2;
     for (int i = tid; i < n2; i += NTHREADS) rows[i] = P.s2_rows[s2_off + i];
-    for (int i = tid; i <= n1; i += NTHREADS) lrp[i] = P.lrowptr[rp_off + i];
+    if constexpr (image) {
+        const unsigned char* src = P.ell2 + (size_t)tile * (size_t)P.ell2_stride;
+        unsigned char* dst = reinterpret_cast<unsigned char*>(ell_val);          // values, then the u8 positions: contiguous in LDS
+        const int nbytes = P.max_n1 * W * 5;
+        for (int i = tid; i < (nbytes >> 4); i += NTHREADS)
+            *reinterpret_cast<uint4*>(dst + 16 * i) = *reinterpret_cast<const uint4*>(src + 16 * i);
+        for (int i = (nbytes & ~15) + tid; i < nbytes; i += NTHREADS) dst[i] = src[i];
+    } else {
+        for (int i = tid; i <= n1; i += NTHREADS) lrp[i] = P.lrowptr[rp_off + i];
+    }
     __syncthreads();
 
     const int grp = tid >> 3;                       // row of a 64-row pass
@@ -212,21 +224,23 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
 #pragma unroll
         for (int k = 0; k < NST; ++k) su[k] = *reinterpret_cast<const u32x4*>(P.X + sb + offU(k));
     }
-    const int tile_nnz = lrp[n1];
-    for (int t = tid; t < n1 * W; t += NTHREADS) {
-        const int i = t / W, j = t - i * W;
-        const int p0 = lrp[i], p1 = lrp[i + 1];
-        unsigned col = 0;
-        float val = 0.f;
-        if (tile_nnz > 0) {
-            const int p = max(0, min(p0 + j, tile_nnz - 1));
-            col = P.lcol[nnz_off + p];
-            val = P.lval[nnz_off + p];
+    if constexpr (!image) {
+        const int tile_nnz = lrp[n1];
+        for (int t = tid; t < n1 * W; t += NTHREADS) {
+            const int i = t / W, j = t - i * W;
+            const int p0 = lrp[i], p1 = lrp[i + 1];
+            unsigned col = 0;
+            float val = 0.f;
+            if (tile_nnz > 0) {
+                const int p = max(0, min(p0 + j, tile_nnz - 1));
+                col = P.lcol[nnz_off + p];
+                val = P.lval[nnz_off + p];
+            }
+            if (j == 0 && p1 - p0 > 2) atomicMax(tile_w, p1 - p0);
+            const bool live = p0 + j < p1;
+            ell_idx[t] = (unsigned char)(live ? col : (unsigned)i);
+            ell_val[t] = live ? val : 0.f;
         }
-        if (j == 0 && p1 - p0 > 2) atomicMax(tile_w, p1 - p0);
-        const bool live = p0 + j < p1;
-        ell_idx[t] = (unsigned char)(live ? col : (unsigned)i);
-        ell_val[t] = live ? val : 0.f;
     }
 
     // ---- W fragments of this wave's column block, split once: lane l holds W[f = 8 (l >> 4) + j][plane][n = 16 cbk + (l & 15)]
@@ -245,7 +259,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
     f32x4_t bias4 = {0.f, 0.f, 0.f, 0.f};
     if (P.bias != nullptr) bias4 = *reinterpret_cast<const f32x4_t*>(P.bias + 16 * cbk + 4 * kc);
 
-    __syncthreads();   // ELL complete (and lrp in bufT dead)
+    if constexpr (!image) __syncthreads();   // ELL complete (and lrp in bufT dead); with the image it was complete at the first barrier
     const int Wt = *tile_w;                           // gather loop length of this tile: its longest row (may be odd)
     // the first sample's rows (the loop writes the NEXT sample's rows after its barrier C)
 #pragma unroll
@@ -639,6 +653,7 @@ int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X,
     A.V = (int)V; A.n_tiles = plan->n_tiles; A.max_n1 = plan->max_n1; A.max_n2 = plan->max_n2;
     A.B = (int)B; A.ell_w = (plan->reserved + 3) & ~3; A.Fout = (int)Fout; A.relu = relu;
     A.explicit_tiles = plan->explicit_tiles;
+    A.ell2 = plan->explicit_tiles ? nullptr : plan->ell2; A.ell2_stride = (long)plan->ell2_stride;
 
     // batch chunks: same cost model as the two-hop kernel (rounds x (staging + samples per chunk))
     const long slots = 256L * ((160 * 1024) / (long)lds > 0 ? (160 * 1024) / (long)lds : 1);
@@ -657,7 +672,7 @@ int dsw_cheb3_fwd_fused_try(const dsw_hop2_plan* plan, int64_t V, const void* X,
     const long nwg = (long)plan->n_tiles * A.n_chunks;
     if (nwg > 2147483647L) return 0;
     int r;
-    const bool full = (V % 64 == 0) && !plan->explicit_tiles;
+    const bool full = (V % 64 == 0) && !plan->explicit_tiles && plan->ell2 != nullptr;
     const bool keep = T != nullptr;
 #define DSW_F3_PICK(A_, B_)                                                                           \
     r = !full ? launch_ncb<A_, B_, false>(A, nwg, lds, stream)                                        \
@@ -713,6 +728,7 @@ int dsw_cheb3_hop2mix_try(const dsw_hop2_plan* plan, int64_t V, const void* X, c
     A.V = (int)V; A.n_tiles = plan->n_tiles; A.max_n1 = plan->max_n1; A.max_n2 = plan->max_n2;
     A.B = (int)B; A.ell_w = (plan->reserved + 3) & ~3; A.Fout = (int)Fout; A.relu = relu;
     A.explicit_tiles = plan->explicit_tiles;
+    A.ell2 = nullptr; A.ell2_stride = 0;
     const long slots = 256L * ((160 * 1024) / (long)lds > 1 ? 2 : 1);
     long chunks = 1;
     {

@@ -46,6 +46,8 @@ class Hop2PlanStruct(ctypes.Structure):
         ("ell_w", ctypes.c_int32),            # > 0: the tile rows' stencils also as padded ELL (64 rows x ell_w per tile)
         ("ell_pos", ctypes.c_void_p),         # uint16 [n_tiles][64][ell_w]: list positions (padding: the row itself)
         ("ell_val", ctypes.c_void_p),         # float32 [n_tiles][64][ell_w] (padding: 0)
+        ("ell2", ctypes.c_void_p),            # two-hop plans: per tile [max_n1][W] fp32 values + [max_n1][W] u8 positions (LDS image)
+        ("ell2_stride", ctypes.c_int64),      # bytes between the images of consecutive tiles
     ]
 
 
@@ -55,6 +57,8 @@ class Hop2Plan:
         self.hops = int(hops)
         self.ell_w = 0
         self.ell_pos = self.ell_val = None
+        self.ell2 = None
+        self.ell2_stride = 0
         self.max_row_len = int(max_row_len)
         self.explicit_tiles = bool(explicit_tiles)
         self.tile_rows = int(tile_rows)
@@ -112,6 +116,35 @@ class Hop2Plan:
         self.tile_meta, self.ell_pos, self.ell_val, self.ell_w = meta, pos.reshape(-1), val.reshape(-1), W
         return self
 
+    def add_ell2(self):
+        """Two-hop plans on consecutive tiles: the ELL image of every tile exactly as the one-launch kernels (csrc/dsw_fwd3.hip,
+        csrc/dsw_bwd3d.hip) hold it in LDS - [max_n1][W] fp32 values, then [max_n1][W] u8 list positions, padding {own row, 0} -
+        so that their prologue copies it in one round of loads; tile_meta[t][5] becomes the tile's longest row (at least 2,
+        as the kernels' own expansion computes it)."""
+        if self.hops == 1 or self.explicit_tiles or self.max_n2 > 255 or self.max_row_len <= 0:
+            return self
+        W = (self.max_row_len + 3) & ~3
+        vbytes = self.max_n1 * W * 4
+        stride = (vbytes + self.max_n1 * W + 15) & ~15
+        img = np.zeros((self.n_tiles, stride), dtype=np.uint8)
+        meta = self.tile_meta.copy()
+        for t in range(self.n_tiles):
+            s2_off, n1, n2, nnz_off, rp_off, _ = (int(v) for v in self.tile_meta[t])
+            lrp = self.lrowptr[rp_off:rp_off + n1 + 1].astype(np.int64)
+            lens = np.diff(lrp)
+            val = np.zeros((self.max_n1, W), dtype=np.float32)
+            pos = np.zeros((self.max_n1, W), dtype=np.uint8)
+            pos[:] = np.arange(self.max_n1, dtype=np.int64)[:, None].astype(np.uint8)      # padding: the row itself, weight 0
+            rid = np.repeat(np.arange(n1), lens)
+            col = np.arange(int(lrp[-1])) - np.repeat(lrp[:-1], lens)
+            pos[rid, col] = self.lcol[nnz_off:nnz_off + lrp[-1]].astype(np.uint8)
+            val[rid, col] = self.lval[nnz_off:nnz_off + lrp[-1]]
+            img[t, :vbytes] = val.reshape(-1).view(np.uint8)
+            img[t, vbytes:vbytes + self.max_n1 * W] = pos.reshape(-1)
+            meta[t, 5] = max(2, int(lens.max()) if lens.size else 0)
+        self.tile_meta, self.ell2, self.ell2_stride = meta, img.reshape(-1), int(stride)
+        return self
+
     def gather_passes_per_row(self, slots: int = 64) -> float:
         """Passes of ``slots`` row slots the kernel spends per output row (first hop on tile + 1-ring, second hop on the
         tile) - the cost figure tile heights are compared by."""
@@ -127,7 +160,8 @@ class Hop2Plan:
         if self._dev is not None and self._dev[0] == device:
             return self
         arrs = {}
-        for name in ("tile_meta", "s2_rows", "lrowptr", "lcol", "lval") + (("ell_pos", "ell_val") if self.ell_w else ()):
+        for name in ("tile_meta", "s2_rows", "lrowptr", "lcol", "lval") + (("ell_pos", "ell_val") if self.ell_w else ()) + \
+                (("ell2",) if self.ell2 is not None else ()):
             a = getattr(self, name)
             t = torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a)
             arrs[name] = t.to(device)
@@ -136,6 +170,7 @@ class Hop2Plan:
             arrs["tile_meta"].data_ptr(), arrs["s2_rows"].data_ptr(), arrs["lrowptr"].data_ptr(),
             arrs["lcol"].data_ptr(), arrs["lval"].data_ptr(), 1 if self.explicit_tiles else 0, self.hops,
             self.ell_w, arrs["ell_pos"].data_ptr() if self.ell_w else None, arrs["ell_val"].data_ptr() if self.ell_w else None,
+            arrs["ell2"].data_ptr() if self.ell2 is not None else None, self.ell2_stride,
         )
         self._dev = (device, arrs)   # keeps the device tensors alive
         self._struct = st
@@ -301,7 +336,7 @@ def build_hop2_plan(rowptr: np.ndarray, colind: np.ndarray, values: np.ndarray, 
     return Hop2Plan(
         tile_rows, meta, np.concatenate(s2_chunks), np.concatenate(rp_chunks), np.concatenate(col_chunks),
         np.concatenate(val_chunks), max_n1, max_n2, max_nnz, n, max_len, explicit_tiles=explicit, hops=hops,
-    ).add_ell()
+    ).add_ell().add_ell2()
 
 
 def _bank_friendly_order(lcol: np.ndarray, lens: np.ndarray) -> np.ndarray:

@@ -65,6 +65,13 @@ typedef struct dsw_hop2_plan {
                                   tile's longest row */
     const uint16_t* ell_pos;   /* [n_tiles][64][ell_w] list positions (padding: the row's own position) */
     const float* ell_val;      /* [n_tiles][64][ell_w] values (padding: 0) */
+    /* hops == 2 (or 0), consecutive tiles (explicit_tiles == 0): the stencils of a tile's rows and one-ring as the padded ELL
+     * image the one-launch kernels (dsw_fwd3.hip, dsw_bwd3d.hip) keep in LDS, so that a workgroup's prologue is ONE round of
+     * loads instead of row pointers -> columns / values -> expansion: per tile max_n1 rows x W entries, W = (reserved + 3) & ~3,
+     * values first, then the u8 list positions (padding: {own row, 0}), ell2_stride bytes apart; tile_meta[t][5] = the tile's
+     * longest row.  NULL: the kernels expand the local CSR themselves. */
+    const unsigned char* ell2;
+    int64_t ell2_stride;
 } dsw_hop2_plan;
 
 /* Library version (major*10000 + minor*100 + patch). */
