@@ -52,7 +52,7 @@ static inline const char* dsw_diag_env(const char*) { return nullptr; }
 #define DSW_TU_F_DIAG 0
 #endif
 #if defined(DSW_ABLATION) || defined(DSW_ABL_NODMA) || defined(DSW_ABL_NOGATHER) || defined(DSW_ABL_F3_NOGATHER) || \
-    defined(DSW_ABL_F3_NOSPLIT) || defined(DSW_ABL_F3_NOLOAD) || defined(DSW_ABL_F3_NOSTORE) || defined(DSW_ABL_F3_NOMFMA) || defined(DSW_ABL_B3_NOSPLIT) || \
+    defined(DSW_ABL_F3_NOSPLIT) || defined(DSW_F3_PLAIN_STORE) || defined(DSW_ABL_F3_NOLOAD) || defined(DSW_ABL_F3_NOSTORE) || defined(DSW_ABL_F3_NOMFMA) || defined(DSW_ABL_B3_NOSPLIT) || \
     defined(DSW_ABL_B3_NOGATHER) || defined(DSW_ABL_B3_NOMFMA) || defined(DSW_STAGE_EARLY) || defined(DSW_ABL_B3_NOLOAD) || defined(DSW_ABL_B3_NOFRAG)
 #define DSW_TU_F_ABL DSW_FLAG_ABLATION
 #else

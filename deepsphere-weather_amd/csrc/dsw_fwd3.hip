@@ -42,7 +42,11 @@ static __device__ __forceinline__ void st16(char* p, const T4& v) {
     if (p != nullptr) return;      // (never null here: keeps the operands alive)
 #endif
     typedef unsigned u32x4_nt __attribute__((ext_vector_type(4)));
+#ifdef DSW_F3_PLAIN_STORE      // A/B builds: cached stores (partial lines of a row meet in L2)
+    *reinterpret_cast<u32x4_nt*>(p) = __builtin_bit_cast(u32x4_nt, v);
+#else
     __builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, v), reinterpret_cast<u32x4_nt*>(p));
+#endif
 }
 
 
