@@ -616,6 +616,9 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
     if t_dual is not None:   # the fused launch moves far fewer bytes than the 8(d) count of what it replaces: say both
         out["compulsory_bytes"] = int(E + yb_bytes + E)
         out["frac_compulsory"] = round((E + yb_bytes + E) / (t_dual["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        out["limited_by"] = ("on-chip work, not HBM: `frac` prices the launch by the SURVEY 8(d) bytes of the launches it replaces; it "
+                             "moves `traffic` bytes (`frac_counter`), `compulsory_bytes` at the least (`frac_compulsory`) - LDS gathers, "
+                             "operand splits and 576 MFMAs per tile and sample bound it (DESIGN.md section 3: ablation, counters)")
     if ms_per_step is not None and in_step:
         out["in_step_sum_vs_ms_per_step"] = round(step_sum_us / (ms_per_step * 1e3), 4)
     return out
