@@ -78,6 +78,10 @@ def parse():
     ap.add_argument("--kernel-trace-child", type=int, default=0,
                     help="internal (graph_kernel_durations): build, capture, warm up, replay this many steps and exit - the "
                          "process rocprofv3 traces to time the kernels inside the replayed graph")
+    ap.add_argument("--detail", default="file", choices=["file", "inline", "none"],
+                    help="where the long form of the roofline measurement goes (every role of the step, pooling products, stand-alone "
+                         "legs): a side file (gpurun_out/bench_detail_<workload>.json, or --detail-file), the line itself, or nowhere")
+    ap.add_argument("--detail-file", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--zero-inputs", action="store_true",
@@ -241,13 +245,15 @@ def trace_steps(step_fn, n_steps, warm=5, capacity=1 << 15):
         for (c, key, _b), rec in zip(seq, chunk):
             calls.setdefault((c, key), []).append(rec)
         for (c, key), recs in calls.items():
-            e = agg.setdefault(key, {"us": [], "nk": len(recs), "name": max(recs, key=lambda r: r[5])[6]})
+            e = agg.setdefault(key, {"us": [], "lus": [], "nk": len(recs), "name": max(recs, key=lambda r: r[5])[6]})
             e["us"].append(sum(r[5] for r in recs))
+            e["lus"].append(max(r[5] for r in recs))
     out = {}
     for k, e in agg.items():
         v = sorted(e["us"])
         out[k] = {"calls_per_step": len(v) / n_steps, "avg_us": sum(v) / len(v), "median_us": v[len(v) // 2],
                   "us_per_step": sum(v) / n_steps, "kernels": e["nk"], "longest_kernel": e["name"],
+                  "longest_us": sum(e["lus"]) / len(e["lus"]),
                   "timing": "EAGER launches (dsw_trace): ~10 % above the replayed graph's kernels"}
     return out, seq0
 
@@ -315,10 +321,12 @@ def graph_kernel_durations(seq, n_steps=40, timeout=150):
             calls.setdefault((c, key), []).append(pos_us[j])
         roles = {}
         for (c, key), durs in calls.items():
-            e = roles.setdefault(key, {"sum": 0.0, "n": 0, "nk": len(durs)})
+            e = roles.setdefault(key, {"sum": 0.0, "lsum": 0.0, "n": 0, "nk": len(durs)})
             e["sum"] += sum(durs)
+            e["lsum"] += max(durs)
             e["n"] += 1
         out = {k: {"calls_per_step": float(e["n"]), "avg_us": e["sum"] / e["n"], "us_per_step": e["sum"], "kernels": e["nk"],
+                   "longest_us": e["lsum"] / e["n"],
                    "timing": "in-graph kernel durations (rocprofv3 kernel trace of the replayed step graph, %d steps)" % n_steps}
                for k, e in roles.items()}
         # everything the graph ran in those steps (torch kernels included), and the wall time they spanned
@@ -450,7 +458,7 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
     t_gemm = tr("bwd_gemm_fused", V, C, Fout)
     t_dgrad, t_wgrad = tr("bwd_dgrad", V, C, Fout), tr("bwd_wgrad", V, C, Fout)
     t_adj = tr("basis_adj", V, C, K)
-    t_bwdf = tr("bwd_fused", V, C, Fout)
+    t_bwdf = None                                      # (the mix-first one-launch dX was retired in round 6)
     t_dual = tr("bwd_dual", V, C, Fout)                # whole backward in one launch in the dual form (dsw_bwd3d.hip)
     have_trace = t_adj is not None or t_bwdf is not None or t_dual is not None or mf
 
@@ -467,161 +475,168 @@ def roofline_leg(layer, x, steps, warmup, traffic_key=None, pmc_leg=None, traced
     out_mfma = mfma_leg(layer, x, T, steps, in_step=t_mix)
 
     yb_bytes = N * Fout * es
-    wf_bytes = fwd_b + (K * E + yb_bytes)
-    # (a backward in the dual form needs no basis planes: the forward then stores Y only)
-    compulsory_fwd = int(E + yb_bytes) if t_dual is not None else int(E + (K - 1) * E + yb_bytes)
+    mm_peak = MFMA_PEAK_TFLOPS["bf16" if x.dtype == torch.bfloat16 else "f32"]
+    mix_flops = 2.0 * N * C * K * Fout          # one contraction over (k, f): forward mix, dgrad or wgrad
+    hop1_b = spmm_algorithmic_bytes(E, Lb, 2)[0]
 
-    def entry(role, kernels, sec, nbytes, calls, extra=None):
-        d = {"role": role, "kernels": kernels, "avg_us": round(sec * 1e6, 2), "calls_per_step": calls,
-             "algorithmic_bytes": int(nbytes), "achieved_GBs": round(nbytes / sec / 1e9, 1),
-             "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4), "timing": IN}
-        d.update(extra or {})
+    # ---- one entry per role the step launches.  SURVEY 8(d) splits a ConvCheb layer's work in two: the SpMM recurrence is
+    # priced in BYTES against HBM (`bytes_8d`: [2 + 3 (K - 2)] E + (K - 1) Lb forward, [3 + 4 (K - 2)] E + (K - 1) Lb adjoint),
+    # the channel-mix contractions in FLOPS against the matrix peak of the storage dtype.  A fused launch carries both: its
+    # recurrence bytes over its in-graph time is `hbm_frac`, its flops over the same time `mfma_frac` - GEMM operand bytes of
+    # an unfused design are never added to the byte count (no entry can exceed 1 by construction of the count).
+    # `frac` repeats the fraction of the entry's `bound`.
+    def entry(role, kernel, t, bound, rec_b=None, flops=None, compulsory=None, leg=None, gemm_bytes=None, n_launch=None):
+        # `us` = everything the role launches per call (a fused launch + its small reduce; the K - 1 hops of a recurrence);
+        # fractions are over that time.  `n_launch` = launches that carry the recurrence; `kernel_us` = the longest kernel alone
+        sec = t["avg_us"] * 1e-6
+        d = {"role": role, "kernel": kernel, "us": round(sec * 1e6, 2), "calls": t["calls_per_step"], "bound": bound,
+             "n_launch": int(n_launch if n_launch is not None else t["kernels"])}
+        if t["kernels"] > 1 and t.get("longest_us"):
+            d["kernel_us"] = round(t["longest_us"], 2)
+        if rec_b is not None:
+            d["bytes_8d"] = int(rec_b)
+            d["hbm_frac"] = round(rec_b / sec / 1e9 / HBM_PEAK_GBS, 4)
+        if flops is not None:
+            d["flops"] = flops
+            d["TFLOPs"] = round(flops / sec / 1e12, 1)
+            d["mfma_frac"] = round(flops / sec / 1e12 / mm_peak, 4)
+        if gemm_bytes is not None:      # operand + result bytes of a stand-alone GEMM pass (what it streams; context only)
+            d["gemm_bytes"] = int(gemm_bytes)
+            d["gemm_GBs"] = round(gemm_bytes / sec / 1e9, 1)
+        if compulsory is not None:
+            d["compulsory_bytes"] = int(compulsory)
+            d["frac_compulsory"] = round(compulsory / sec / 1e9 / HBM_PEAK_GBS, 4)
+        d.update(_moved(traffic_key, leg, sec))
+        d["frac"] = d["hbm_frac"] if bound == "hbm" else d["mfma_frac"]
         return d
 
     in_step = []
-    if t_one is not None:
-        in_step.append(entry("forward (dsw_cheb_fwd)", "cheb3_fwd_fused: hops + channel mix + bias in ONE launch",
-                             t_one["avg_us"] * 1e-6, wf_bytes, t_one["calls_per_step"],
-                             dict({"compulsory_bytes": compulsory_fwd}, **_moved(traffic_key, "fwd1l" if t_dual is not None else None,
-                                                                               t_one["avg_us"] * 1e-6))))
+    if t_one is not None:        # (a backward in the dual form needs no basis planes: the forward then stores Y only)
+        in_step.append(entry("forward: both hops + channel mix + bias in ONE launch", "cheb3_fwd_fused", t_one, "hbm", fwd_b, mix_flops,
+                             E + yb_bytes if t_dual is not None else K * E + yb_bytes, "fwd1l" if t_dual is not None else None, n_launch=1))
     elif t_h2m is not None:
-        hop1_b = spmm_algorithmic_bytes(E, Lb, 2)[0]
         if t_bfwd is not None:
-            in_step.append(entry("forward hop 1 (dsw_cheb_fwd: staged launch, T1 = L X)", "spmm1_dma", t_bfwd["avg_us"] * 1e-6, hop1_b,
-                                 t_bfwd["calls_per_step"]))
-        in_step.append(entry("forward hop 2 + channel mix + bias in ONE launch", "cheb3_hop2mix", t_h2m["avg_us"] * 1e-6,
-                             (fwd_b - hop1_b) + (K * E + yb_bytes), t_h2m["calls_per_step"],
-                             {"compulsory_bytes": int(2 * E + E + yb_bytes),
-                              "bytes_note": "algorithmic = hop 2 (3E + Lb) + the GEMM it replaces (K E in, Y out); compulsory = T1, X in, "
-                                            "T2 (kept for backward) and Y out"}))
+            in_step.append(entry("forward hop 1 (staged launch, T1 = L X)", "spmm1_dma", t_bfwd, "hbm", hop1_b, None, 2 * E))
+        in_step.append(entry("forward hop 2 + channel mix + bias in ONE launch", "cheb3_hop2mix", t_h2m, "hbm", fwd_b - hop1_b,
+                             mix_flops, 2 * E + E + yb_bytes, n_launch=1))
     else:
         if t_bfwd is not None:
-            in_step.append(entry("forward recurrence (dsw_cheb_fwd: basis launches)", "spmm2_fused / spmm1_dma / spmm_csr hops",
-                                 t_bfwd["avg_us"] * 1e-6, fwd_b, t_bfwd["calls_per_step"]))
+            in_step.append(entry("forward recurrence (basis launches)", "spmm2_fused / spmm1_dma / spmm_csr", t_bfwd, "hbm", fwd_b, None,
+                                 K * E, "fwd"))
         if t_mix is not None:
-            in_step.append(entry("forward channel mix (dsw_cheb_fwd: GEMM + bias)", "ts_gemm_x3 / ts_gemm_x3s / ts_gemm",
-                                 t_mix["avg_us"] * 1e-6, K * E + yb_bytes, t_mix["calls_per_step"],
-                                 {"flops": 2.0 * N * C * K * Fout}))
+            in_step.append(entry("forward channel mix (GEMM + bias)", "ts_gemm_x3 / ts_gemm_x3s / ts_gemm", t_mix, "mfma", None, mix_flops,
+                                 gemm_bytes=K * E + yb_bytes))
         if t_zmix is not None:
-            in_step.append(entry("forward plane GEMM of a mix-first layer", "ts_gemm* / narrow_*", t_zmix["avg_us"] * 1e-6,
-                                 E + K * yb_bytes, t_zmix["calls_per_step"]))
+            in_step.append(entry("forward plane GEMM of a mix-first layer", "ts_gemm* / narrow_*", t_zmix, "mfma", None, mix_flops,
+                                 gemm_bytes=E + K * yb_bytes))
         if t_clen is not None:
-            in_step.append(entry("forward Clenshaw recurrence on the output channels", "spmm* hops", t_clen["avg_us"] * 1e-6,
-                                 spmm_algorithmic_bytes(yb_bytes, Lb, K)[1], t_clen["calls_per_step"]))
-    gemm_flops = 4.0 * N * C * K * Fout         # dW and dgrad
+            in_step.append(entry("forward Clenshaw recurrence on the output channels", "spmm* hops", t_clen, "hbm",
+                                 spmm_algorithmic_bytes(yb_bytes, Lb, K)[1]))
     if t_gemm is not None:
-        in_step.append(entry("backward GEMM pass (dW partials + db + dgrad planes in one pass, + reduce)",
-                             "cheb_wgrad_x3<FUSE> + cheb_wgrad_reduce", t_gemm["avg_us"] * 1e-6, K * E + yb_bytes + K * E,
-                             t_gemm["calls_per_step"],
-                             {"flops": gemm_flops, "TFLOPs": round(gemm_flops / (t_gemm["avg_us"] * 1e-6) / 1e12, 1),
-                              "bytes_note": "K basis planes + dY read once, K dgrad planes written"}))
+        in_step.append(entry("backward GEMM pass (dW partials + db + dgrad planes, + reduce)", "cheb_wgrad_x3<FUSE> + cheb_wgrad_reduce",
+                             t_gemm, "mfma", None, 2 * mix_flops, gemm_bytes=K * E + yb_bytes + K * E))
     if t_dgrad is not None:
-        in_step.append(entry("backward dgrad GEMM (planes G_k = dY W_k^T)", "ts_gemm_x3 / ts_gemm_x3s", t_dgrad["avg_us"] * 1e-6,
-                             yb_bytes + K * E, t_dgrad["calls_per_step"], {"flops": gemm_flops / 2}))
+        in_step.append(entry("backward dgrad GEMM (planes G_k = dY W_k^T)", "ts_gemm_x3 / ts_gemm_x3s", t_dgrad, "mfma", None, mix_flops,
+                             gemm_bytes=yb_bytes + K * E))
     if t_wgrad is not None:
-        in_step.append(entry("backward wgrad (dW, db)", "cheb_wgrad_x3 / cheb_wgrad_bf16 + reduce", t_wgrad["avg_us"] * 1e-6,
-                             K * E + yb_bytes, t_wgrad["calls_per_step"], {"flops": gemm_flops / 2}))
+        in_step.append(entry("backward wgrad (dW, db)", "cheb_wgrad_x3 / cheb_wgrad_bf16 + reduce", t_wgrad, "mfma", None, mix_flops,
+                             gemm_bytes=K * E + yb_bytes))
     if t_bwdf is not None:
-        in_step.append(entry("backward dgrad + adjoint recurrence in ONE launch (dY -> dX)", "cheb3_bwd_fused",
-                             t_bwdf["avg_us"] * 1e-6, yb_bytes + K * E + bwd_b, t_bwdf["calls_per_step"],
-                             {"compulsory_bytes": int(yb_bytes + E),
-                              "bytes_note": "algorithmic = the dgrad GEMM (dY in, K planes out) + the adjoint recurrence it replaces"}))
-    dual_bytes = (K * E + yb_bytes + K * E) + bwd_b      # what the dual launch replaces: fused wgrad + dgrad pass + adjoint recurrence
+        in_step.append(entry("backward dgrad + adjoint recurrence in ONE launch (dY -> dX)", "cheb3_bwd_fused", t_bwdf, "hbm", bwd_b,
+                             mix_flops, yb_bytes + E, n_launch=1))
     if t_dual is not None:
-        in_step.append(entry("whole backward in ONE launch in the dual form (X, dY -> dX, dW, db; + the partial reduce)",
-                             "cheb3_bwd_dual + cheb_wgrad_reduce", t_dual["avg_us"] * 1e-6, dual_bytes, t_dual["calls_per_step"],
-                             {"compulsory_bytes": int(E + yb_bytes + E), "flops": gemm_flops,
-                              "TFLOPs": round(gemm_flops / (t_dual["avg_us"] * 1e-6) / 1e12, 1),
-                              "frac_compulsory": round((E + yb_bytes + E) / (t_dual["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                              **_moved(traffic_key, "bwdd", t_dual["avg_us"] * 1e-6),
-                              "bytes_note": "algorithmic = the launches it replaces (SURVEY 8d: K basis planes + dY in, K dgrad planes "
-                                            "out; adjoint recurrence 7E + 2Lb); it MOVES X, dY in and dX out (compulsory_bytes): the "
-                                            "Chebyshev basis of dY under L^T lives in LDS only"}))
+        in_step.append(entry("whole backward in ONE launch, dual form (X, dY -> dX, dW, db; + the partial reduce)",
+                             "cheb3_bwd_dual + cheb_wgrad_reduce", t_dual, "hbm", bwd_b, 2 * mix_flops, E + yb_bytes + E, "bwdd", n_launch=1))
     if t_adj is not None:
-        in_step.append(entry("adjoint recurrence (dsw_cheb_bwd: basis_adj launches)", "spmm_csr x%d" % (K - 1) if ppt is None else
+        in_step.append(entry("adjoint recurrence (basis_adj launches)", "spmm_csr x%d" % (K - 1) if ppt is None else
                              "spmm1_dma / spmm1_staged x%d" % (K - 1) if _k2.hops == 1 else "spmm2_fused adjoint pair(s)",
-                             t_adj["avg_us"] * 1e-6, bwd_b, t_adj["calls_per_step"]))
-    step_sum_us = sum(d["avg_us"] * d["calls_per_step"] for d in in_step)
+                             t_adj, "hbm", bwd_b, None, None, "adj"))
+    step_sum_us = sum(d["us"] * d["calls"] for d in in_step)
     for d in in_step:
-        d["share_of_layer"] = round(d["avg_us"] * d["calls_per_step"] / max(step_sum_us, 1e-9), 3)
+        d["share"] = round(d["us"] * d["calls"] / max(step_sum_us, 1e-9), 3)
 
-    # ---- the headline entry: the SpMM recurrence launches that a timed step really makes --------------------------------
-    # the adjoint recurrence always (inside cheb3_bwd_fused where the step takes that launch); the forward recurrence only
-    # where the step launches it (not at the north-star shape, whose forward is ONE launch with the hops inside)
-    legs = []
-    if t_bwdf is None and t_dual is None:
-        legs.append(("adj", n_adj, adj_s, bwd_b))
-    if fwd_rec_in_step:
-        legs.append(("fwd", n_fwd, fwd_s, fwd_b))
-    elif t_h2m is not None and t_bfwd is not None:     # hop 1 is a launch of its own; hop 2 lives in the fused launch (in_step)
-        legs.append(("fwd1", 1, t_bfwd["avg_us"] * 1e-6, spmm_algorithmic_bytes(E, Lb, 2)[0]))
-    fused_bwd = t_bwdf is not None or t_dual is not None
-    if t_bwdf is not None:   # the adjoint recurrence lives inside the fused backward launch: that launch against the bytes it replaces
-        legs.append(("bwdf", 1, t_bwdf["avg_us"] * 1e-6, yb_bytes + K * E + bwd_b))
-    if t_dual is not None:   # ... or inside the dual launch, together with the wgrad + dgrad pass
-        legs.append(("bwdd", 1, t_dual["avg_us"] * 1e-6, dual_bytes))
-    n_in = sum(l[1] for l in legs)
-    t_in = sum(l[2] for l in legs)
-    b_in = sum(l[3] for l in legs)
-    achieved = b_in / t_in / 1e9
-    moved = [_traffic(traffic_key, l[0]) for l in legs]
-    traffic = None if any(m is None for m in moved) else sum(m["hbm_bytes_per_call"] for m in moved) / n_in
+    # ---- headline: the DOMINANT launch among those that carry SpMM recurrence work in the step (SURVEY 8d bytes of its
+    # recurrence / its in-graph duration); the whole step's recurrence bytes over the whole step's time beside it
+    rec = [d for d in in_step if "bytes_8d" in d]
+    if rec:
+        dom = max(rec, key=lambda d: d["us"] * d["calls"])
+        # a fused launch is ONE kernel (the small partial reduce behind it carries no recurrence work): its own duration, the
+        # figure `rocprofv3 --stats` reports for it; a K - 1 hop recurrence is its launches together
+        one = dom["n_launch"] == 1 and "kernel_us" in dom
+        dom_sec, dom_b, dom_n = (dom["kernel_us"] if one else dom["us"]) * 1e-6, dom["bytes_8d"], dom["n_launch"]
+        timing = IN
+    else:                        # nothing traced: isolated legs of the two recurrences
+        adj_s = adj_s if adj_s is not None else timed(adj)
+        dom = {"role": "adjoint recurrence (ISOLATED leg)", "kernel": "basis_adj launches"}
+        dom_sec, dom_b, dom_n = adj_s, bwd_b, n_adj
+        timing = ISO
+    m_dom = dom.get("bytes_moved")
+    rec_bytes_step = sum(d["bytes_8d"] * d["calls"] for d in rec)
+    flops_step = sum(d.get("flops", 0.0) * d["calls"] for d in in_step)
+    out = {
+        "bound": "hbm",
+        "kernel": "%s [%s]" % (dom["kernel"], dom["role"]),
+        "achieved": round(dom_b / dom_sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(dom_b / dom_sec / 1e9 / HBM_PEAK_GBS, 4),
+        "traffic": None if m_dom is None else int(m_dom / dom_n),
+        "frac_counter": None if m_dom is None else round(m_dom / dom_sec / 1e9 / HBM_PEAK_GBS, 4),
+        "bytes_per_launch": int(dom_b / dom_n), "avg_launch_us": round(dom_sec / dom_n * 1e6, 2), "launches": dom_n,
+        "launch_timing": timing,
+        "definition": "SURVEY 8(d) recurrence bytes of the dominant launch / its in-graph duration / 8 TB/s; GEMM flops -> mfma_*",
+    }
+    if "flops" in dom:
+        out.update({"flops_per_launch": dom["flops"], "mfma_TFLOPs": round(dom["flops"] / dom_sec / 1e12, 1),
+                    "mfma_peak_TFLOPs": mm_peak, "mfma_frac": round(dom["flops"] / dom_sec / 1e12 / mm_peak, 4)})
+    if "compulsory_bytes" in dom:
+        out.update({"compulsory_bytes": dom["compulsory_bytes"],
+                    "frac_compulsory": round(dom["compulsory_bytes"] / dom_sec / 1e9 / HBM_PEAK_GBS, 4)})
+    if ms_per_step is not None and rec:
+        out["step_bytes_8d"] = int(rec_bytes_step)
+        out["step_frac"] = round(rec_bytes_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        out["step_flops"] = flops_step
+        out["step_mfma_frac"] = round(flops_step / (ms_per_step * 1e-3) / 1e12 / mm_peak, 4)
+    # second launch of the step by time, flat (the driver's parser keeps scalars of this object only)
+    others = sorted((d for d in in_step if d is not dom), key=lambda d: -d["us"] * d["calls"])
+    if others:
+        o = others[0]
+        out.update({"second_kernel": o["kernel"], "second_us": o["us"], "second_bound": o["bound"], "second_frac": o["frac"],
+                    "second_hbm_frac": o.get("hbm_frac"), "second_mfma_frac": o.get("mfma_frac"),
+                    "second_frac_counter": o.get("frac_counter")})
+    # north-star gate: the K = 3 forward recurrence alone (in the step where the step launches it, else an isolated leg)
+    out.update({"fwd_recurrence_us": round(fwd_s * 1e6, 2), "fwd_recurrence_frac": round(fwd_b / fwd_s / 1e9 / HBM_PEAK_GBS, 4),
+                "fwd_recurrence_in_step": bool(fwd_rec_in_step and t_bfwd is not None and t_h2m is None),
+                "forward_path": path_names.get(fwd_path),
+                "in_step_sum_us": round(step_sum_us, 2)})
+    if ms_per_step is not None and in_step:
+        out["in_step_sum_vs_ms_per_step"] = round(step_sum_us / (ms_per_step * 1e3), 4)
+    out["in_step"] = in_step
+
     kname = lambda plan, trn: ("spmm_csr_rowsplit x%d" % (K - 1) if plan is None else
                                "spmm1_dma / spmm1_staged x%d (one staged launch per hop)" % (K - 1) if plan.hops == 1 else
                                "spmm2_fused x%d (hops pairwise in one launch)" % pairs) + (" on L^T" if trn else "")
 
     def rec_entry(leg, plan, trn, n, sec, nbytes, how):
         m = _traffic(traffic_key, leg)
-        return {"kernels": kname(plan, trn), "launches": n, "us": round(sec * 1e6, 2), "algorithmic_bytes": int(nbytes),
+        return {"kernels": kname(plan, trn), "launches": n, "us": round(sec * 1e6, 2), "bytes_8d": int(nbytes),
                 "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4), "timing": how,
-                # a launch that keeps an intermediate plane on chip moves fewer bytes than SURVEY 8d's unfused pass count: the
-                # fraction by algorithmic bytes may then exceed what the memory system delivered - bytes_moved says what it did
                 "fused": bool(plan is not None and plan.hops != 1),
                 "bytes_moved": None if m is None else int(m["hbm_bytes_per_call"]),
                 "frac_counter": None if m is None else round(m["hbm_bytes_per_call"] / sec / 1e9 / HBM_PEAK_GBS, 4)}
 
-    out = {
-        "bound": "hbm",
-        "kernel": ("SpMM recurrence launches of a timed step: " +
-                   ("cheb3_bwd_dual (the WHOLE backward in one launch: L^T recurrence on dY in LDS, dX and dW from it)" if t_dual is not None else
-                    "cheb3_bwd_fused (dgrad GEMM + adjoint recurrence in one launch)" if fused_bwd else
-                    "adjoint recurrence (%s)" % kname(_k2, True)) +
-                   ((" + forward recurrence (%s)" % kname(_k1, False)) if fwd_rec_in_step else "") +
-                   "; forward path of this layer: %s" % path_names.get(fwd_path)),
-        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4),
-        "fused": fused_bwd or any(p is not None and p.hops != 1 for p in ((_k2, _k1) if fwd_rec_in_step else (_k2,))),
-        "traffic": None if traffic is None else int(traffic),
-        "frac_counter": None if traffic is None else round(traffic * n_in / t_in / 1e9 / HBM_PEAK_GBS, 4),
-        "traffic_source": (None if traffic is None else
-                           "profiles/spmm_traffic.json: HBM bytes per launch from separate rocprofv3 --pmc passes over exactly "
-                           "these launches (2 x FETCH_SIZE + WRITE_SIZE, tools/pmc_traffic.sh); a committed measurement, not "
-                           "read in this run"),
-        "bytes_per_launch": int(b_in / n_in), "avg_launch_us": round(t_in / n_in * 1e6, 2), "launches": n_in,
-        "launch_timing": (IN if have_trace and adj_s_iso is None else ISO),
-        "definition": "achieved = SURVEY 8d algorithmic bytes of these launches / their in-step time; frac_counter = measured "
-                      "HBM bytes / the same time / 8 TB/s",
+    # detail (side file / --detail inline): the recurrences as stand-alone launches, the stand-alone channel mix
+    detail = {
         "forward_recurrence": dict(rec_entry("fwd", _k1, False, n_fwd, fwd_s, fwd_b,
-                                             IN if (fwd_rec_in_step and t_bfwd is not None) else ISO),
-                                   in_step=fwd_rec_in_step,
+                                             IN if (fwd_rec_in_step and t_bfwd is not None) else ISO), in_step=fwd_rec_in_step,
                                    note="north-star gate: >= 0.60 of 8 TB/s on the K = 3 forward recurrence"),
-        "adjoint_recurrence": (None if fused_bwd else
-                               dict(rec_entry("adj", _k2, True, n_adj, adj_s, bwd_b, IN if adj_s_iso is None else ISO), in_step=True)),
-        "fwd_recurrence_us": round(fwd_s * 1e6, 2),
-        "fwd_recurrence_frac": round(fwd_b / fwd_s / 1e9 / HBM_PEAK_GBS, 4),
-        "in_step": in_step,
-        "in_step_sum_us": round(step_sum_us, 2),
+        "adjoint_recurrence": (None if adj_s is None else
+                               dict(rec_entry("adj", _k2, True, n_adj, adj_s, bwd_b, IN if adj_s_iso is None else ISO),
+                                    in_step=t_adj is not None)),
         "mfma": out_mfma,
+        "traffic_source": "profiles/spmm_traffic.json: HBM bytes per launch from separate rocprofv3 --pmc passes over exactly these "
+                          "launches (2 x FETCH_SIZE + WRITE_SIZE, tools/pmc_traffic.sh); a committed measurement, not read in this run",
+        "E_bytes": int(E), "Lb_bytes": int(Lb),
     }
-    if t_dual is not None:   # the fused launch moves far fewer bytes than the 8(d) count of what it replaces: say both
-        out["compulsory_bytes"] = int(E + yb_bytes + E)
-        out["frac_compulsory"] = round((E + yb_bytes + E) / (t_dual["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-        out["limited_by"] = ("on-chip work, not HBM: `frac` prices the launch by the SURVEY 8(d) bytes of the launches it replaces; it "
-                             "moves `traffic` bytes (`frac_counter`), `compulsory_bytes` at the least (`frac_compulsory`) - LDS gathers, "
-                             "operand splits and 576 MFMAs per tile and sample bound it (DESIGN.md section 3: ablation, counters)")
-    if ms_per_step is not None and in_step:
-        out["in_step_sum_vs_ms_per_step"] = round(step_sum_us / (ms_per_step * 1e3), 4)
-    return out
+    return out, detail
 
 
 def pooling_leg(model, run_forward, steps, traffic_key=None, pmc_leg=None, traced=None):
@@ -1327,13 +1342,13 @@ def main():
                     trace_note = "in-graph durations unavailable (%s): EAGER kernel durations, ~10 %% above the replayed graph" % graph_info
                     graph_info = None
                     print("bench: " + trace_note, file=sys.stderr)
-            out["roofline"] = roofline_leg(rl_layer, rl_x, max(10, args.steps), 5, traffic_key=tkey, traced=traced,
-                                           ms_per_step=ms if args.workload in ("ns", "c3") else None)
+            out["roofline"], detail = roofline_leg(rl_layer, rl_x, max(10, args.steps), 5, traffic_key=tkey, traced=traced,
+                                                   ms_per_step=ms if args.workload in ("ns", "c3") else None)
             if rl_what is not None:
                 out["roofline"]["kernel"] += "; layer " + rl_what
             if traced is not None:
                 tot = sum(v["us_per_step"] for v in traced.values())
-                out["roofline"]["traced_step"] = {
+                detail["traced_step"] = {
                     "what": "every role the library's entry points ran in one step, us per step: order and roles from the eager "
                             "launch trace (dsw_trace), durations " + ("from the rocprofv3 kernel trace of the replayed graph"
                                                                       if graph_info is not None else "from the EAGER launches"),
@@ -1344,9 +1359,28 @@ def main():
                                       "kernels": v["kernels"], "longest_kernel": v.get("longest_kernel"),
                                       "eager_avg_us": v.get("eager_avg_us")}
                                      for k, v in traced.items()), key=lambda d: -d["us_per_step"])[:24]}
+                out["roofline"]["traced_sum_vs_ms_per_step"] = detail["traced_step"]["vs_ms_per_step"]
+                if trace_note:
+                    out["roofline"]["trace_note"] = trace_note
             if args.workload in ("unet", "c5"):
-                out["roofline"]["pooling"] = pooling_leg(model, lambda: model(x.detach()), max(10, args.steps), traffic_key=tkey,
-                                                         traced=traced)
+                po = pooling_leg(model, lambda: model(x.detach()), max(10, args.steps), traffic_key=tkey, traced=traced)
+                detail["pooling"] = po
+                out["roofline"].update({"pooling_us_per_step": po["us_per_step"], "pooling_frac": po["frac"],
+                                        "pooling_frac_counter": po["frac_counter"]})
+            # the long form (every role of the step, the pooling products, the stand-alone recurrence / GEMM legs) goes to a side
+            # file - the line itself stays short enough for the driver to keep whole - or inline on request
+            if args.detail == "inline":
+                out["roofline"]["detail"] = detail
+            elif args.detail != "none":
+                path = args.detail_file or os.path.join(REPO, "gpurun_out", "bench_detail_%s%s.json" % (
+                    args.workload, "_k20" if (args.workload == "ns" and args.knn == 20) else ""))
+                try:
+                    os.makedirs(os.path.dirname(path), exist_ok=True)
+                    with open(path, "w") as fh:
+                        json.dump(detail, fh)
+                    out["roofline"]["detail_file"] = os.path.relpath(path, REPO)
+                except OSError as exc:
+                    out["roofline"]["detail_file"] = "not written (%s)" % type(exc).__name__
         if not args.no_cpu_baseline:
             if args.workload == "unet":
                 out["cpu_baseline"] = cpu_baseline_unet(model, wl, V)

@@ -151,10 +151,6 @@ int64_t dsw_cheb3_bwd_dual_ws_bytes(void);
 int dsw_cheb3_bwd_dual_try(const dsw_hop2_plan* plan_t, int64_t V, const void* X, const void* dY, const void* W, void* dX,
                            void* dW, void* db, float* partial, int64_t B, int64_t Fin, int64_t Fout, int64_t K, int dtype,
                            hipStream_t stream, int* rc, int accumulate);
-int dsw_cheb3_bwd_fused_try(const dsw_hop2_plan* plan_t, int64_t V, const void* dY, const void* W, void* dX, int64_t B,
-                            int64_t Fin, int64_t Fout, int64_t K, int dtype, hipStream_t stream, int* rc, void* ws,
-                            int64_t ws_bytes);
-int dsw_cheb3_bwd_fused_eligible(const dsw_hop2_plan* plan_t, int64_t Fin, int64_t Fout, int64_t K, int dtype);
 int dsw_zdgrad_launch(const void* dY, const void* D, const void* W, void* dX, int64_t N, int64_t Fin, int64_t Fout,
                       int64_t K, int dtype, hipStream_t stream, const DswEpiExtra* extra = nullptr);
 
@@ -459,30 +455,6 @@ int dsw_cheb_mix_fwd(const void* X, const void* T, const void* W, const void* bi
 
 int dsw_cheb_mix_first(int64_t Fin, int64_t Fout, int64_t K) { return mix_first(Fin, Fout, K) ? 1 : 0; }
 
-int dsw_cheb_dx_one_launch_supported(const dsw_hop2_plan* plan_t, int64_t Fin, int64_t Fout, int64_t K, int dtype) {
-    return dsw_cheb3_bwd_fused_eligible(plan_t, Fin, Fout, K, dtype);
-}
-
-int64_t dsw_cheb_dx_one_launch_workspace_bytes(void) { return 3 * 2 * 2 * 3 * 64 * 16 + 256; }
-
-int dsw_cheb_dx_one_launch(const dsw_hop2_plan* plan_t, int64_t V, const void* dY, const void* W, void* dX, void* workspace,
-                           int64_t workspace_bytes, int64_t B, int64_t Fin, int64_t Fout, int64_t K, int dtype,
-                           dsw_stream_t stream) {
-    if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
-    if (V < 0 || B < 0 || Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
-    if (!dsw_cheb3_bwd_fused_eligible(plan_t, Fin, Fout, K, dtype)) return DSW_ERR_BAD_ARG;
-    if (V == 0 || B == 0) return DSW_OK;
-    if (!dY || !W || !dX) return DSW_ERR_BAD_ARG;
-    if (!workspace || workspace_bytes < dsw_cheb_dx_one_launch_workspace_bytes()) return DSW_ERR_WORKSPACE;
-    char* wsa = reinterpret_cast<char*>(round_up((int64_t)(uintptr_t)workspace, 256));
-    int rc = DSW_OK;
-    trace_start(stream);
-    const int took = dsw_cheb3_bwd_fused_try(plan_t, V, dY, W, dX, B, Fin, Fout, K, dtype, (hipStream_t)stream, &rc, wsa,
-                                             workspace_bytes - (wsa - static_cast<char*>(workspace)));
-    trace_mark(stream, DSW_ROLE_BWD_FUSED, V, Fin, Fout);
-    return took ? rc : DSW_ERR_ALIGN;
-}
-
 int dsw_cheb_bwd_needs_basis(const dsw_hop2_plan* plan_t, int64_t V, int64_t Fin, int64_t Fout, int64_t K, int dtype) {
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     if (Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
@@ -715,7 +687,10 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
             return rcd;
         }
     }
-    if (K > 1 && !T) return DSW_ERR_BAD_ARG;         // every other route reads the forward's basis planes
+    // every other route reads the forward's basis planes.  T == NULL is the contract of the dual form only (include/dsw_hip.h:
+    // dsw_cheb_bwd_needs_basis() == 0 AND 16-byte aligned X, dY, W, dX, workspace): say which half of it was broken
+    if (K > 1 && !T)
+        return (!extras && dsw_cheb_bwd_needs_basis(plan_t, V, Fin, Fout, K, dtype) == 0) ? DSW_ERR_ALIGN : DSW_ERR_BAD_ARG;
     const int64_t plane = N * Fin * elem_size(dtype);
     char* G = ws;                                                    // G_1 .. G_{K-1}
     char* spare = G + (K - 1) * plane;
@@ -726,8 +701,6 @@ static int cheb_bwd_impl(const int32_t* rowptr_t, const int32_t* colind_t, const
     // (staged one-hop plans only: inside a fused pair the subtracted plane is the staged input of the first hop - no pass
     // is saved there and the fold would only add work)
     const int folded = (K >= 3 && dX != nullptr && N > 0 && plan_t != nullptr && plan_t->hops == 1) ? 1 : 0;
-    // (dsw_cheb_dx_one_launch - dX straight from dY, dgrad planes in LDS only - exists for the K = 3, 32 -> 64 fp32 shape and is
-    // NOT taken here: measured 203 us against the 157 us it has to beat)
     if (dX != nullptr && dW != nullptr && N > 0 && !extras) {
         // small aligned fp32 layers: dgrad planes and dW partials from ONE pass over dY (dsw_wgrad_x3.hip, FUSE); the fold is
         // applied while that kernel fills its W^T panel

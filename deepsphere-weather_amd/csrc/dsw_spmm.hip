@@ -605,10 +605,12 @@ __global__ __launch_bounds__(256) void remap_parts_kernel(
         for (int q = s + part; q < e; q += 4 * parts) {
             int col[4];
             float a[4];
+            bool live[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int qq = q + u * parts;
                 const bool ok = qq < e;
+                live[u] = ok;
                 col[u] = ok ? colind[qq] : 0;
                 a[u] = ok ? vals[qq] : 0.f;
             }
@@ -622,7 +624,8 @@ __global__ __launch_bounds__(256) void remap_parts_kernel(
 #pragma unroll
                 for (int i = 0; i < NB; ++i)
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) acc[i][j] = fmaf(a[u], x[u][i][j], acc[i][j]);
+                    for (int j = 0; j < VEC; ++j)    // a padding slot read row 0: an Inf / NaN there must not reach this row (0 * Inf)
+                        acc[i][j] = fmaf(a[u], live[u] ? x[u][i][j] : 0.f, acc[i][j]);
         }
     }
     for (int m = cpr; m < gl; m <<= 1) {

@@ -59,9 +59,6 @@ SIGNATURES = {
     "dsw_cheb_mix_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp]),
     "dsw_cheb_mix_first": (_int, [_i64, _i64, _i64]),
     "dsw_cheb_bwd_needs_basis": (_int, [_vp, _i64, _i64, _i64, _i64, _int]),
-    "dsw_cheb_dx_one_launch_supported": (_int, [_vp, _i64, _i64, _i64, _int]),
-    "dsw_cheb_dx_one_launch_workspace_bytes": (_i64, []),
-    "dsw_cheb_dx_one_launch": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _vp]),
     "dsw_cheb_fwd_path": (_int, [_vp, _i64, _i64, _i64, _int]),
     "dsw_rezero_residual_workspace_bytes": (_i64, []),
     "dsw_rezero_residual_fwd": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _vp]),

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 SOURCES = ["dsw_api.hip", "dsw_spmm.hip", "dsw_gemm.hip", "dsw_gemm_x3.hip", "dsw_spmm2.hip", "dsw_wgrad_x3.hip",
-           "dsw_gemm_x3s.hip", "dsw_narrow.hip", "dsw_elementwise.hip", "dsw_pool.hip", "dsw_fwd3.hip", "dsw_spmm1s.hip", "dsw_bwd3.hip", "dsw_bwd3d.hip"]
+           "dsw_gemm_x3s.hip", "dsw_narrow.hip", "dsw_elementwise.hip", "dsw_pool.hip", "dsw_fwd3.hip", "dsw_spmm1s.hip", "dsw_bwd3d.hip"]
 OUT = os.path.join(HERE, "libdsw_hip.so")
 
 

@@ -339,6 +339,14 @@ _plan_ptr.disabled = False
 _FWD_FUSED = True   # forward hop pairs run fused whenever a plan exists
 
 
+def _aligned16(t):
+    """A backward without basis planes (``T`` = None) exists only as the one-launch dual form, whose 16-byte vector loads need
+    16-byte aligned operands.  Tensors torch allocates are (256-byte) aligned; a contiguous VIEW into a flat buffer at an odd
+    element offset (flattened parameter / gradient buckets of other frameworks) is not: it is copied once - rare, and cheaper
+    than keeping the planes for everybody (the shape check of the forward cannot see the backward's pointers)."""
+    return t if t is None or t.data_ptr() % 16 == 0 else t.clone(memory_format=torch.contiguous_format)
+
+
 class _HipBackend:
     """Thin tensor-level wrapper over the C ABI (include/dsw_hip.h)."""
 
@@ -404,10 +412,12 @@ class _HipBackend:
             _native.check(rc, "dsw_cheb_basis_fwd")
         return T
 
-    def cheb_fwd(self, op, x, w, bias, relu=False, keep_basis=True):
+    def cheb_fwd(self, op, x, w, bias, relu=False, keep_basis=True, no_backward=False):
         """``keep_basis=False``: the caller's backward is plain ``cheb_bwd`` / ``cheb_bwd_res`` without scale / dx_add - where
         that backward runs in the dual form (``dsw_cheb_bwd_needs_basis`` == 0: X and dY only) AND the forward is the
-        one-launch kernel, the basis planes are neither allocated nor stored and ``T`` comes back as None."""
+        one-launch kernel, the basis planes are neither allocated nor stored and ``T`` comes back as None.
+        ``no_backward=True`` (inference, ``torch.no_grad()``): no backward will ever run, so the planes are dropped wherever
+        the forward can do without them, without building the plan of the transposed operator."""
         lib = _native.load()
         B, V, Fin = x.shape
         _, K, Fout = w.shape
@@ -420,8 +430,11 @@ class _HipBackend:
         drop = False
         if not keep_basis and K > 1 and not mix_first and pp is not None and op is not None \
                 and lib.dsw_cheb_fwd_path(pp, Fin, Fout, K, _DTYPES[x.dtype]) == 3:      # DSW_FWD_ONE_LAUNCH takes T = NULL
-            ppt, _keep_t = _plan_ptr(op.transpose(), x, Fin)
-            drop = ppt is not None and lib.dsw_cheb_bwd_needs_basis(ppt, V, Fin, Fout, K, _DTYPES[x.dtype]) == 0
+            if no_backward:
+                drop = True        # inference / no_grad: nobody will read the planes - and the plan of L^T is not even built
+            else:
+                ppt, _keep_t = _plan_ptr(op.transpose(), x, Fin)
+                drop = ppt is not None and lib.dsw_cheb_bwd_needs_basis(ppt, V, Fin, Fout, K, _DTYPES[x.dtype]) == 0
         T = torch.empty((K - 1, B, V, Fin), dtype=x.dtype, device=x.device) if (K > 1 and not drop) else None
         csr = (None, None, None, V, 0) if op is None else (
             op.rowptr.data_ptr(), op.colind.data_ptr(), op.values.data_ptr(), V, op.nnz)
@@ -446,6 +459,16 @@ class _HipBackend:
             _native.check(n, "dsw_cheb_fwd_workspace_bytes")
         return torch.empty((n,), dtype=torch.uint8, device=x.device), n
 
+    @staticmethod
+    def _bwd_workspace(lib, x, Fin, Fout, K, dt):
+        """Scratch of one backward call.  The size depends on the CU count of the CURRENT device (slabs of the one-launch dual
+        backward): queried under the guard of the tensor's device, where the launch will run."""
+        with torch.cuda.device(x.device):
+            nbytes = int(lib.dsw_cheb_bwd_workspace_bytes(x.shape[0], x.shape[1], Fin, Fout, K, dt))
+        if nbytes < 0:
+            _native.check(nbytes, "dsw_cheb_bwd_workspace_bytes")
+        return torch.empty((nbytes,), dtype=torch.uint8, device=x.device), nbytes
+
     def cheb_bwd(self, op, x, T, w, dy, need_dx, need_dw, need_db):
         lib = _native.load()
         B, V, Fin = x.shape
@@ -455,11 +478,10 @@ class _HipBackend:
         want_w = need_dw or need_db
         dw = torch.empty_like(w) if want_w else None
         db = torch.empty((Fout,), dtype=w.dtype, device=w.device) if want_w else None
-        nbytes = int(lib.dsw_cheb_bwd_workspace_bytes(B, V, Fin, Fout, K, dt))
-        if nbytes < 0:
-            _native.check(nbytes, "dsw_cheb_bwd_workspace_bytes")
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+        ws, nbytes = self._bwd_workspace(lib, x, Fin, Fout, K, dt)
         mix_first = bool(lib.dsw_cheb_mix_first(Fin, Fout, K))
+        if T is None and K > 1 and not mix_first:
+            x, w, dy = _aligned16(x), _aligned16(w), _aligned16(dy)
         need_hops = K > 1 and (need_dx or (mix_first and want_w) or T is None)    # (T is None: the dual form runs its hops on dY)
         opt = op.transpose() if need_hops else op
         pp, _keep = _plan_ptr(opt, x, Fout if mix_first else Fin) if (need_hops and K > 1) else (None, None)
@@ -513,11 +535,10 @@ class _HipBackend:
         else:
             dw = torch.empty_like(w) if need_dw else None
             db = torch.empty((Fout,), dtype=w.dtype, device=w.device) if need_dw else None
-        nbytes = int(lib.dsw_cheb_bwd_workspace_bytes(B, V, Fin, Fout, K, dt))
-        if nbytes < 0:
-            _native.check(nbytes, "dsw_cheb_bwd_workspace_bytes")
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+        ws, nbytes = self._bwd_workspace(lib, x, Fin, Fout, K, dt)
         mix_first = bool(lib.dsw_cheb_mix_first(Fin, Fout, K))
+        if T is None and K > 1 and not mix_first:
+            x, w, dy = _aligned16(x), _aligned16(w), _aligned16(dy)
         need_hops = K > 1 and (need_dx or (mix_first and need_dw) or T is None)
         opt = op.transpose() if need_hops else op
         pp, _keep = _plan_ptr(opt, x, Fout if mix_first else Fin) if (need_hops and K > 1) else (None, None)
@@ -734,7 +755,8 @@ class _ChebConvFn(torch.autograd.Function):
         bc = None if bias is None else bias.contiguous()
         if getattr(be, "name", "") == "hip":
             # this Function's backward is the plain closed form: the basis planes are dropped where it runs in the dual form
-            y, T = be.cheb_fwd(op, xc, wc, bc, relu, keep_basis=False)
+            no_bwd = not any(ctx.needs_input_grad[:3])    # (apply() under no_grad / on constants: all False)
+            y, T = be.cheb_fwd(op, xc, wc, bc, relu, keep_basis=False, no_backward=no_bwd)
         else:
             y, T = be.cheb_fwd(op, xc, wc, bc, relu) if relu else be.cheb_fwd(op, xc, wc, bc)
         # the plain output is NOT saved: callers modify it in place (layers.py:375, my_models_graph.py:213).  With the

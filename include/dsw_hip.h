@@ -115,7 +115,7 @@ int dsw_build_flags(void);
 #define DSW_ROLE_ZMIX 11           /* mix-first forward: plane GEMM Z_k = X W_k */
 #define DSW_ROLE_CLENSHAW_FWD 12   /* mix-first forward: Clenshaw recurrence on the output channels */
 #define DSW_ROLE_ELEMENTWISE 13    /* relu mask (kind 1), ReZero residual forward (2) / backward (3), ReZero parameter gradients (4) */
-#define DSW_ROLE_BWD_FUSED 14      /* dgrad + adjoint recurrence in one launch (dY -> dX) */
+#define DSW_ROLE_BWD_FUSED 14      /* (retired in round 6 with dsw_cheb_dx_one_launch: never emitted) */
 #define DSW_ROLE_FWD_HOP2_MIX 16     /* hop 2 + channel mix + bias of the forward in one launch (one-hop plans) */
 #define DSW_ROLE_BASIS_DUAL 15     /* mix-first backward: Chebyshev basis of dY under L^T (on the output channels) */
 #define DSW_ROLE_BWD_DUAL 17       /* whole backward in one launch in the dual form (X, dY -> dX, dW, db), + the partial reduce */
@@ -231,20 +231,6 @@ int dsw_cheb_mix_fwd(const void* X, const void* T, const void* W, const void* bi
  * HBM-bound part, run on Fout instead of Fin channels).  Callers use it to size the tile plan they pass
  * (rows of Fout vs Fin channels) and to know whether T comes back as the basis. */
 int dsw_cheb_mix_first(int64_t Fin, int64_t Fout, int64_t K);
-
-/* dX of a K = 3, 32 -> 64 channel fp32 layer straight from dY in ONE launch (dsw_bwd3.hip):
- *     G_k = dY W_k^T,   dX = G_0 - G_2 + L^T (G_1 + 2 L^T G_2)
- * with the dgrad planes G_k formed on the two-ring of each 64-row tile in LDS (matrix cores) and both L^T hops run from LDS:
- * HBM sees dY in and dX out - the planes, 604 MB of the north-star step, never travel.  plan_t: two-hop plan of L^T.
- * An ALTERNATIVE to the dgrad + adjoint launches inside dsw_cheb_bwd, which does not call it: it is correct (parity-tested)
- * but measured slower on MI355X than the launches it replaces (203 us against 157 us at nside 64, B = 16: its phases - split,
- * matrix cores, gathers - are short, latency-bound and do not overlap).  workspace:
- * dsw_cheb_dx_one_launch_workspace_bytes() of scratch (the pre-split W fragments). */
-int dsw_cheb_dx_one_launch_supported(const dsw_hop2_plan* plan_t, int64_t Fin, int64_t Fout, int64_t K, int dtype);
-int64_t dsw_cheb_dx_one_launch_workspace_bytes(void);
-int dsw_cheb_dx_one_launch(const dsw_hop2_plan* plan_t, int64_t V, const void* dY, const void* W, void* dX, void* workspace,
-                           int64_t workspace_bytes, int64_t B, int64_t Fin, int64_t Fout, int64_t K, int dtype,
-                           dsw_stream_t stream);
 
 /* Which launch sequence dsw_cheb_fwd takes for a layer shape and plan (pointer alignment aside) - what a profile of a
  * training step should be read against:
