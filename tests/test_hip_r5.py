@@ -76,7 +76,9 @@ def test_bench_n1_runs_the_n_gt_1_step_and_agrees():
     # the headline is the SURVEY 8(d) figure of ONE launch: recurrence bytes (7E + 2Lb for the adjoint side, 5E + 2Lb forward) over
     # its duration - never the bytes of launches an unfused design would have made - and no entry exceeds its roof
     E = 16 * 49152 * 32 * 4
-    assert r["bytes_per_launch"] * r["launches"] in (7 * E + 2 * 3735556, 5 * E + 2 * 3735556), r["bytes_per_launch"]
+    # (Lb = nnz * 8 + 4 (V + 1) of the operator the bench built: 3.74-3.76 MB at k = 8)
+    got = r["bytes_per_launch"] * r["launches"]
+    assert any(0 <= got - n * E - 2 * 3_700_000 <= 2 * 100_000 for n in (7, 5)), r["bytes_per_launch"]
     assert abs(r["achieved"] - r["bytes_per_launch"] / r["avg_launch_us"] / 1e3) <= 0.01 * r["achieved"]
     for e in r["in_step"]:
         assert 0.0 < e["frac"] <= 1.0 and e.get("hbm_frac", 0) <= 1.0 and e.get("mfma_frac", 0) <= 1.0, e
