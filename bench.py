@@ -956,7 +956,16 @@ def roofline_target(args, model, x, B, V, device):
     return rl_layer, rl_what, rl_x, tkey
 
 
-def _arm_watchdog(rank, world, limit=None, what="the run"):
+def _next_rung():
+    """Environment of the next, more conservative way to run the N > 1 step (the ladder of `launch_ranks`), or None at its end."""
+    if os.environ.get("DSW_BENCH_NO_GRAPH") == "1":
+        return None
+    if os.environ.get("DSW_BENCH_COLLECTIVES") == "eager":
+        return {"DSW_BENCH_COLLECTIVES": "eager", "DSW_BENCH_NO_GRAPH": "1"}
+    return {"DSW_BENCH_COLLECTIVES": "eager"}
+
+
+def _arm_watchdog(rank, world, limit=None, what="the run", retry=False):
     """A rank of an N > 1 run that is still alive after DSW_BENCH_TIMEOUT seconds (a collective that never completes)
     exits with an error instead of holding the node: the launcher (ours, or torchrun) then tears the job down.  Also
     used with a short limit around the FIRST replay of a graph that holds collectives."""
@@ -966,6 +975,18 @@ def _arm_watchdog(rank, world, limit=None, what="the run"):
         limit = float(os.environ.get("DSW_BENCH_TIMEOUT", "420")) * 0.9
 
     def bark():
+        nxt = _next_rung()
+        if retry and nxt is not None:
+            # launched by somebody else's torchrun (the driver's scaling run): nobody will start a second attempt for us,
+            # and a rank that exits takes the whole job down.  Every rank sits behind the same guard, so every rank
+            # replaces its own process image with the next, more conservative rung (same RANK / WORLD_SIZE / MASTER_*,
+            # a new process group behind its own store prefix - dsw_amd.parallel.init_from_env).
+            print("bench.py: rank %d/%d: %s still not finished after %.0f s - re-executing with %s" % (
+                rank, world, what, limit, nxt), file=sys.stderr, flush=True)
+            env = dict(os.environ, **nxt)
+            env["DSW_PG_ATTEMPT"] = str(int(os.environ.get("DSW_PG_ATTEMPT", "0") or 0) + 1)
+            sys.stdout.flush()
+            os.execve(sys.executable, [sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env)
         print("bench.py: rank %d/%d: %s still not finished after %.0f s - giving up" % (rank, world, what, limit),
               file=sys.stderr, flush=True)
         os._exit(124)
@@ -998,8 +1019,11 @@ def main():
 
     rank, world, local = init_from_env()
     assert world == args.gpus, (world, args.gpus)
+    # ranks started by somebody else's launcher (the driver's torchrun) climb down the ladder in place (see `_arm_watchdog`);
+    # under our own self-launch the launcher process does (launch_ranks)
+    external = os.environ.get("WORLD_SIZE") is not None and not os.environ.get("DSW_BENCH_LAUNCHER")
     if world > 1:
-        _arm_watchdog(rank, world)
+        _arm_watchdog(rank, world, retry=external)
     assert torch.cuda.is_available(), "bench.py measures the HIP path; a ROCm device is required"
     _native.load()
     local = local % torch.cuda.device_count()   # (gloo smoke runs of the N>1 path put two ranks on one device)
@@ -1146,13 +1170,19 @@ def main():
                 # every rank replays the same collectives in the same order: validate what the graph computes.  A replay
                 # that never completes must not cost the whole time limit: 90 s, then this rank exits and the launcher
                 # moves on to collectives outside the graph
-                guard = _arm_watchdog(rank, world, 90.0, "the first replay of the graph-captured exchange")
+                # (the guard stays armed over the agreement collective as well: a rank whose replay came back while another's
+                # did not would otherwise wait there for the whole time limit - every rank must reach the next rung together)
+                guard = _arm_watchdog(rank, world, float(os.environ.get("DSW_BENCH_GUARD_S", "90")),
+                                      "the first replay of the graph-captured exchange", retry=external)
+                if os.environ.get("DSW_BENCH_TEST_HANG") == "replay" and not os.environ.get("DSW_PG_ATTEMPT"):
+                    time.sleep(1e6)          # tests: a replay that never returns (first incarnation only)
                 g1.replay()
                 torch.cuda.synchronize()
-                guard.cancel()
                 same = torch.equal(bucket.bucket, want) or bool(
                     (bucket.bucket - want).abs().max() <= 1e-5 * want.abs().max().clamp_min(1e-30))
-                if all_ranks_agree(same):
+                agreed = all_ranks_agree(same)
+                guard.cancel()
+                if agreed:
                     graph, graph_multi, captured_sync = g1, (gm if args.steps >= GRAPH_STEPS else None), True
                 else:
                     capture_note = "captured exchange did not reproduce the eager result; collectives stay outside the graph"
@@ -1272,6 +1302,9 @@ def main():
     }
     if os.environ.get("DSW_BENCH_LAUNCHER"):
         out["config"]["launcher"] = os.environ["DSW_BENCH_LAUNCHER"]
+    if os.environ.get("DSW_PG_ATTEMPT"):
+        out["config"]["ladder"] = ("rung %d of the in-place fallback ladder (a guard fired in the rung before: the ranks re-executed "
+                                   "themselves under the same launcher)" % (int(os.environ["DSW_PG_ATTEMPT"]) + 1))
     if os.environ.get("DSW_HIP_LIB"):
         out["config"]["DSW_HIP_LIB"] = os.environ["DSW_HIP_LIB"]   # an A/B build stands in for the product library
     if bucket.active():

@@ -153,6 +153,57 @@ static __device__ __forceinline__ void gather_ell(const unsigned char* __restric
     }
 }
 
+#ifdef DSW_GATHER_N
+// The loop form with the NEXT batch's position word and weights requested in front of this batch's row reads: one dependent
+// LDS round trip per batch of four instead of two (positions -> rows).  ELL storage is padded to W % 4 == 0 entries per row,
+// so the look-ahead read of the last batch stays inside the row (ell_w) or is skipped.
+static __device__ __forceinline__ void gather_n(const unsigned char* __restrict__ row_idx, const float* __restrict__ row_val,
+                                                const int W, const int Wpad, const unsigned char* __restrict__ bufc, float (&acc)[4]) {
+    unsigned w = *reinterpret_cast<const unsigned*>(row_idx);
+    float4 v0 = *reinterpret_cast<const float4*>(row_val);
+    int j = 0;
+    for (; j + 4 <= W; j += 4) {
+        unsigned wn = 0u;
+        float4 vn = {0.f, 0.f, 0.f, 0.f};
+        if (j + 4 < Wpad) {
+            wn = *reinterpret_cast<const unsigned*>(row_idx + j + 4);
+            vn = *reinterpret_cast<const float4*>(row_val + j + 4);
+        }
+        const unsigned ix[4] = {(w & 0xffu) << 7, ((w >> 8) & 0xffu) << 7, ((w >> 16) & 0xffu) << 7, (w >> 24) << 7};
+        const float vv[4] = {v0.x, v0.y, v0.z, v0.w};
+        float4 d[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) d[t] = *reinterpret_cast<const float4*>(bufc + ix[t]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc[0] = fmaf(vv[t], d[t].x, acc[0]); acc[1] = fmaf(vv[t], d[t].y, acc[1]);
+            acc[2] = fmaf(vv[t], d[t].z, acc[2]); acc[3] = fmaf(vv[t], d[t].w, acc[3]);
+        }
+        w = wn; v0 = vn;
+    }
+    const int rem = W - j;      // 0..3 entries left: their positions and weights are here already
+    if (rem > 0) {
+        const float4 d0 = *reinterpret_cast<const float4*>(bufc + ((w & 0xffu) << 7));
+        float4 d1 = {0.f, 0.f, 0.f, 0.f}, d2 = d1;
+        if (rem > 1) d1 = *reinterpret_cast<const float4*>(bufc + (((w >> 8) & 0xffu) << 7));
+        if (rem > 2) d2 = *reinterpret_cast<const float4*>(bufc + (((w >> 16) & 0xffu) << 7));
+        acc[0] = fmaf(v0.x, d0.x, acc[0]); acc[1] = fmaf(v0.x, d0.y, acc[1]);
+        acc[2] = fmaf(v0.x, d0.z, acc[2]); acc[3] = fmaf(v0.x, d0.w, acc[3]);
+        if (rem > 1) {
+            acc[0] = fmaf(v0.y, d1.x, acc[0]); acc[1] = fmaf(v0.y, d1.y, acc[1]);
+            acc[2] = fmaf(v0.y, d1.z, acc[2]); acc[3] = fmaf(v0.y, d1.w, acc[3]);
+        }
+        if (rem > 2) {
+            acc[0] = fmaf(v0.z, d2.x, acc[0]); acc[1] = fmaf(v0.z, d2.y, acc[1]);
+            acc[2] = fmaf(v0.z, d2.z, acc[2]); acc[3] = fmaf(v0.z, d2.w, acc[3]);
+        }
+    }
+}
+#define GATHER(idx_, val_, wt_, buf_, acc_) gather_n(idx_, val_, wt_, W, buf_, acc_)
+#else
+#define GATHER(idx_, val_, wt_, buf_, acc_) gather_ell(idx_, val_, wt_, buf_, acc_)
+#endif
+
 // 8 consecutive ROWS of one channel column of a row-major image: two transposing reads (rows +0..3 at p, +4..7 at p + 256)
 static __device__ __forceinline__ bf16x8_t read_tr(const unsigned char* p) {
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -305,7 +356,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_bwd_dual_kernel(const DualA
                     const int i = grp + k * RPP;
                     if (k == 0 || i < n1) {
                         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                        gather_ell(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, bufX + cb, acc);
+                        GATHER(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, bufX + cb, acc);
                         *reinterpret_cast<uint4*>(bufT + (size_t)i * RB + cb) =
                             make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3]));
                         if (k == 0) {
@@ -322,7 +373,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_bwd_dual_kernel(const DualA
                 // ---- phase 2: U_2 = 2 L^T U_1 - U_0 on the tile rows -> split image; chunk phase 0: the X tile rows -> split image
                 {
                     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                    gather_ell(ell_idx + (size_t)grp * W, ell_val + (size_t)grp * W, Wt, bufT + cb, acc);
+                    GATHER(ell_idx + (size_t)grp * W, ell_val + (size_t)grp * W, Wt, bufT + cb, acc);
                     const float t2[4] = {fmaf(2.f, acc[0], -u0[0]), fmaf(2.f, acc[1], -u0[1]), fmaf(2.f, acc[2], -u0[2]), fmaf(2.f, acc[3], -u0[3])};
                     split_store(u2img, grp, c4, t2);
                     if (c == 0) {
@@ -337,6 +388,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_bwd_dual_kernel(const DualA
                 __syncthreads();   // C: images complete; nobody reads bufT of this chunk any more
                 DSW_STAMP(5);
                 // ---- phase 3: matrix cores
+#ifdef DSW_PRIO_MATRIX
+                __builtin_amdgcn_s_setprio(DSW_PRIO_MATRIX);
+#endif
                 int tv = tid;
                 asm volatile("" : "+v"(tv));          // opaque: everything below is recomputed here, not kept across the phases
                 const unsigned lane_ = (unsigned)tv & 63u, l15_ = lane_ & 15u, kc_ = lane_ >> 4, jw_ = ((unsigned)tv >> 6) & 3u;
@@ -435,6 +489,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_bwd_dual_kernel(const DualA
                     }
                 }
                 DSW_STAMP(6);
+#ifdef DSW_PRIO_MATRIX
+                __builtin_amdgcn_s_setprio(0);
+#endif
 #ifndef DSW_ABL_D3_NOD
                 __syncthreads();   // D: everybody has left the matrix phase: images, bufX, handoff slot readable / writable
 #endif

@@ -163,6 +163,57 @@ static __device__ __forceinline__ void gather_ell(const unsigned char* __restric
     }
 }
 
+#ifdef DSW_GATHER_N
+// The loop form with the NEXT batch's position word and weights requested in front of this batch's row reads: one dependent
+// LDS round trip per batch of four instead of two (positions -> rows).  ELL storage is padded to W % 4 == 0 entries per row,
+// so the look-ahead read of the last batch stays inside the row (ell_w) or is skipped.
+static __device__ __forceinline__ void gather_n(const unsigned char* __restrict__ row_idx, const float* __restrict__ row_val,
+                                                const int W, const int Wpad, const unsigned char* __restrict__ bufc, float (&acc)[4]) {
+    unsigned w = *reinterpret_cast<const unsigned*>(row_idx);
+    float4 v0 = *reinterpret_cast<const float4*>(row_val);
+    int j = 0;
+    for (; j + 4 <= W; j += 4) {
+        unsigned wn = 0u;
+        float4 vn = {0.f, 0.f, 0.f, 0.f};
+        if (j + 4 < Wpad) {
+            wn = *reinterpret_cast<const unsigned*>(row_idx + j + 4);
+            vn = *reinterpret_cast<const float4*>(row_val + j + 4);
+        }
+        const unsigned ix[4] = {(w & 0xffu) << 7, ((w >> 8) & 0xffu) << 7, ((w >> 16) & 0xffu) << 7, (w >> 24) << 7};
+        const float vv[4] = {v0.x, v0.y, v0.z, v0.w};
+        float4 d[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) d[t] = *reinterpret_cast<const float4*>(bufc + ix[t]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc[0] = fmaf(vv[t], d[t].x, acc[0]); acc[1] = fmaf(vv[t], d[t].y, acc[1]);
+            acc[2] = fmaf(vv[t], d[t].z, acc[2]); acc[3] = fmaf(vv[t], d[t].w, acc[3]);
+        }
+        w = wn; v0 = vn;
+    }
+    const int rem = W - j;      // 0..3 entries left: their positions and weights are here already
+    if (rem > 0) {
+        const float4 d0 = *reinterpret_cast<const float4*>(bufc + ((w & 0xffu) << 7));
+        float4 d1 = {0.f, 0.f, 0.f, 0.f}, d2 = d1;
+        if (rem > 1) d1 = *reinterpret_cast<const float4*>(bufc + (((w >> 8) & 0xffu) << 7));
+        if (rem > 2) d2 = *reinterpret_cast<const float4*>(bufc + (((w >> 16) & 0xffu) << 7));
+        acc[0] = fmaf(v0.x, d0.x, acc[0]); acc[1] = fmaf(v0.x, d0.y, acc[1]);
+        acc[2] = fmaf(v0.x, d0.z, acc[2]); acc[3] = fmaf(v0.x, d0.w, acc[3]);
+        if (rem > 1) {
+            acc[0] = fmaf(v0.y, d1.x, acc[0]); acc[1] = fmaf(v0.y, d1.y, acc[1]);
+            acc[2] = fmaf(v0.y, d1.z, acc[2]); acc[3] = fmaf(v0.y, d1.w, acc[3]);
+        }
+        if (rem > 2) {
+            acc[0] = fmaf(v0.z, d2.x, acc[0]); acc[1] = fmaf(v0.z, d2.y, acc[1]);
+            acc[2] = fmaf(v0.z, d2.z, acc[2]); acc[3] = fmaf(v0.z, d2.w, acc[3]);
+        }
+    }
+}
+#define GATHER(idx_, val_, wt_, buf_, acc_) gather_n(idx_, val_, wt_, W, buf_, acc_)
+#else
+#define GATHER(idx_, val_, wt_, buf_, acc_) gather_ell(idx_, val_, wt_, buf_, acc_)
+#endif
+
 // NST / NS1: register-stage slots per thread for the gather list (ceil(max_n2 / 64)) and for S1 (ceil(max_n1 / 64));
 // the tile is 64 rows = slot 0.  NCB = Fout / 16 column blocks; a wave owns ONE column block (its W fragments stay in
 // registers) and RBW = NCB / 2 of the four 16-row blocks of the tile.
@@ -286,12 +337,16 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
 #endif
         }
         // ---- phase 1: T1 = L X on S1; the tile rows (slot 0) also leave their split images of X and T1
+#ifdef DSW_GATHER_N
+#pragma unroll 1
+#else
 #pragma unroll
+#endif
         for (int k = 0; k < NS1; ++k) {
             const int i = grp + k * RPP;
             if (k == 0 || i < n1) {               // slot 0 = the tile rows (64 <= n1 whenever the tile is full)
                 float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                gather_ell(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, bufX + cb, acc);
+                GATHER(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, bufX + cb, acc);
                 const uint4 packed = make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]),
                                                 __float_as_uint(acc[3]));
                 *reinterpret_cast<uint4*>(bufT + (size_t)i * RB + cb) = packed;
@@ -312,7 +367,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
             const int i = grp;
             if (FULL || i < rt) {
                 float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                gather_ell(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, bufT + cb, acc);
+                GATHER(ell_idx + (size_t)i * W, ell_val + (size_t)i * W, Wt, bufT + cb, acc);
                 const float4 u = *reinterpret_cast<const float4*>(bufX + (size_t)i * RB + cb);
                 const float t2[4] = {fmaf(2.f, acc[0], -u.x), fmaf(2.f, acc[1], -u.y), fmaf(2.f, acc[2], -u.z), fmaf(2.f, acc[3], -u.w)};
                 if ((FULL && KEEP) || (!FULL && P.T2 != nullptr))
@@ -330,6 +385,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
         }
 #endif
         // ---- phase 3: Y[tile rows, 16 cbk ..+16] = [X | T1 | T2] W + bias on the matrix cores, from the split images
+#ifdef DSW_PRIO_MATRIX
+        __builtin_amdgcn_s_setprio(DSW_PRIO_MATRIX);
+#endif
         f32x4_t acc[RBW];
         unsigned fro[RBW];
 #pragma unroll
@@ -375,6 +433,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
                 st16(P.Y + (size_t)b * ((size_t)P.V * P.Fout * 4) +
                          (unsigned)(rows[FULL ? row : min(row, rt - 1)] * P.Fout * 4 + (16 * cbk + 4 * kc) * 4), acc[r]);
         }
+#ifdef DSW_PRIO_MATRIX
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #ifndef DSW_STAGE_EARLY
         // next sample's rows -> the (single) input buffer, BEHIND the matrix phase (bufX is free since barrier C, the next
         // barrier A publishes it): the loads get the whole sample to land

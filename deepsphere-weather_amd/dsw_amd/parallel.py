@@ -36,12 +36,26 @@ def init_from_env(backend: str | None = None):
                 + (["DSW_FORCE_GRAD_SYNC=1 (gradient exchange in a one-rank world)"] if force else [])), file=sys.stderr, flush=True)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
+        attempt = int(os.environ.get("DSW_PG_ATTEMPT", "0") or 0)
+        if attempt > 0:
+            # A rank that re-executed itself (bench.py: the first replay of a graph-captured exchange never came back) joins a
+            # NEW process group under the same launcher: the launcher's store still holds the keys of the first group
+            # (barrier counts, the communicator id), so this incarnation talks through its own key prefix.  Under torchrun
+            # the agent hosts the store; without it rank 0 does (and its old store died with the old process image).
+            from datetime import timedelta
+
+            agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
+            store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world,
+                                  is_master=(rank == 0 and not agent_store), timeout=timedelta(seconds=120),
+                                  wait_for_workers=False)
+            kw["store"] = dist.PrefixStore("dsw_attempt_%d" % attempt, store)
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local))
+                                    device_id=torch.device("cuda", local), **kw)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 

@@ -1344,6 +1344,44 @@ def test_bench_one_rank_world_captures_the_exchange():
     assert "20 steps per graph" in out["config"]["launch"]        # --steps 20: one replay of a 20-step graph
 
 
+def test_bench_under_foreign_torchrun_walks_the_ladder_in_place():
+    """the driver starts the N > 1 bench under ITS torchrun, so nobody re-launches a failed attempt.  A
+    first replay of the graph-captured exchange that never returns (simulated: DSW_BENCH_TEST_HANG=replay) must end in ONE
+    JSON line from the next rung - the ranks re-execute themselves into a new process group (own store prefix) with the
+    collectives issued after the replay - and the remaining rungs (collectives outside the graph, eager launches) must
+    each print one complete line as well: `allreduce_us`, `grad_sync.identical`, `config.grad_handling`."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DSW_DIST_BACKEND", "DSW_PG_ATTEMPT",
+                                                             "DSW_BENCH_LAUNCHER", "DSW_BENCH_COLLECTIVES", "DSW_BENCH_NO_GRAPH")}
+    args = ["--gpus", "1", "--steps", "20", "--warmup", "2", "--min-timed-ms", "100", "--no-cpu-baseline", "--no-roofline"]
+
+    def run(extra):
+        env = dict(base, DSW_FORCE_GRAD_SYNC="1", **extra)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), *args],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2500:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+        assert len(lines) == 1, (len(lines), r.stderr[-1500:])
+        out = json.loads(lines[0])
+        assert out["grad_sync"]["identical"] is True and out["allreduce_us"] > 0 and "bucket" in out["config"]["grad_handling"]
+        return out, r.stderr
+
+    out, err = run({"DSW_BENCH_TEST_HANG": "replay", "DSW_BENCH_GUARD_S": "6"})
+    assert "re-executing" in err, err[-1500:]
+    assert "issued after every replay" in out["config"]["launch"] and "rung 2" in out["config"]["ladder"], out["config"]
+    out, _ = run({})
+    assert "captured in the graph" in out["config"]["launch"] and "ladder" not in out["config"], out["config"]
+    out, _ = run({"DSW_BENCH_COLLECTIVES": "eager"})
+    assert "issued after every replay" in out["config"]["launch"], out["config"]
+    out, _ = run({"DSW_BENCH_COLLECTIVES": "eager", "DSW_BENCH_NO_GRAPH": "1"})
+    assert out["config"]["launch"].startswith("eager"), out["config"]
+
+
 @pytest.mark.parametrize("dt", [torch.float32])
 def test_resblock_fused_tail_vs_fp64(dt):
     """ReZero scale + residual add in the epilogue of the block's last convolution
