@@ -172,6 +172,9 @@ static bool mix_first(int64_t Fin, int64_t Fout, int64_t K) {
 
 extern "C" {
 
+// a plan built against another version of include/dsw_hip.h (the struct grew): refuse it instead of reading past its end
+#define DSW_PLAN_CHECK(p_) do { if ((p_) != nullptr && (p_)->struct_bytes != (int64_t)sizeof(dsw_hop2_plan)) return DSW_ERR_BAD_ARG; } while (0)
+#define DSW_PLAN_OK(p_) ((p_) == nullptr || (p_)->struct_bytes == (int64_t)sizeof(dsw_hop2_plan))
 int dsw_version(void) { return DSW_VERSION; }
 
 int dsw_build_flags(void) { return g_build_flags.load(std::memory_order_relaxed); }
@@ -305,6 +308,7 @@ int dsw_remap_csr(const dsw_remap_plan* plan, const int32_t* rowptr, const int32
 int dsw_spmm2_fused(const dsw_hop2_plan* plan, int64_t V, const void* U, const void* Z1, const void* Z1b,
                     const void* Z2, void* Y1, void* Y2, int64_t B, int64_t C, float a1, float b1, float d1,
                     float a2, float b2, float c2, int dtype, dsw_stream_t stream) {
+    DSW_PLAN_CHECK(plan);
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     if (V < 0 || B < 0 || C < 0) return DSW_ERR_BAD_ARG;
     trace_start(stream);
@@ -316,6 +320,7 @@ int dsw_spmm2_fused(const dsw_hop2_plan* plan, int64_t V, const void* U, const v
 
 int dsw_spmm_staged(const dsw_hop2_plan* plan, int64_t V, const void* U, const void* Z, const void* Z2, void* Y,
                     int64_t B, int64_t C, float a, float b, float c, int dtype, dsw_stream_t stream, int stream_out) {
+    DSW_PLAN_CHECK(plan);
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     if (V < 0 || B < 0 || C < 0) return DSW_ERR_BAD_ARG;
     trace_start(stream);
@@ -324,7 +329,9 @@ int dsw_spmm_staged(const dsw_hop2_plan* plan, int64_t V, const void* U, const v
     return rc;
 }
 
-int dsw_spmm_staged_supported(const dsw_hop2_plan* plan, int64_t C, int dtype) { return dsw_spmm1s_supported(plan, C, dtype); }
+int dsw_spmm_staged_supported(const dsw_hop2_plan* plan, int64_t C, int dtype) {
+    return DSW_PLAN_OK(plan) ? dsw_spmm1s_supported(plan, C, dtype) : 0;
+}
 
 static int cheb_basis_fwd_impl(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V,
                                int64_t nnz, const void* X, void* T, int64_t B, int64_t C, int64_t K, int dtype,
@@ -427,6 +434,7 @@ static int cheb_basis_adj_impl(const int32_t* rowptr_t, const int32_t* colind_t,
 int dsw_cheb_basis_fwd(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V,
                        int64_t nnz, const void* X, void* T, int64_t B, int64_t C, int64_t K, int dtype,
                        dsw_stream_t stream, const dsw_hop2_plan* plan) {
+    DSW_PLAN_CHECK(plan);
     trace_start(stream);
     const int rc = cheb_basis_fwd_impl(rowptr, colind, vals, V, nnz, X, T, B, C, K, dtype, stream, plan);
     trace_mark(stream, DSW_ROLE_BASIS_FWD, V, C, K);
@@ -436,6 +444,7 @@ int dsw_cheb_basis_fwd(const int32_t* rowptr, const int32_t* colind, const float
 int dsw_cheb_basis_adj(const int32_t* rowptr_t, const int32_t* colind_t, const float* vals_t, int64_t V,
                        int64_t nnz, void* G0, void* Grest, int64_t B, int64_t C, int64_t K, int dtype,
                        dsw_stream_t stream, const dsw_hop2_plan* plan_t, void* spare) {
+    DSW_PLAN_CHECK(plan_t);
     trace_start(stream);
     const int rc = cheb_basis_adj_impl(rowptr_t, colind_t, vals_t, V, nnz, G0, Grest, B, C, K, dtype, stream, plan_t, spare, 0);
     trace_mark(stream, DSW_ROLE_BASIS_ADJ, V, C, K);
@@ -456,6 +465,7 @@ int dsw_cheb_mix_fwd(const void* X, const void* T, const void* W, const void* bi
 int dsw_cheb_mix_first(int64_t Fin, int64_t Fout, int64_t K) { return mix_first(Fin, Fout, K) ? 1 : 0; }
 
 int dsw_cheb_bwd_needs_basis(const dsw_hop2_plan* plan_t, int64_t V, int64_t Fin, int64_t Fout, int64_t K, int dtype) {
+    DSW_PLAN_CHECK(plan_t);
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     if (Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
     if (K == 1 || mix_first(Fin, Fout, K)) return 0;
@@ -463,6 +473,7 @@ int dsw_cheb_bwd_needs_basis(const dsw_hop2_plan* plan_t, int64_t V, int64_t Fin
 }
 
 int dsw_cheb_fwd_path(const dsw_hop2_plan* plan, int64_t Fin, int64_t Fout, int64_t K, int dtype) {
+    DSW_PLAN_CHECK(plan);
     if (dtype != DSW_F32 && dtype != DSW_BF16) return DSW_ERR_BAD_DTYPE;
     if (Fin <= 0 || Fout <= 0 || K <= 0) return DSW_ERR_BAD_ARG;
     if (mix_first(Fin, Fout, K)) return DSW_FWD_MIX_FIRST;
@@ -575,6 +586,7 @@ int dsw_cheb_fwd_ws(const int32_t* rowptr, const int32_t* colind, const float* v
                     const void* X, const void* W, const void* bias, void* Y, int64_t ldy, void* T, int64_t B, int64_t Fin,
                     int64_t Fout, int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan, int act,
                     const void* scale, const void* R, int64_t ldr, void* workspace, int64_t workspace_bytes) {
+    DSW_PLAN_CHECK(plan);
     return cheb_fwd_impl(rowptr, colind, vals, V, nnz, X, W, bias, Y, T, B, Fin, Fout, K, dtype, stream, plan, act,
                          scale, R, ldr, ldy, workspace, workspace_bytes);
 }
@@ -582,6 +594,7 @@ int dsw_cheb_fwd_ws(const int32_t* rowptr, const int32_t* colind, const float* v
 int dsw_cheb_fwd_act(const int32_t* rowptr, const int32_t* colind, const float* vals, int64_t V, int64_t nnz,
                      const void* X, const void* W, const void* bias, void* Y, void* T, int64_t B, int64_t Fin,
                      int64_t Fout, int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan, int act) {
+    DSW_PLAN_CHECK(plan);
     return cheb_fwd_impl(rowptr, colind, vals, V, nnz, X, W, bias, Y, T, B, Fin, Fout, K, dtype, stream, plan, act,
                          nullptr, nullptr, 0, 0);
 }
@@ -590,6 +603,7 @@ int dsw_cheb_fwd_res(const int32_t* rowptr, const int32_t* colind, const float* 
                      const void* X, const void* W, const void* bias, void* Y, int64_t ldy, void* T, int64_t B, int64_t Fin,
                      int64_t Fout, int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan, int act,
                      const void* scale, const void* R, int64_t ldr) {
+    DSW_PLAN_CHECK(plan);
     return cheb_fwd_impl(rowptr, colind, vals, V, nnz, X, W, bias, Y, T, B, Fin, Fout, K, dtype, stream, plan, act,
                          scale, R, ldr, ldy);
 }
@@ -747,6 +761,7 @@ int dsw_cheb_bwd(const int32_t* rowptr_t, const int32_t* colind_t, const float* 
                  int64_t nnz, const void* X, const void* T, const void* W, const void* dY, void* dX, void* dW,
                  void* db, void* workspace, int64_t workspace_bytes, int64_t B, int64_t Fin, int64_t Fout,
                  int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan_t) {
+    DSW_PLAN_CHECK(plan_t);
     return cheb_bwd_impl(rowptr_t, colind_t, vals_t, V, nnz, X, T, W, dY, dX, dW, db, workspace, workspace_bytes, B, Fin,
                          Fout, K, dtype, stream, plan_t, nullptr, nullptr, 0, 0);
 }
@@ -756,6 +771,7 @@ int dsw_cheb_bwd_res(const int32_t* rowptr_t, const int32_t* colind_t, const flo
                      void* db, void* workspace, int64_t workspace_bytes, int64_t B, int64_t Fin, int64_t Fout,
                      int64_t K, int dtype, dsw_stream_t stream, const dsw_hop2_plan* plan_t, const void* scale,
                      const void* dX_add, int64_t ld_add, int accumulate_dw) {
+    DSW_PLAN_CHECK(plan_t);
     if (accumulate_dw && B * V == 0) return DSW_OK;        // an empty shard adds nothing
     return cheb_bwd_impl(rowptr_t, colind_t, vals_t, V, nnz, X, T, W, dY, dX, dW, db, workspace, workspace_bytes, B,
                          Fin, Fout, K, dtype, stream, plan_t, scale, dX_add, ld_add, accumulate_dw ? 1 : 0);

@@ -388,9 +388,6 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_bwd_dual_kernel(const DualA
                 __syncthreads();   // C: images complete; nobody reads bufT of this chunk any more
                 DSW_STAMP(5);
                 // ---- phase 3: matrix cores
-#ifdef DSW_PRIO_MATRIX
-                __builtin_amdgcn_s_setprio(DSW_PRIO_MATRIX);
-#endif
                 int tv = tid;
                 asm volatile("" : "+v"(tv));          // opaque: everything below is recomputed here, not kept across the phases
                 const unsigned lane_ = (unsigned)tv & 63u, l15_ = lane_ & 15u, kc_ = lane_ >> 4, jw_ = ((unsigned)tv >> 6) & 3u;
@@ -489,9 +486,6 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_bwd_dual_kernel(const DualA
                     }
                 }
                 DSW_STAMP(6);
-#ifdef DSW_PRIO_MATRIX
-                __builtin_amdgcn_s_setprio(0);
-#endif
 #ifndef DSW_ABL_D3_NOD
                 __syncthreads();   // D: everybody has left the matrix phase: images, bufX, handoff slot readable / writable
 #endif

@@ -4,7 +4,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
-#define DSW_VERSION 100  // 0.1.0
+#define DSW_VERSION 101  // 0.1.1: dsw_hop2_plan carries its own size (struct_bytes)
 
 // error codes returned by every C-ABI entry point (0 = ok)
 #define DSW_OK 0

@@ -385,9 +385,6 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
         }
 #endif
         // ---- phase 3: Y[tile rows, 16 cbk ..+16] = [X | T1 | T2] W + bias on the matrix cores, from the split images
-#ifdef DSW_PRIO_MATRIX
-        __builtin_amdgcn_s_setprio(DSW_PRIO_MATRIX);
-#endif
         f32x4_t acc[RBW];
         unsigned fro[RBW];
 #pragma unroll
@@ -422,6 +419,31 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
             for (int r = 0; r < RBW; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], th[r], acc[r], 0, 0, 0);
         }
 #endif
+#ifdef DSW_F3_YBOUNCE
+        // A/B build: the Y tile through LDS (the dead input buffer; rows padded to Fout * 4 + 16 bytes: conflict-free 16-byte
+        // writes), so that every wave instruction stores whole rows - 1 KiB contiguous - instead of 64-byte quarters of 16 rows
+        if constexpr (FULL) {
+            const unsigned yrb = (unsigned)P.Fout * 4u, ypad = yrb + 16u;
+#pragma unroll
+            for (int r = 0; r < RBW; ++r) {
+                const unsigned row = 16u * (rb0 + r) + l15;
+                if (P.relu) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[r][t] = acc[r][t] < 0.f ? 0.f : acc[r][t];
+                }
+                *reinterpret_cast<f32x4_t*>(bufX + row * ypad + (16u * cbk + 4u * kc) * 4u) = acc[r];
+            }
+            __syncthreads();   // E: the tile is complete
+            const unsigned lpr = yrb >> 4;                       // 16-byte lanes per row (8 or 16)
+            char* ydst = P.Y + (size_t)b * ((size_t)P.V * P.Fout * 4);
+            for (unsigned q = (unsigned)tid; q < 64u * lpr; q += NTHREADS) {
+                const unsigned row = q / lpr, c16 = q - row * lpr;
+                const f32x4_t v = *reinterpret_cast<const f32x4_t*>(bufX + row * ypad + c16 * 16u);
+                st16(ydst + ((unsigned)rows[row] * yrb + c16 * 16u), v);
+            }
+            __syncthreads();   // F: the buffer is free for the next sample's rows
+        } else
+#endif
 #pragma unroll
         for (int r = 0; r < RBW; ++r) {   // lane: row 16 (rb0 + r) + l15, output channels 16 cbk + 4 kc .. + 3
             const int row = 16 * (rb0 + r) + l15;
@@ -433,9 +455,6 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
                 st16(P.Y + (size_t)b * ((size_t)P.V * P.Fout * 4) +
                          (unsigned)(rows[FULL ? row : min(row, rt - 1)] * P.Fout * 4 + (16 * cbk + 4 * kc) * 4), acc[r]);
         }
-#ifdef DSW_PRIO_MATRIX
-        __builtin_amdgcn_s_setprio(0);
-#endif
 #ifndef DSW_STAGE_EARLY
         // next sample's rows -> the (single) input buffer, BEHIND the matrix phase (bufX is free since barrier C, the next
         // barrier A publishes it): the loads get the whole sample to land

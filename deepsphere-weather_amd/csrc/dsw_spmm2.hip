@@ -276,7 +276,8 @@ static size_t hop2_lds_bytes(const dsw_hop2_plan* plan, int row_bytes, bool sing
 
 // 1 if the fused kernel can run this plan / shape (LDS fits, rows are whole 16-byte lanes)
 int dsw_spmm2_supported(const dsw_hop2_plan* plan, int64_t C, int dtype) {
-    if (!plan || plan->hops == 1 || plan->n_tiles <= 0 || plan->reserved <= 0) return 0;
+    if (!plan || plan->struct_bytes != (int64_t)sizeof(dsw_hop2_plan)) return 0;   // (another version of the header: see dsw_hip.h)
+    if (plan->hops == 1 || plan->n_tiles <= 0 || plan->reserved <= 0) return 0;
     const int es = dtype == DSW_BF16 ? 2 : 4;
     int64_t row_bytes = C * es;
     if (row_bytes % 16 != 0) return 0;

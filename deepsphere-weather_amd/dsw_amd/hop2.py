@@ -48,6 +48,7 @@ class Hop2PlanStruct(ctypes.Structure):
         ("ell_val", ctypes.c_void_p),         # float32 [n_tiles][64][ell_w] (padding: 0)
         ("ell2", ctypes.c_void_p),            # two-hop plans: per tile [max_n1][W] fp32 values + [max_n1][W] u8 positions (LDS image)
         ("ell2_stride", ctypes.c_int64),      # bytes between the images of consecutive tiles
+        ("struct_bytes", ctypes.c_int64),     # sizeof(dsw_hop2_plan) as this binding declares it (checked by every entry point)
     ]
 
 
@@ -171,6 +172,7 @@ class Hop2Plan:
             arrs["lcol"].data_ptr(), arrs["lval"].data_ptr(), 1 if self.explicit_tiles else 0, self.hops,
             self.ell_w, arrs["ell_pos"].data_ptr() if self.ell_w else None, arrs["ell_val"].data_ptr() if self.ell_w else None,
             arrs["ell2"].data_ptr() if self.ell2 is not None else None, self.ell2_stride,
+            ctypes.sizeof(Hop2PlanStruct),
         )
         self._dev = (device, arrs)   # keeps the device tensors alive
         self._struct = st

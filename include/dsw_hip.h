@@ -72,6 +72,10 @@ typedef struct dsw_hop2_plan {
      * longest row.  NULL: the kernels expand the local CSR themselves. */
     const unsigned char* ell2;
     int64_t ell2_stride;
+    int64_t struct_bytes;      /* sizeof(dsw_hop2_plan) of the header the CALLER was built with (since 0.1.1).  Every entry point
+                                  that takes a plan refuses one of another size (DSW_ERR_BAD_ARG; the *_supported predicates
+                                  say 0): the struct grew between versions, and a caller built against an older header would
+                                  otherwise have the library read past the end of its struct. */
 } dsw_hop2_plan;
 
 /* Library version (major*10000 + minor*100 + patch). */

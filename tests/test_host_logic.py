@@ -27,12 +27,34 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     lib = _native.load()
-    assert lib.dsw_version() >= 100
+    assert lib.dsw_version() >= 101
     assert lib.dsw_strerror(0) == b"ok" and b"workspace" in lib.dsw_strerror(-3)
     # argument validation needs no GPU: negative sizes / bad dtype are rejected before any launch
     assert lib.dsw_spmm_csr(None, None, None, -1, 1, 0, None, None, 1, 1, 1.0, None, 0.0, None, 0.0, 0, None) == -1
     assert lib.dsw_cheb_bwd_workspace_bytes(16, 49152, 32, 64, 3, 0) > 2 * 16 * 49152 * 32 * 4
     assert lib.dsw_cheb_bwd_workspace_bytes(1, 1, 0, 1, 1, 0) < 0
+
+
+def test_plan_struct_of_another_header_version_is_refused():
+    """dsw_hop2_plan grew between versions; a caller built against an older header passes a shorter struct.  The plan
+    now carries sizeof(dsw_hop2_plan) as its caller knows it, and every entry point that takes a plan refuses another size
+    before reading anything else (the predicates say "not supported")."""
+    from dsw_amd import _native
+    from dsw_amd.hop2 import Hop2PlanStruct
+
+    lib = _native.load()
+    assert lib.dsw_version() >= 101
+    st = Hop2PlanStruct()
+    st.n_tiles, st.tile_rows, st.max_n1, st.max_n2, st.reserved, st.hops = 4, 64, 100, 150, 9, 2
+    st.struct_bytes = ctypes.sizeof(Hop2PlanStruct) - 8          # what a build against the previous header would say: garbage / short
+    p = ctypes.byref(st)
+    assert lib.dsw_cheb_fwd_path(p, 32, 64, 3, 0) == -1          # DSW_ERR_BAD_ARG
+    assert lib.dsw_cheb_bwd_needs_basis(p, 4096, 32, 64, 3, 0) == -1
+    assert lib.dsw_spmm2_supported(p, 32, 0) == 0 and lib.dsw_spmm_staged_supported(p, 32, 0) == 0
+    assert lib.dsw_cheb_fwd(None, None, None, 64, 0, None, None, None, None, None, 1, 32, 64, 3, 0, None, p) == -1
+    assert lib.dsw_cheb_bwd(None, None, None, 64, 0, None, None, None, None, None, None, None, None, 0, 1, 32, 64, 3, 0, None, p) == -1
+    st.struct_bytes = ctypes.sizeof(Hop2PlanStruct)
+    assert lib.dsw_spmm2_supported(ctypes.byref(st), 32, 0) == 1
 
 
 def test_cpu_tensors_fail_loudly():
