@@ -1,4 +1,5 @@
-// WHOLE backward of a K = 3, 32 -> 64 fp32 ConvCheb layer in ONE launch (+ the partial reduce), in the DUAL form:
+// WHOLE backward of a K = 3, 32 -> 64 (or 32 -> 32: one chunk phase, template parameter NCH) fp32 ConvCheb layer in ONE launch
+// (+ the partial reduce), in the DUAL form:
 //
 //     U_0 = dY,   U_1 = L^T dY,   U_2 = 2 L^T U_1 - dY          (the Chebyshev basis of dY under L^T, 64 channels)
 //     dX    = sum_k U_k W_k^T                                    (autograd of layers.py:163-178)
@@ -43,11 +44,10 @@ namespace {
 
 constexpr int NTHREADS = 512;
 constexpr int RB = 128;             // bytes of one staged row (a 32-channel chunk of a dY row) and of a dX / X row
-constexpr int YB = 256;             // bytes of a dY row in HBM
 constexpr int RPP = 64;             // rows per pass of the 512 threads
 constexpr int IMG_TERM = 64 * 64;   // one bf16 term of one image: [64 rows][32 bf16]
 constexpr int IMG_PLANE = 3 * IMG_TERM;
-constexpr int SLAB = (3 * 32 + 1) * 64;   // floats of one partial slab: [(k, f) | db][o]
+constexpr int SLAB = (3 * 32 + 1) * 64;   // floats of one partial slab: [(k, f) | db][o] at Fout = 64 (what the scratch is sized for)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -63,7 +63,7 @@ struct DualArgs {
     const char* dY;
     const char* X;
     char* dX;            // may be null (the input needs no gradient)
-    const float* W;      // [32][3][64]
+    const float* W;      // [32][3][Fout]
     float* partial;      // [gridDim.x][SLAB] or null (no parameter gradients wanted)
     char* pscr;          // [gridDim.x][8 KB]: the chunk-0 partial of dX on its way from waves 0-3 to waves 4-7 (L2-resident)
     int V, n_tiles, max_n1, max_n2, bufx_rows;
@@ -232,8 +232,12 @@ static __device__ __forceinline__ bf16x8_t read_tr(const unsigned char* p) {
 #endif
 // NST / NS1: register-stage slots per thread for the gather list (ceil(max_n2 / 64)) and for the one-ring (ceil(max_n1 / 64)).
 // Every tile is FULL (64 rows: V % 64 == 0, tiles of consecutive rows) - a condition of eligibility.
-template <int NST, int NS1>
+// NCH: 32-channel chunks of a dY row (Fout = 32 NCH).  NCH = 1 (32 -> 32 layers): ONE chunk phase per sample - waves 0-3 run the
+// whole dX reduction (no partial travels), waves 4-7 the dW products of the same phase.
+template <int NST, int NS1, int NCH = 2>
 __global__ __launch_bounds__(NTHREADS, 4) void cheb3_bwd_dual_kernel(const DualArgs P) {
+    constexpr int YB = RB * NCH;            // bytes of a dY row in HBM
+    constexpr int FO = 32 * NCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* bufX = lds;                                              // [bufx_rows][128] dY chunk rows of the 2-ring; U_2 image after hop 1
     unsigned char* bufT = bufX + (size_t)P.bufx_rows * RB;                  // [max_n1][128] U_1 on the 1-ring; dX partial handoff after hop 2
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_bwd_dual_kernel(const DualA
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         float f[8];
-        const float* src = P.W + ((size_t)(16 * cbk + l15) * 3 + s) * 64 + 32 * gsel + 8 * kc;
+        const float* src = P.W + ((size_t)(16 * cbk + l15) * 3 + s) * FO + 32 * (gsel < NCH ? gsel : 0) + 8 * kc;   // (NCH = 1: waves 4-7 never use theirs)
         const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
         f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
         split3x8(f, wh[s], wm[s], wl[s]);
@@ -334,13 +338,13 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_bwd_dual_kernel(const DualA
 
         for (int b = b_begin; b < b_end; ++b) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
+            for (int c = 0; c < NCH; ++c) {
                 DSW_STAMP(0);
                 __syncthreads();   // A: the rows of (b, c) are complete in bufX
                 DSW_STAMP(1);
                 {   // next chunk's rows (and, in chunk phase 1, the next sample's X tile row): in flight under phases 1, 2 and 3
-                    const int bn = c == 0 ? b : (b + 1 < b_end ? b + 1 : b);
-                    const char* src = P.dY + (size_t)bn * y_sample + (c == 0 ? RB : 0);
+                    const int bn = c + 1 < NCH ? b : (b + 1 < b_end ? b + 1 : b);
+                    const char* src = P.dY + (size_t)bn * y_sample + (c + 1 < NCH ? (c + 1) * RB : 0);
 #pragma unroll
                     for (int k = 0; k < NST; ++k)
 #ifdef DSW_ABL_D3_NOLOAD
@@ -379,7 +383,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_bwd_dual_kernel(const DualA
                     if (c == 0) {
                         const float xf[4] = {__uint_as_float(xq[0]), __uint_as_float(xq[1]), __uint_as_float(xq[2]), __uint_as_float(xq[3])};
                         split_store(ximg, grp, c4, xf);
-                    } else {
+                    }
+                    if (c == NCH - 1) {
                         const int bn = b + 1 < b_end ? b + 1 : b;
                         xq = *reinterpret_cast<const u32x4*>(P.X + (size_t)bn * x_sample + ((unsigned)rows[grp] * (unsigned)RB + cb));
                     }
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_bwd_dual_kernel(const DualA
                     // workgroup, three barriers apart), requested here and added behind the products.
                     char* slot = P.pscr + (size_t)blockIdx.x * 8192 + ((jw_ * 2u) * 64u + lane_) * 16u;
                     f32x4_t h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0;
-                    if (c == 1) {
+                    if (NCH == 2 && c == 1) {
                         h0 = *reinterpret_cast<const f32x4_t*>(slot);
                         h1 = *reinterpret_cast<const f32x4_t*>(slot + 1024);
                     }
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_bwd_dual_kernel(const DualA
 #pragma unroll
                         for (int r = 0; r < 2; ++r) pacc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], th[r], pacc[r], 0, 0, 0);
                     }
-                    if (c == 0) {
+                    if (NCH == 2 && c == 0) {
                         *reinterpret_cast<f32x4_t*>(slot) = pacc[0];
                         *reinterpret_cast<f32x4_t*>(slot + 1024) = pacc[1];
                     } else if (P.dX != nullptr) {
@@ -502,13 +507,15 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_bwd_dual_kernel(const DualA
 
     // ---- the workgroup's slab of dW / db partials: [(s, f)][o] rows, then the db row
     if (P.partial != nullptr) {
-        float* slab = P.partial + (size_t)blockIdx.x * SLAB;
-        const int cdw = 1 - gsel;
+        float* slab = P.partial + (size_t)blockIdx.x * ((3 * 32 + 1) * FO);
+        const int cdw = 1 - gsel;               // the chunk whose dW this wave accumulated (NCH = 1: waves 0-3 none)
+        if (cdw < NCH) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
-            *reinterpret_cast<f32x4_t*>(slab + (size_t)(s * 32 + 16 * fb + l15) * 64 + 32 * cdw + 16 * ob + 4 * kc) = dwa[s];
+            for (int s = 0; s < 3; ++s)
+                *reinterpret_cast<f32x4_t*>(slab + (size_t)(s * 32 + 16 * fb + l15) * FO + 32 * cdw + 16 * ob + 4 * kc) = dwa[s];
+        }
         __syncthreads();
-        if (tid < 64) slab[(size_t)96 * 64 + tid] = dbs[tid];
+        if (tid < FO) slab[(size_t)96 * FO + tid] = dbs[tid];
     }
 }
 
@@ -521,13 +528,20 @@ size_t dual_lds_bytes(const dsw_hop2_plan* plan) {
     return (s + 15) & ~(size_t)15;
 }
 
-template <int NST, int NS1>
+template <int NST, int NS1, int NCH>
 int launch_dual(const DualArgs& A, long nwg, size_t lds, hipStream_t stream) {
-    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)cheb3_bwd_dual_kernel<NST, NS1>,
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)cheb3_bwd_dual_kernel<NST, NS1, NCH>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DSW_ERR_LAUNCH;
-    DSW_LAUNCH((cheb3_bwd_dual_kernel<NST, NS1>), dim3((unsigned)nwg), dim3(NTHREADS), lds, stream, A);
+    DSW_LAUNCH((cheb3_bwd_dual_kernel<NST, NS1, NCH>), dim3((unsigned)nwg), dim3(NTHREADS), lds, stream, A);
     return dsw_check_launch();
+}
+template <int NCH>
+int launch_dual_n(const int nst, const int ns1, const DualArgs& A, long nwg, size_t lds, hipStream_t stream) {
+    if (nst == 3 && ns1 == 2) return launch_dual<3, 2, NCH>(A, nwg, lds, stream);
+    if (nst == 2 && ns1 <= 2) return launch_dual<2, 2, NCH>(A, nwg, lds, stream);
+    if (nst == 3) return launch_dual<3, 3, NCH>(A, nwg, lds, stream);
+    return launch_dual<4, 4, NCH>(A, nwg, lds, stream);
 }
 
 // persistent workgroups: two per CU, a multiple of 8 (one XCD per residue class), never more than there are items
@@ -544,9 +558,12 @@ long dual_grid(long n_items) {
 int dsw_cheb3_bwd_dual_eligible(const dsw_hop2_plan* plan_t, int64_t V, int64_t Fin, int64_t Fout, int64_t K, int dtype) {
     static const char* env = dsw_diag_env("DSW_BWD_DUAL");   // "0": separate dgrad / wgrad / adjoint launches (diagnostics / A-B)
     if (env && env[0] == '0') return 0;
-    if (dtype != DSW_F32 || K != 3 || Fin != 32 || Fout != 64) return 0;
+    if (dtype != DSW_F32 || K != 3 || Fin != 32 || (Fout != 64 && Fout != 32)) return 0;
+#ifdef DSW_D3_NO_FOUT32      // A/B builds: 32 -> 32 layers on the route over the basis planes, as before round 6
+    if (Fout == 32) return 0;
+#endif
     if (!plan_t || plan_t->hops == 1 || plan_t->tile_rows != 64 || plan_t->explicit_tiles || !dsw_spmm2_supported(plan_t, Fin, dtype)) return 0;
-    if (V <= 0 || V % 64 != 0 || (unsigned long long)V * YB >= (1ull << 32)) return 0;   // full tiles; 32-bit row offsets inside a sample
+    if (V <= 0 || V % 64 != 0 || (unsigned long long)V * 256ull >= (1ull << 32)) return 0;   // full tiles; 32-bit row offsets inside a sample
     if (plan_t->max_n2 > 255 || plan_t->max_n1 < 64) return 0;     // u8 list positions in the ELL; the handoff slot is 64 rows of the U_1 buffer
     if (dual_lds_bytes(plan_t) > 80 * 1024) return 0;              // two workgroups per CU or not at all
     const int nst = (plan_t->max_n2 + RPP - 1) / RPP, ns1 = (plan_t->max_n1 + RPP - 1) / RPP;
@@ -591,11 +608,7 @@ int dsw_cheb3_bwd_dual_try(const dsw_hop2_plan* plan_t, int64_t V, const void* X
     const long nwg = dual_grid((long)plan_t->n_tiles * A.n_chunks);
     const size_t lds = dual_lds_bytes(plan_t);
     const int nst = (plan_t->max_n2 + RPP - 1) / RPP, ns1 = (plan_t->max_n1 + RPP - 1) / RPP;
-    int r;
-    if (nst == 3 && ns1 == 2) r = launch_dual<3, 2>(A, nwg, lds, stream);
-    else if (nst == 2 && ns1 <= 2) r = launch_dual<2, 2>(A, nwg, lds, stream);
-    else if (nst == 3) r = launch_dual<3, 3>(A, nwg, lds, stream);
-    else r = launch_dual<4, 4>(A, nwg, lds, stream);
+    int r = Fout == 64 ? launch_dual_n<2>(nst, ns1, A, nwg, lds, stream) : launch_dual_n<1>(nst, ns1, A, nwg, lds, stream);
     if (r == DSW_OK && dW != nullptr)
         r = dsw_wgrad_reduce_launch(partial, nwg, Fin, Fout, K, dW, db, K, 0, 1 << 30, dtype, stream, accumulate);
     *rc = r;

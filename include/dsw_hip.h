@@ -309,8 +309,8 @@ int dsw_cheb_fwd_ws(const int32_t* rowptr, const int32_t* colind, const float* v
 int dsw_relu_bwd(const void* dY, const void* Y, void* dYm, int64_t n, int dtype, dsw_stream_t stream);
 
 /* 0 if dsw_cheb_bwd of this layer shape works WITHOUT the forward's basis planes (T = NULL): mix-first layers, K = 1, and
- * layers whose whole backward runs in one launch in the dual form (dsw_bwd3d.hip: fp32, K = 3, 32 -> 64, two-hop plan of
- * L^T, V % 64 == 0):
+ * layers whose whole backward runs in one launch in the dual form (dsw_bwd3d.hip: fp32, K = 3, 32 -> 64 or - round 6 -
+ * 32 -> 32, two-hop plan of L^T, V % 64 == 0):
  *     U_k = T_k(L^T) dY on chip,   dX = sum_k U_k W_k^T,   dW_k = X^T U_k,   db = 1^T dY
  * - X and dY in, dX out, no T_1 / T_2 and no dgrad planes.  The forward of such a layer may then be called with T = NULL
  * (dsw_cheb_fwd: "inference" form, the basis is not stored).  1: T is required.  plan_t: the plan dsw_cheb_bwd will get. */

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _layer(nside, knn=8, seed=0, lap=None):
+def _layer(nside, knn=8, seed=0, lap=None, fout=64):
     from dsw_amd import sphere
     from modules.layers import ConvCheb, prepare_torch_laplacian
 
@@ -20,7 +20,7 @@ def _layer(nside, knn=8, seed=0, lap=None):
         g = sphere.SphereHealpix(nside, nest=True, k=knn)
         lap = prepare_torch_laplacian(g.L, lmax=1.9)
     torch.manual_seed(seed)
-    return ConvCheb(32, 64, 3, laplacian=lap).to(DEV)
+    return ConvCheb(32, fout, 3, laplacian=lap).to(DEV)
 
 
 def _needs_basis(layer, x):
@@ -28,7 +28,7 @@ def _needs_basis(layer, x):
 
     op = F_.get_operator(layer.laplacian)
     pt, _keep = F_._plan_ptr(op.transpose(), x, 32)
-    return int(_native.load().dsw_cheb_bwd_needs_basis(pt, x.shape[1], 32, 64, 3, 0))
+    return int(_native.load().dsw_cheb_bwd_needs_basis(pt, x.shape[1], 32, layer.out_channels, 3, 0))
 
 
 def _oracle(layer, x, gy):
@@ -38,19 +38,20 @@ def _oracle(layer, x, gy):
     return orc.cheb_backward_f64(rp, ci, va, x.detach().cpu().numpy(), layer.weight.detach().cpu().numpy(), gy.cpu().numpy(), True)
 
 
-@pytest.mark.parametrize("nside,B", [(8, 1), (8, 3), (16, 5), (16, 16)])
-def test_dual_backward_vs_oracle(nside, B, monkeypatch):
+@pytest.mark.parametrize("nside,B,fout", [(8, 1, 64), (8, 3, 64), (16, 5, 64), (16, 16, 64), (8, 3, 32), (16, 7, 32)])
+def test_dual_backward_vs_oracle(nside, B, fout, monkeypatch):
     """Module-level forward + backward of the eligible shape: the launch trace shows ONE backward role (bwd_dual: no dgrad
     planes, no adjoint launches), the forward keeps no basis planes, dX / dW / db agree with the fp64 closed form in every
-    element (odd sample counts and batch chunks included), reruns are bit-identical."""
+    element (odd sample counts and batch chunks included), reruns are bit-identical.  Fout = 32 (round 6): ONE chunk phase per
+    sample, the whole dX reduction in waves 0-3."""
     from dsw_amd import _native, functional as F_
     from oracle import cheb_oracle as orc
 
     monkeypatch.setattr(F_, "MIN_CLUSTERED_TILES", 1)
-    layer = _layer(nside, seed=nside + B)
+    layer = _layer(nside, seed=nside + B, fout=fout)
     V = 12 * nside * nside
     x = torch.randn(B, V, 32, device=DEV, requires_grad=True)
-    gy = torch.randn(B, V, 64, device=DEV)
+    gy = torch.randn(B, V, fout, device=DEV)
     assert _needs_basis(layer, x) == 0
     layer(x).backward(gy)                      # (plans built, caches warm)
     grads = []
@@ -105,7 +106,8 @@ def test_dual_backward_partial_requests_and_accumulation(monkeypatch):
     assert orc.max_rel_err(ab - 2.0, full[2].cpu().numpy()) <= 1e-6
 
 
-def test_dual_backward_non_symmetric_operator(monkeypatch):
+@pytest.mark.parametrize("fout", [64, 32])
+def test_dual_backward_non_symmetric_operator(fout, monkeypatch):
     """The dual form runs its hops with L^T (the plan of the transposed operator) and its weight gradient with X^T T_k(L^T) dY
     = (T_k(L) X)^T dY: a NON-symmetric L (random row scaling of a HEALPix Laplacian) pins both against the oracle."""
     from scipy import sparse
@@ -119,9 +121,9 @@ def test_dual_backward_non_symmetric_operator(monkeypatch):
     L = sparse.diags(rng.uniform(0.3, 1.2, L.shape[0])) @ L * 0.5
     L = sparse.csr_matrix(L).astype(np.float32)
     L.sort_indices()
-    layer = _layer(8, seed=3, lap=orc.coo_from_scipy(L).float())
+    layer = _layer(8, seed=3, lap=orc.coo_from_scipy(L).float(), fout=fout)
     x = torch.randn(4, 768, 32, device=DEV, requires_grad=True)
-    gy = torch.randn(4, 768, 64, device=DEV)
+    gy = torch.randn(4, 768, fout, device=DEV)
     assert _needs_basis(layer, x) == 0
     layer(x).backward(gy)
     dx64, dw64, db64 = _oracle(layer, x, gy)
@@ -154,7 +156,8 @@ def test_forward_without_basis_planes_is_the_same_forward(monkeypatch):
     assert T20 is not None
 
 
-def test_dual_backward_equals_the_basis_route_at_full_size():
+@pytest.mark.parametrize("fout", [64, 32])
+def test_dual_backward_equals_the_basis_route_at_full_size(fout):
     """North-star shape (nside 64, B 16): the dual launch against dsw_cheb_bwd on the forward's basis planes WITHOUT a plan
     (dgrad GEMM, plain adjoint hops, wgrad from T_k: a route that shares no kernel with it) in every element of dX, dW, db;
     dsw_cheb_bwd with T = NULL and no plan is refused (every other route reads the planes)."""
@@ -166,7 +169,7 @@ def test_dual_backward_equals_the_basis_route_at_full_size():
     g = sphere.SphereHealpix(64, nest=True, k=8)
     op = F_.get_operator(prepare_torch_laplacian(g.L, lmax=1.95).to(DEV))
     opt = op.transpose()
-    B, V, fin, K, fout = 16, op.shape[0], 32, 3, 64
+    B, V, fin, K = 16, op.shape[0], 32, 3
     torch.manual_seed(11)
     x = torch.randn(B, V, fin, device=DEV)
     w = torch.randn(fin, K, fout, device=DEV) * 0.1

@@ -12,7 +12,7 @@ from modules.layers import prepare_torch_laplacian
 
 nside = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-fin, fout, K = 32, 64, 3
+fin, fout, K = 32, (32 if "--fout32" in sys.argv else 64), 3
 lib = _native.load()
 g = sphere.SphereHealpix(nside, nest=True, k=8)
 op = F_.get_operator(prepare_torch_laplacian(g.L, lmax=1.95).to("cuda"))
