@@ -281,6 +281,21 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_bwd_dual_kernel(const DualA
     for (int s = 0; s < 3; ++s) dwa[s] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if (tid < 64) dbs[tid] = 0.f;                    // (published by the first barrier of the item loop)
 
+#ifdef DSW_D3_SKEW
+    // A/B builds: the two workgroups of a CU start in step and stay in step - both in their LDS-bound hop phases, then both in
+    // the matrix phase; one of them starts DSW_D3_SKEW cycles late so that one's hops run under the other's matrix phase.
+    // DSW_D3_SKEW_MODE 0: the upper half of the grid (the second workgroup of every CU if the dispatcher fills CU slots in order),
+    // 1: odd (blockIdx.x >> 3), 2: odd blockIdx.x >> 4
+    {
+#ifndef DSW_D3_SKEW_MODE
+#define DSW_D3_SKEW_MODE 0
+#endif
+        const bool late = DSW_D3_SKEW_MODE == 0 ? (blockIdx.x >= gridDim.x / 2)
+                          : DSW_D3_SKEW_MODE == 1 ? (((blockIdx.x >> 3) & 1u) != 0u) : (((blockIdx.x >> 4) & 1u) != 0u);
+        if (late)
+            for (int i = 0; i < DSW_D3_SKEW / 1024; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     const long n_items = (long)P.n_tiles * P.n_chunks;
     const long q8 = n_items >> 3, r8 = n_items & 7;
     for (long orig = blockIdx.x; orig < n_items; orig += gridDim.x) {
@@ -546,7 +561,11 @@ int launch_dual_n(const int nst, const int ns1, const DualArgs& A, long nwg, siz
 
 // persistent workgroups: two per CU, a multiple of 8 (one XCD per residue class), never more than there are items
 long dual_grid(long n_items) {
+#ifdef DSW_D3_WG_PER_CU     // A/B builds: how much of a workgroup's time is waiting that a second workgroup fills
+    long g = DSW_D3_WG_PER_CU * dsw_device_cus();
+#else
     long g = 2 * dsw_device_cus();
+#endif
     g -= g % 8;
     if (g < 8) g = 8;
     return n_items < g ? n_items : g;

@@ -234,6 +234,12 @@ __global__ __launch_bounds__(NTHREADS, 4) void cheb3_fwd_fused_kernel(const Fwd3
     int* tile_w = rows + ((P.max_n2 + 3) & ~3);
 
     const long nwg = gridDim.x, orig = blockIdx.x;                          // XCD-aware order (see dsw_spmm2.hip)
+#ifdef DSW_F3_SKEW
+    // A/B builds: the second workgroup of every CU (first round of the grid: blocks 256..511 on a 256-CU part) starts late, so
+    // that its LDS-bound hop phases run under the other workgroup's matrix phase; later rounds inherit the offset
+    if (blockIdx.x >= 256u && blockIdx.x < 512u)
+        for (int i = 0; i < DSW_F3_SKEW / 1024; ++i) __builtin_amdgcn_s_sleep(16);
+#endif
     const long q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
     const long wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
     const int tile = (int)(wg / P.n_chunks);
