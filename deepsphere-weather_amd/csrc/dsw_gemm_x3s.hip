@@ -97,12 +97,21 @@ __global__ __launch_bounds__(64 * NWV, (PRE || NWV == 8) ? 2 : 1) void ts_gemm_x
     constexpr int NPAIR = (16 * BNT + NTH - 1) / NTH;  // (k, k+1) element pairs of one W chunk per thread
     constexpr bool BTAIL = (16 * BNT) % NTH != 0;      // last slot only partly populated (6- and 7-wave workgroups)
     constexpr int BPLANE = BNT * KSB;                  // one bf16 plane of one B buffer
+    // DIRECT (pre-split W, 8 waves): the A rows never touch LDS.  A lane loads, straight from HBM / L2, exactly the 2 x 8 values of
+    // its row that the MFMA operand layout gives it (k = 16 s2 + 8 half .. + 7) - the same four 16-byte loads per lane and chunk
+    // as the staged form, but no ds_write pass, no fragment reads, no A buffers: 61 KB of LDS instead of 134, so TWO workgroups
+    // share a CU and run under each other's waits.
+#ifdef DSW_X3S_NO_DIRECT
+    constexpr bool DIRECT = false;
+#else
+    constexpr bool DIRECT = PRE && NWV == 8;
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                                               // [2][BMT][LDA]
+    float* As = smem;                                                               // [2][BMT][LDA] (not DIRECT)
     // A rows are wave-private (a wave stages and reads only its own 32 rows, LDS operations of a wave complete in order): the
     // 4-wave shape keeps ONE A buffer - chunk it+1 is stored behind the fragment reads of chunk it - and with 78 KB of LDS
     // two of its workgroups share a CU, each with its own barrier: one's staging runs under the other's MFMAs.
-    constexpr int NABUF = NWV == 4 ? 1 : 2;
+    constexpr int NABUF = DIRECT ? 0 : NWV == 4 ? 1 : 2;
     unsigned short* Bt = reinterpret_cast<unsigned short*>(smem + NABUF * BMT * LDA);   // [2][3][BNT][KSB]
 
     const int tid = threadIdx.x;
@@ -244,11 +253,19 @@ __global__ __launch_bounds__(64 * NWV, (PRE || NWV == 8) ? 2 : 1) void ts_gemm_x
     unsigned arow_off[4];
     auto fetch = [&](f32x4 (&dra)[4]) __attribute__((always_inline)) {   // A rows of chunk `pre`, then advance it
         if (pre.c == 0 || pre.it == 0) {                                // uniform: first chunk of a row tile / of the range
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                long r = pre.row0 + ar + 8 * i;
+            if constexpr (DIRECT) {
+                long r = pre.row0 + wave * 32 + l31;                    // this lane's row of the wave's 32; its k-halves: 8 half + 16 s2
                 r = r < P.M ? r : P.M - 1;
-                arow_off[i] = (unsigned)(((size_t)r * P.lda + ac4) * 4);    // < 4 GiB (checked by the launcher)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    arow_off[i] = (unsigned)(((size_t)r * P.lda + 8 * half + 16 * (i >> 1) + 4 * (i & 1)) * 4);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    long r = pre.row0 + ar + 8 * i;
+                    r = r < P.M ? r : P.M - 1;
+                    arow_off[i] = (unsigned)(((size_t)r * P.lda + ac4) * 4);    // < 4 GiB (checked by the launcher)
+                }
             }
         }
         const char* abase = reinterpret_cast<const char*>(static_cast<const float*>((pre.p == 0) ? P.A0 : P.A1) +
@@ -267,7 +284,10 @@ __global__ __launch_bounds__(64 * NWV, (PRE || NWV == 8) ? 2 : 1) void ts_gemm_x
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&abuf[(ar + 8 * i) * LDA + ac4]) = slot[i];
     };
-    if constexpr (PRE) {
+    if constexpr (DIRECT) {
+        dma_b(0);
+        fetch(ra0); fetch(ra1); fetch(ra2);     // chunks 0, 1, 2: stage it multiplies ring slot it % 3 and refills it with chunk it + 3
+    } else if constexpr (PRE) {
         dma_b(0);                      // chunk 0 -> pair 0; chunk it+1 follows at the top of stage it
         fetch(ra0); fetch(ra1); fetch(ra2);
         store_a(As, ra0);
@@ -305,10 +325,20 @@ __global__ __launch_bounds__(64 * NWV, (PRE || NWV == 8) ? 2 : 1) void ts_gemm_x
         if constexpr (PRE) dma_b(par ^ 1);     // chunk it+1 -> the other pair, under the MFMAs of this one
         const float* arow = &abuf[(wave * 32 + l31) * LDA + 8 * half];
         const unsigned short* brow = bbuf + (size_t)l31 * KSB + 8 * half;
+        f32x4 (&cslot)[4] = *[&]() -> f32x4 (*)[4] {          // DIRECT: the ring slot of chunk `it` itself
+            if constexpr (decltype(U)::value == 0) return &ra0;
+            else if constexpr (decltype(U)::value == 1) return &ra1;
+            else return &ra2;
+        }();
 #pragma unroll
         for (int s2 = 0; s2 < BK / 16; ++s2) {
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(arow + 16 * s2);
-            const f32x4 x1 = *reinterpret_cast<const f32x4*>(arow + 16 * s2 + 4);
+            f32x4 x0, x1;
+            if constexpr (DIRECT) {
+                x0 = cslot[2 * s2]; x1 = cslot[2 * s2 + 1];
+            } else {
+                x0 = *reinterpret_cast<const f32x4*>(arow + 16 * s2);
+                x1 = *reinterpret_cast<const f32x4*>(arow + 16 * s2 + 4);
+            }
             const float f[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
             float r1[8], r2[8];
 #pragma unroll
@@ -333,11 +363,15 @@ __global__ __launch_bounds__(64 * NWV, (PRE || NWV == 8) ? 2 : 1) void ts_gemm_x
                 acc[nt] = a_;
             }
         }
-        // chunk it+1 -> the other pair, then refill its ring slot with chunk it+4
-        store_b(Bt + (size_t)(par ^ 1) * 3 * BPLANE, bslot);
-        store_a(As + (size_t)(NABUF == 2 ? (par ^ 1) : 0) * BMT * LDA, slot);
-        fetch_b(bslot);
-        fetch(slot);
+        if constexpr (DIRECT) {
+            fetch(cslot);       // chunk it + 3 into the slot just multiplied
+        } else {
+            // chunk it+1 -> the other pair, then refill its ring slot with chunk it+4
+            store_b(Bt + (size_t)(par ^ 1) * 3 * BPLANE, bslot);
+            store_a(As + (size_t)(NABUF == 2 ? (par ^ 1) : 0) * BMT * LDA, slot);
+            fetch_b(bslot);
+            fetch(slot);
+        }
         const bool tile_end = cur.c == total - 1;
         bool finish = tile_end && it < n_iter;
         if (sk && it < n_iter && (tile_end || it == n_iter - 1) && !(seg_first && tile_end)) {
@@ -440,7 +474,12 @@ int launch_x3s(const TsGemmParams& P0, int col_tiles, hipStream_t stream, char* 
     { static const char* d = dsw_diag_env("DSW_DBG"); P.dbg = d ? atoi(d) : 0; }
 #endif
     constexpr int BMT = 32 * NWV;
-    const size_t lds = (size_t)(NWV == 4 ? 1 : 2) * BMT * LDA * 4 + (size_t)2 * 3 * (32 * NT) * KSB * 2;
+#ifdef DSW_X3S_NO_DIRECT
+    constexpr bool DIRECT = false;
+#else
+    constexpr bool DIRECT = PRE && NWV == 8;
+#endif
+    const size_t lds = (size_t)(DIRECT ? 0 : NWV == 4 ? 1 : 2) * BMT * LDA * 4 + (size_t)2 * 3 * (32 * NT) * KSB * 2;
     const long row_tiles = (P.M + BMT - 1) / BMT;
     const void* kfn = (const void*)ts_gemm_x3s_kernel<NT, NWV, KFAST, RES, PRE>;
     if (lds > 64 * 1024 &&
