@@ -7,7 +7,8 @@
 // Workgroup = NWV waves, tile = (32 * NWV rows) x (32 * NT columns); a wave owns 32 rows and NT MFMA tiles.
 // Per 32-wide reduction chunk:
 //   A: 3-deep register prefetch ring -> the wave's private staging rows in LDS (no workgroup barrier), split
-//      into bf16 terms in registers right before the MFMAs (as in the resident kernel);
+//      into bf16 terms in registers right before the MFMAs (as in the resident kernel); round 6, 8-wave form with the
+//      pre-split W image (DIRECT): the ring IS the operand - a lane loads its 2 x 8 values of the MFMA layout, no LDS;
 //   B: the chunk's [32 k][32 * NT cols] fp32 block of W is fetched one chunk ahead into registers, split ONCE per
 //      workgroup into three bf16 planes and written to LDS as [plane][col][k] (k contiguous, 80-byte rows ->
 //      conflict-free ds_read_b128), double buffered: one workgroup barrier per chunk.
@@ -347,12 +348,29 @@ __global__ __launch_bounds__(64 * NWV, (PRE || NWV == 8) ? 2 : 1) void ts_gemm_x
                 r2[j] = r1[j] - trunc_bf16(r1[j]);
             }
             const bf16x8_t ah = pack_trunc8(f), am = pack_trunc8(r1), al = pack_trunc8(r2);
+#ifdef DSW_X3S_BFRAG_ALL
+            // A/B build: every W fragment of this k-step requested before its first MFMA (48 registers of the 70 this kernel leaves
+            // unused at two waves per SIMD), instead of one column tile ahead
+            bf16x8_t fbh[NT], fbm[NT], fbl[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const unsigned short* bp_ = brow + (size_t)(32 * nt) * KSB + 16 * s2;
+                fbh[nt] = *reinterpret_cast<const bf16x8_t*>(bp_);
+                fbm[nt] = *reinterpret_cast<const bf16x8_t*>(bp_ + BPLANE);
+                fbl[nt] = *reinterpret_cast<const bf16x8_t*>(bp_ + 2 * BPLANE);
+            }
+#endif
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const unsigned short* bp_ = brow + (size_t)(32 * nt) * KSB + 16 * s2;
+#ifdef DSW_X3S_BFRAG_ALL
+                const bf16x8_t bh = fbh[nt], bm = fbm[nt], bl = fbl[nt];
+                (void)bp_;
+#else
                 const bf16x8_t bh = *reinterpret_cast<const bf16x8_t*>(bp_);
                 const bf16x8_t bm = *reinterpret_cast<const bf16x8_t*>(bp_ + BPLANE);
                 const bf16x8_t bl = *reinterpret_cast<const bf16x8_t*>(bp_ + 2 * BPLANE);
+#endif
                 f32x16 a_ = acc[nt];
                 a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, a_, 0, 0, 0);
                 a_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, a_, 0, 0, 0);
@@ -363,6 +381,17 @@ __global__ __launch_bounds__(64 * NWV, (PRE || NWV == 8) ? 2 : 1) void ts_gemm_x
                 acc[nt] = a_;
             }
         }
+#ifdef DSW_X3S_BFRAG_ALL
+        // order of the region: the 3 NT fragment reads of k-step 0 first; the reads of k-step 1 trickle in, one behind every
+        // two MFMAs of k-step 0 (their registers free up as they go); then the MFMAs of k-step 1
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * NT, 0);
+#pragma unroll
+        for (int i = 0; i < 3 * NT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * NT, 0);
+#endif
         if constexpr (DIRECT) {
             fetch(cslot);       // chunk it + 3 into the slot just multiplied
         } else {
