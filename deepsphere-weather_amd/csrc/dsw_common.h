@@ -55,7 +55,7 @@ static inline const char* dsw_diag_env(const char*) { return nullptr; }
     defined(DSW_ABL_F3_NOSPLIT) || defined(DSW_F3_PLAIN_STORE) || defined(DSW_ABL_F3_NOLOAD) || defined(DSW_ABL_F3_NOSTORE) || defined(DSW_ABL_F3_NOMFMA) || defined(DSW_ABL_B3_NOSPLIT) || \
     defined(DSW_ABL_B3_NOGATHER) || defined(DSW_ABL_B3_NOMFMA) || defined(DSW_STAGE_EARLY) || defined(DSW_ABL_B3_NOLOAD) || defined(DSW_ABL_B3_NOFRAG) || \
     defined(DSW_GATHER_N) || defined(DSW_F3_YBOUNCE) || defined(DSW_F3_SKEW) || defined(DSW_D3_SKEW) || defined(DSW_D3_WG_PER_CU) || \
-    defined(DSW_D3_NO_FOUT32) || defined(DSW_X3S_NO_DIRECT) || defined(DSW_X3S_BFRAG_ALL)   /* round-6 A/B switches (correct results, other schedules) */
+    defined(DSW_D3_NO_FOUT32) || defined(DSW_X3S_NO_DIRECT) || defined(DSW_X3S_BFRAG_ALL) || defined(DSW_ABL_X3S_NOB) || defined(DSW_X3S_LB4) || defined(DSW_X3S_FORCE_NT2)   /* round-6 A/B switches (correct results, other schedules) */
 #define DSW_TU_F_ABL DSW_FLAG_ABLATION
 #else
 #define DSW_TU_F_ABL 0

@@ -90,7 +90,12 @@ __global__ void x3s_presplit_kernel(const TsGemmParams P, unsigned* __restrict__
 // KFAST: the B operand is contiguous along the reduction index (dgrad: W^T), else along the columns (forward).
 // PRE: the W chunk comes pre-split from TsGemmParams::pre_ws (x3s_presplit_kernel) - three ready-made dwords per slot.
 template <int NT, int NWV, bool KFAST, bool RES = false, bool PRE = false>
-__global__ __launch_bounds__(64 * NWV, (PRE || NWV == 8) ? 2 : 1) void ts_gemm_x3s_kernel(const TsGemmParams P) {
+#ifdef DSW_X3S_LB4     // A/B builds: 128 registers per lane, two 8-wave workgroups per CU (with -DDSW_X3S_FORCE_NT2: 64-column tiles)
+#define DSW_X3S_WAVES_PER_EU(pre_, nwv_) 4
+#else
+#define DSW_X3S_WAVES_PER_EU(pre_, nwv_) (((pre_) || (nwv_) == 8) ? 2 : 1)
+#endif
+__global__ __launch_bounds__(64 * NWV, DSW_X3S_WAVES_PER_EU(PRE, NWV)) void ts_gemm_x3s_kernel(const TsGemmParams P) {
     constexpr int BMT = 32 * NWV;
     constexpr int NTH = 64 * NWV;
     constexpr int BNT = 32 * NT;
@@ -197,9 +202,16 @@ __global__ __launch_bounds__(64 * NWV, (PRE || NWV == 8) ? 2 : 1) void ts_gemm_x
     constexpr int IMG_BYTES = 3 * BPLANE * 2;
     constexpr int NPIECE = IMG_BYTES / 1024;
     static_assert(IMG_BYTES % 1024 == 0, "whole 1 KiB pieces");
+#ifdef DSW_ABL_X3S_NOB
+    int abl_nob = 0;
+#endif
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const unsigned bt_lds = (unsigned)reinterpret_cast<uintptr_t>(Bt);
     auto dma_b = [&](const int buf) __attribute__((always_inline)) {
+#ifdef DSW_ABL_X3S_NOB      // timing experiment (wrong results): the W image is copied for the first two chunks only - what does its stream cost?
+        if (abl_nob >= 2) { if (++bkc == chunks) { bkc = 0; if (++bp == P.n_planes_a) bp = 0; } return; }
+        ++abl_nob;
+#endif
         const char* src = static_cast<const char*>(P.pre_ws) + (((long)bp * chunks + bkc) * gridDim.y + blockIdx.y) * (long)IMG_BYTES + lane * 16;
         const unsigned dst = bt_lds + (unsigned)buf * IMG_BYTES;
 #pragma unroll
@@ -592,6 +604,9 @@ int dsw_ts_gemm_x3s_try_launch(const TsGemmParams& P, hipStream_t stream, int* r
     int nt = n_total > 64 ? 4 : 2;
     if (nt == 4 && row_tiles8 * ((n_total + 127) / 128) < 128) nt = 2;
     if (ntenv) nt = ntenv[0] == '2' ? 2 : (n_total > 64 ? 4 : 2);
+#ifdef DSW_X3S_FORCE_NT2
+    nt = 2;
+#endif
     const int col_tiles = (n_total + 32 * nt - 1) / (32 * nt);
     const long tiles8 = row_tiles8 * col_tiles;
     // one column tile + the pre-split image: two 4-wave workgroups per CU (one A buffer: 78 KB of LDS each) beat one 8-wave
